@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- HQP control cycles/s on batched TOCABI states (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the fused hot path (UpdateKinematics .. CalcContactRedistribute, one kernel launch) over one
+batch of B synthetic TOCABI states that are already resident in HBM.  N = 1 workload = BASELINE.json configs[1]:
+batch = 1024, double support, 2-level HQP (pelvis 6D, upper-body rotation), tau limit 300, fp64.
+N > 1: every rank solves its own B instances (weak scaling, no data-path collective); the only collective is the
+final RCCL all_gather of (tau[33], wrench[12], status) of the last step, inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit (SURVEY 8d / BASELINE.md 3)
+PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    import libdwbc_amd as D
+    from tests import cases
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    B = args.batch
+
+    model = D.Model.from_urdf(cases.URDF)
+    wbc = D.Batch(model, B, device=local_rank)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+
+    q, flags, fstar = cases.synth_batch(B, seed=20251226 + 2 + 1000 * rank)
+    tq = torch.from_numpy(q).to(dev)
+    tf = torch.from_numpy(flags).to(dev)
+    ts = torch.from_numpy(fstar).to(dev)
+    # outputs packed per instance as [tau(3x33) | wrench(12) | status] for the final gather
+    ttau = torch.zeros((B, 3, 33), dtype=torch.float64, device=dev)
+    twr = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+    tst = torch.zeros((B,), dtype=torch.int32, device=dev)
+    for name, t in (("in_q", tq), ("in_contact", tf), ("in_fstar", ts), ("tau", ttau), ("wrench", twr), ("status", tst)):
+        wbc.bind_tensor(name, t)
+    stream = torch.cuda.current_stream()
+    wbc.set_stream(stream.cuda_stream)
+
+    def gather_final():
+        if world == 1:
+            return None
+        pack = torch.cat([ttau.sum(dim=1), twr, tst.to(torch.float64)[:, None]], dim=1).contiguous()  # B x 46
+        out = torch.empty((world * B, pack.shape[1]), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, pack)
+        return out
+
+    for _ in range(args.warmup):
+        wbc.solve()
+    gather_final()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wbc.solve()
+    gather_final()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    status_ok = float(tst.float().mean().item())
+
+    # kernel-only time with HIP events on the launch stream (roofline.achieved)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(args.steps):
+        wbc.solve()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        achieved = F_ALG * B / (kern_ms * 1e-3) / 1e12
+        nt, lds = wbc.launch_info()
+        line = {
+            "metric": "HQP control cycles/sec (batched TOCABI)",
+            "value": value,
+            "unit": "cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: batch=1024 per GPU, TOCABI double support, 2-level HQP (pelvis 6D + upper-body rotation), tau limit 300, fp64",
+                "batch_per_gpu": B,
+                "threads_per_instance": nt,
+                "lds_bytes_per_instance": lds,
+                "status_ok_fraction": status_ok,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_TFLOPS,
+                "traffic": None,
+                "kernel": "dwbc_cycle_kernel<39,34,64>",
+                "kernel_ms": kern_ms,
+                "flop_per_cycle": F_ALG,
+                "note": "fp64 FMA roof (vector = matrix rate on MI355X, public spec 78.6 TFLOP/s); algorithmic flop of the reference's dense formulas",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc
+
+            M = orc.make_model(cases.tocabi_model())
+            S = orc.make_setup(cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+            cores = len(os.sched_getaffinity(0))
+            qs, fls, fss = cases.synth_batch(2048, seed=20251226 + 2)
+            orc.cycle_batch(M, S, qs[:64], fls[:64], fss[:64], cores)
+            done, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < args.cpu_seconds:
+                orc.cycle_batch(M, S, qs, fls, fss, cores)
+                done += qs.shape[0]
+            cdt = time.perf_counter() - t1
+            t2 = time.perf_counter()
+            orc.cycle_batch(M, S, qs[:512], fls[:512], fss[:512], 1)
+            single = 512 / (time.perf_counter() - t2)
+            line["cpu_baseline"] = {
+                "value": done / cdt,
+                "unit": "cycles/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{done} cycles of the same workload (2048-instance seeded batches repeated for {cdt:.1f} s), "
+                          f"oracle/dwbc_oracle.c -O3 OpenMP over instances; single thread: {single:.0f} cycles/s",
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/*
+ * dwbc_batch.h -- C-ABI of the MI355X-native batched libdwbc hot path (libdwbc_hip.so).
+ *
+ * The reference (saga0619/libdwbc) has no FFI: its boundary is the C++ class DWBC::RobotData
+ * (reference include/dwbc.h:59-430).  Each entry point below replaces the RobotData method cited next to
+ * it, for B independent robot instances at once; include/dwbc_amd.hpp is the header-only C++ facade that
+ * gives the RobotData names/arguments back on top of this ABI (B = 1 reproduces single-robot behaviour).
+ *
+ * Conventions (same as the reference): q = [x y z | qx qy qz | joints | qw] (size ndof+1), qdot/qddot size
+ * ndof with the base angular velocity in the body frame; Jacobian rows / wrenches are [linear; angular] in
+ * the world frame; int returns are 1 = ok, 0 = failure (no exceptions); failures leave a message in
+ * dwbc_last_error().  Host arrays are instance-major (AoS), double precision.
+ * Not thread-safe per object (one dwbc_batch per thread), like RobotData.
+ */
+#ifndef DWBC_BATCH_H
+#define DWBC_BATCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dwbc_model dwbc_model;
+typedef struct dwbc_batch dwbc_batch;
+
+/* contact types: reference include/dwbc_contact_constraint.h:19-25 */
+enum { DWBC_CONTACT_6D = 0, DWBC_CONTACT_POINT = 1, DWBC_CONTACT_LINK = 2, DWBC_CONTACT_LINE = 3 };
+/* task link modes: reference include/dwbc_task.h:23-33 */
+enum {
+    DWBC_TASK_LINK_6D = 0, DWBC_TASK_LINK_6D_COM_FRAME, DWBC_TASK_LINK_6D_CUSTOM_FRAME,
+    DWBC_TASK_LINK_POSITION, DWBC_TASK_LINK_POSITION_COM_FRAME, DWBC_TASK_LINK_POSITION_CUSTOM_FRAME,
+    DWBC_TASK_LINK_ROTATION, DWBC_TASK_LINK_ROTATION_CUSTOM_FRAME
+};
+enum { DWBC_F64 = 0 };
+enum { DWBC_SOLVE_HQP = 1, DWBC_SOLVE_INIT = 2 };
+
+/* fields for dwbc_batch_get / dwbc_batch_bind_device.  Shapes are per instance, row-major. */
+enum dwbc_field {
+    /* inputs (bindable) */
+    DWBC_IN_Q = 0,        /* (ndof+1)        f64  -- UpdateKinematics(q, ...)          */
+    DWBC_IN_CONTACT = 1,  /* (n_contacts)    u8   -- SetContact(...)                   */
+    DWBC_IN_FSTAR = 2,    /* (sum task dof)  f64  -- SetTaskSpace(level, f*) concatenated */
+    /* outputs (bindable) */
+    DWBC_TAU = 10,        /* (3, m) f64: torque_grav_, torque_task_, torque_contact_  (include/dwbc.h:115-117) */
+    DWBC_WRENCH = 11,     /* (12)   f64: getContactForce(tau_total), zero padded       (src/dwbc.cpp:891-896) */
+    DWBC_STATUS = 12,     /* (1)    i32: 1 ok / 0 failed                               */
+    DWBC_DIAG = 13,       /* (74)   i32: stage status, QP iterations, working sets     */
+    /* derived getters (host only) */
+    DWBC_TAU_GRAV = 20, DWBC_TAU_TASK = 21, DWBC_TAU_CONTACT = 22, DWBC_TAU_TOTAL = 23,
+    /* intermediates, available after a solve with dwbc_batch_enable_dump(b, 1) -- the RobotData public fields */
+    DWBC_A = 30,          /* (n, n)   A_        */
+    DWBC_A_INV = 31,      /* (n, n)   A_inv_    */
+    DWBC_J_C = 32,        /* (12, n)  J_C       */
+    DWBC_LAMBDA_C = 33,   /* (12, 12) Lambda_contact (row stride = active contact dof) */
+    DWBC_J_C_INV_T = 34,  /* (12, n)  J_C_INV_T */
+    DWBC_A_INV_N_C = 35,  /* (n, n)   A_inv_N_C */
+    DWBC_W_INV = 36,      /* (m, m)   W_inv     */
+    DWBC_NWJW = 37,       /* (m, 6)   NwJw      */
+    DWBC_G = 38,          /* (n)      G_        */
+    DWBC_P_C = 39,        /* (12)     P_C       */
+    DWBC_LINK_R = 40,     /* (48, 9)  link_[i].rotm */
+    DWBC_LINK_P = 41,     /* (48, 3)  link_[i].xpos */
+    DWBC_FSTAR_QP = 42,   /* (4, 6)   ts_[l].f_star_qp_  */
+    DWBC_CONTACT_QP = 43, /* (4, 6)   ts_[l].contact_qp_ */
+    DWBC_CF_REDIS = 44,   /* (6)      cf_redis_qp_       */
+    DWBC_J_TASK = 45,     /* (4, 6, n) ts_[l].J_task_ (row stride n)       */
+    DWBC_LAMBDA_TASK = 46,/* (4, 36)  ts_[l].Lambda_task_ (row stride t_l) */
+    DWBC_J_KT = 47,       /* (4, m*6) ts_[l].J_kt_ (row stride t_l)        */
+    DWBC_QP_VIOL = 48,    /* (5)      worst normalised slack of each QP's returned point */
+    DWBC_DUMP_RAW = 49    /* whole dump record */
+};
+
+const char *dwbc_last_error(void);
+int dwbc_device_count(void);
+
+/* ---- model: RobotData::LoadModelData(urdf, floating, verbose)  reference include/dwbc.h:237, src/dwbc.cpp:102-252 */
+dwbc_model *dwbc_model_create_from_urdf(const char *urdf_path, int floating_base);
+/* same tree given as arrays (R_T: nb x 9 child->parent joint-frame rotation, inertia: nb x 9 about the com) */
+dwbc_model *dwbc_model_create_from_arrays(int nb, const int32_t *parent, const double *R_T, const double *p_T,
+                                          const double *axis, const double *mass, const double *com,
+                                          const double *inertia);
+void dwbc_model_destroy(dwbc_model *m);
+int dwbc_model_num_links(const dwbc_model *m);   /* link_num_   */
+int dwbc_model_system_dof(const dwbc_model *m);  /* system_dof_ */
+double dwbc_model_total_mass(const dwbc_model *m); /* total_mass_ */
+int dwbc_model_link_id(const dwbc_model *m, const char *name); /* case-insensitive, -1 if absent (src/dwbc.cpp:397-406) */
+const char *dwbc_model_link_name(const dwbc_model *m, int link);
+int dwbc_model_get_arrays(const dwbc_model *m, int32_t *parent, double *R_T, double *p_T, double *axis, double *mass,
+                          double *com, double *inertia);
+
+/* ---- batch of B RobotData instances sharing one model and one contact/task setup ---- */
+dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype);
+void dwbc_batch_destroy(dwbc_batch *b);
+int dwbc_batch_size(const dwbc_batch *b);
+
+/* AddContactConstraint(link, type, point, normal, lx, ly)  include/dwbc.h:259 ; SetFrictionRatio src/contact_constraint.cpp:93.
+ * returns the contact index or -1 */
+int dwbc_batch_add_contact(dwbc_batch *b, int link, int contact_type, const double point[3], double lx, double ly,
+                           double mu, double mu_z);
+int dwbc_batch_clear_contacts(dwbc_batch *b);                               /* ClearContactConstraint */
+/* AddTaskSpace(level, mode, link, point) include/dwbc.h:319 (same level twice appends a link, src/dwbc.cpp:592-600) */
+int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const double point[3]);
+int dwbc_batch_clear_tasks(dwbc_batch *b);                                  /* ClearTaskSpace */
+int dwbc_batch_set_torque_limit(dwbc_batch *b, const double *tau_lim);      /* SetTorqueLimit include/dwbc.h:249; NULL = unset */
+int dwbc_batch_fstar_size(const dwbc_batch *b);
+int dwbc_batch_task_dof(const dwbc_batch *b, int level);
+
+/* UpdateKinematics(q, qdot, qddot) include/dwbc.h:251 : q is B x (ndof+1); qdot/qddot may be NULL (unused by the torque path) */
+int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot);
+/* SetContact(bool...) include/dwbc.h:291 : flags is B x n_contacts */
+int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags);
+/* SetTaskSpace(level, f*) include/dwbc.h:333 : fstar is B x task_dof(level) */
+int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar);
+
+/* zero-copy: use a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr) for an input or output field */
+int dwbc_batch_bind_device(dwbc_batch *b, int field, void *device_ptr);
+int dwbc_batch_set_stream(dwbc_batch *b, void *hip_stream);
+int dwbc_batch_enable_dump(dwbc_batch *b, int on);
+
+/* CalcContactConstraint + CalcGravCompensation + CalcTaskControlTorque(hqp,init) + CalcContactRedistribute(hqp,init)
+ * (include/dwbc.h:280,246,349,298) as ONE fused kernel launch on the batch's stream (asynchronous). */
+int dwbc_batch_solve(dwbc_batch *b, unsigned flags);
+int dwbc_batch_sync(dwbc_batch *b);
+/* K back-to-back solves bracketed by HIP events on the batch's stream; returns total milliseconds in *ms */
+int dwbc_batch_time_solves(dwbc_batch *b, unsigned flags, int steps, float *ms);
+/* copy a field of all B instances to host memory (synchronises the stream) */
+int dwbc_batch_get(dwbc_batch *b, int field, void *host_out, size_t bytes);
+size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field);
+/* kernel launch geometry, for DESIGN.md / bench bookkeeping */
+int dwbc_batch_launch_info(const dwbc_batch *b, int *threads_per_instance, int *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+"""ctypes binding of libdwbc_hip.so -- the C-ABI declared in include/dwbc_batch.h.
+
+There is deliberately no fallback: if the HIP library is missing or there is no GPU, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdwbc_hip.so")
+
+# every symbol include/dwbc_batch.h declares: (name, restype, argtypes)
+_vp, _i, _d, _cp = C.c_void_p, C.c_int, C.c_double, C.c_char_p
+SYMBOLS = [
+    ("dwbc_last_error", _cp, []),
+    ("dwbc_device_count", _i, []),
+    ("dwbc_model_create_from_urdf", _vp, [_cp, _i]),
+    ("dwbc_model_create_from_arrays", _vp, [_i] + [_vp] * 7),
+    ("dwbc_model_destroy", None, [_vp]),
+    ("dwbc_model_num_links", _i, [_vp]),
+    ("dwbc_model_system_dof", _i, [_vp]),
+    ("dwbc_model_total_mass", _d, [_vp]),
+    ("dwbc_model_link_id", _i, [_vp, _cp]),
+    ("dwbc_model_link_name", _cp, [_vp, _i]),
+    ("dwbc_model_get_arrays", _i, [_vp] + [_vp] * 7),
+    ("dwbc_batch_create", _vp, [_vp, _i, _i, _i]),
+    ("dwbc_batch_destroy", None, [_vp]),
+    ("dwbc_batch_size", _i, [_vp]),
+    ("dwbc_batch_add_contact", _i, [_vp, _i, _i, _vp, _d, _d, _d, _d]),
+    ("dwbc_batch_clear_contacts", _i, [_vp]),
+    ("dwbc_batch_add_task", _i, [_vp, _i, _i, _i, _vp]),
+    ("dwbc_batch_clear_tasks", _i, [_vp]),
+    ("dwbc_batch_set_torque_limit", _i, [_vp, _vp]),
+    ("dwbc_batch_fstar_size", _i, [_vp]),
+    ("dwbc_batch_task_dof", _i, [_vp, _i]),
+    ("dwbc_batch_set_state", _i, [_vp, _vp, _vp, _vp]),
+    ("dwbc_batch_set_contact", _i, [_vp, _vp]),
+    ("dwbc_batch_set_fstar", _i, [_vp, _i, _vp]),
+    ("dwbc_batch_bind_device", _i, [_vp, _i, _vp]),
+    ("dwbc_batch_set_stream", _i, [_vp, _vp]),
+    ("dwbc_batch_enable_dump", _i, [_vp, _i]),
+    ("dwbc_batch_solve", _i, [_vp, C.c_uint]),
+    ("dwbc_batch_sync", _i, [_vp]),
+    ("dwbc_batch_time_solves", _i, [_vp, C.c_uint, _i, C.POINTER(C.c_float)]),
+    ("dwbc_batch_get", _i, [_vp, _i, _vp, C.c_size_t]),
+    ("dwbc_batch_field_bytes", C.c_size_t, [_vp, _i]),
+    ("dwbc_batch_launch_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  libdwbc_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return load().dwbc_last_error().decode()

@@ -1,0 +1,222 @@
+"""Host-side mirror of libdwbc's RobotData call sequence for a batch of B robots (reference include/dwbc.h).
+
+    model = Model.from_urdf(path)                      # RobotData::LoadModelData
+    wbc = Batch(model, B, device=0)
+    wbc.add_contact(link, point, lx, ly)               # AddContactConstraint
+    wbc.add_task(level, mode, link)                    # AddTaskSpace
+    wbc.set_torque_limit(lim)                          # SetTorqueLimit
+    wbc.set_state(q); wbc.set_contact(flags); wbc.set_fstar(level, f)   # UpdateKinematics / SetContact / SetTaskSpace
+    wbc.solve()                                        # CalcContactConstraint .. CalcContactRedistribute, one launch
+    tau = wbc.get("tau_total")
+
+All arithmetic happens in libdwbc_hip.so (hand-written HIP, gfx950).  torch is only used, optionally, to own
+device buffers and streams (bind_tensor) and for torch.distributed in bench.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+CONTACT_6D = 0
+TASK_LINK_6D, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME = 0, 1, 2
+TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME, TASK_LINK_POSITION_CUSTOM_FRAME = 3, 4, 5
+TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME = 6, 7
+SOLVE_HQP, SOLVE_INIT = 1, 2
+
+# field ids of include/dwbc_batch.h
+FIELDS = dict(
+    in_q=0, in_contact=1, in_fstar=2, tau=10, wrench=11, status=12, diag=13,
+    tau_grav=20, tau_task=21, tau_contact=22, tau_total=23,
+    A=30, A_inv=31, J_C=32, Lambda_c=33, J_C_INV_T=34, A_inv_N_C=35, W_inv=36, NwJw=37, G=38, P_C=39,
+    link_R=40, link_p=41, fstar_qp=42, contact_qp=43, cf_redis=44, J_task=45, Lambda_task=46, J_kt=47, qp_viol=48,
+)
+
+
+class DwbcError(RuntimeError):
+    pass
+
+
+def _check(ok):
+    if not ok:
+        raise DwbcError(_lib.last_error())
+
+
+class Model:
+    def __init__(self, handle):
+        self._L = _lib.load()
+        self._h = handle
+        self.nb = self._L.dwbc_model_num_links(handle)
+        self.ndof = self._L.dwbc_model_system_dof(handle)
+        self.total_mass = self._L.dwbc_model_total_mass(handle)
+
+    @classmethod
+    def from_urdf(cls, path, floating=True):
+        L = _lib.load()
+        h = L.dwbc_model_create_from_urdf(str(path).encode(), 1 if floating else 0)
+        if not h:
+            raise DwbcError(_lib.last_error())
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, m):
+        L = _lib.load()
+        arrs = [np.ascontiguousarray(m["parent"], np.int32)] + [
+            np.ascontiguousarray(m[k], np.float64) for k in ("R_T", "p_T", "axis", "mass", "com", "inertia")
+        ]
+        h = L.dwbc_model_create_from_arrays(int(m["nb"]), *[a.ctypes.data for a in arrs])
+        if not h:
+            raise DwbcError(_lib.last_error())
+        return cls(h)
+
+    def link_id(self, name):
+        return self._L.dwbc_model_link_id(self._h, name.encode())
+
+    def link_name(self, i):
+        return self._L.dwbc_model_link_name(self._h, i).decode()
+
+    def arrays(self):
+        nb = self.nb
+        out = dict(parent=np.zeros(nb, np.int32), R_T=np.zeros((nb, 3, 3)), p_T=np.zeros((nb, 3)), axis=np.zeros((nb, 3)),
+                   mass=np.zeros(nb), com=np.zeros((nb, 3)), inertia=np.zeros((nb, 3, 3)))
+        self._L.dwbc_model_get_arrays(self._h, *[out[k].ctypes.data for k in ("parent", "R_T", "p_T", "axis", "mass", "com", "inertia")])
+        out["nb"], out["ndof"] = nb, self.ndof
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.dwbc_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Batch:
+    def __init__(self, model, B, device=0):
+        self._L = _lib.load()
+        self.model = model
+        self.B = int(B)
+        self.n = model.ndof
+        self.m = model.ndof - 6
+        self._h = self._L.dwbc_batch_create(model._h, self.B, int(device), 0)
+        if not self._h:
+            raise DwbcError(_lib.last_error())
+        self.n_contacts = 0
+        self._keep = {}
+
+    # ---- setup (shared by all instances)
+    def add_contact(self, link, point, lx, ly, mu=0.2, mu_z=0.2, contact_type=CONTACT_6D):
+        p = np.ascontiguousarray(point, np.float64)
+        i = self._L.dwbc_batch_add_contact(self._h, int(link), int(contact_type), p.ctypes.data, lx, ly, mu, mu_z)
+        if i < 0:
+            raise DwbcError(_lib.last_error())
+        self.n_contacts = i + 1
+        return i
+
+    def add_task(self, level, mode, link, point=(0.0, 0.0, 0.0)):
+        p = np.ascontiguousarray(point, np.float64)
+        _check(self._L.dwbc_batch_add_task(self._h, int(level), int(mode), int(link), p.ctypes.data))
+
+    def set_torque_limit(self, lim):
+        if lim is None:
+            _check(self._L.dwbc_batch_set_torque_limit(self._h, None))
+        else:
+            t = np.ascontiguousarray(lim, np.float64)
+            assert t.shape == (self.m,)
+            _check(self._L.dwbc_batch_set_torque_limit(self._h, t.ctypes.data))
+
+    @property
+    def fstar_size(self):
+        return self._L.dwbc_batch_fstar_size(self._h)
+
+    def task_dof(self, level):
+        return self._L.dwbc_batch_task_dof(self._h, level)
+
+    # ---- per-cycle inputs (host arrays)
+    def set_state(self, q, qdot=None, qddot=None):
+        q = np.ascontiguousarray(q, np.float64)
+        assert q.shape == (self.B, self.n + 1), q.shape
+        _check(self._L.dwbc_batch_set_state(self._h, q.ctypes.data, None, None))
+
+    def set_contact(self, flags):
+        f = np.ascontiguousarray(flags, np.uint8)
+        assert f.shape == (self.B, self.n_contacts), f.shape
+        _check(self._L.dwbc_batch_set_contact(self._h, f.ctypes.data))
+
+    def set_fstar(self, level, fstar):
+        f = np.ascontiguousarray(fstar, np.float64)
+        assert f.shape == (self.B, self.task_dof(level)), f.shape
+        _check(self._L.dwbc_batch_set_fstar(self._h, int(level), f.ctypes.data))
+
+    def set_fstar_all(self, fstar):
+        off = 0
+        lv = 0
+        while off < fstar.shape[1]:
+            t = self.task_dof(lv)
+            self.set_fstar(lv, fstar[:, off : off + t])
+            off += t
+            lv += 1
+
+    # ---- zero-copy device plumbing (torch owns the memory / stream)
+    def bind_tensor(self, field, tensor):
+        assert tensor.is_cuda and tensor.is_contiguous()
+        nbytes = self._L.dwbc_batch_field_bytes(self._h, FIELDS[field])
+        assert tensor.numel() * tensor.element_size() == nbytes, (field, tensor.shape, nbytes)
+        self._keep[field] = tensor
+        _check(self._L.dwbc_batch_bind_device(self._h, FIELDS[field], C.c_void_p(tensor.data_ptr())))
+
+    def set_stream(self, stream_handle):
+        _check(self._L.dwbc_batch_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def enable_dump(self, on=True):
+        _check(self._L.dwbc_batch_enable_dump(self._h, 1 if on else 0))
+
+    # ---- the cycle
+    def solve(self, hqp=True, init=True):
+        _check(self._L.dwbc_batch_solve(self._h, (SOLVE_HQP if hqp else 0) | (SOLVE_INIT if init else 0)))
+
+    def sync(self):
+        _check(self._L.dwbc_batch_sync(self._h))
+
+    def time_solves(self, steps):
+        ms = C.c_float(0)
+        _check(self._L.dwbc_batch_time_solves(self._h, SOLVE_HQP | SOLVE_INIT, int(steps), C.byref(ms)))
+        return ms.value
+
+    def launch_info(self):
+        t, l = C.c_int(0), C.c_int(0)
+        self._L.dwbc_batch_launch_info(self._h, C.byref(t), C.byref(l))
+        return t.value, l.value
+
+    _SHAPES = dict(
+        tau=lambda s: (3, s.m), wrench=lambda s: (12,), status=lambda s: (), diag=lambda s: (74,),
+        tau_grav=lambda s: (s.m,), tau_task=lambda s: (s.m,), tau_contact=lambda s: (s.m,), tau_total=lambda s: (s.m,),
+        A=lambda s: (s.n, s.n), A_inv=lambda s: (s.n, s.n), A_inv_N_C=lambda s: (s.n, s.n), J_C=lambda s: (12, s.n),
+        J_C_INV_T=lambda s: (12, s.n), Lambda_c=lambda s: (144,), W_inv=lambda s: (s.m, s.m), NwJw=lambda s: (s.m, 6),
+        G=lambda s: (s.n,), P_C=lambda s: (12,), link_R=lambda s: (48, 3, 3), link_p=lambda s: (48, 3),
+        fstar_qp=lambda s: (4, 6), contact_qp=lambda s: (4, 6), cf_redis=lambda s: (6,), J_task=lambda s: (4, 6 * s.n),
+        Lambda_task=lambda s: (4, 36), J_kt=lambda s: (4, s.m * 6), qp_viol=lambda s: (5,),
+        in_q=lambda s: (s.n + 1,), in_contact=lambda s: (s.n_contacts,), in_fstar=lambda s: (s.fstar_size,),
+    )
+
+    def get(self, field):
+        fid = FIELDS[field]
+        shape = (self.B,) + tuple(self._SHAPES[field](self))
+        dt = np.int32 if field in ("status", "diag") else (np.uint8 if field == "in_contact" else np.float64)
+        out = np.zeros(shape, dtype=dt)
+        nbytes = self._L.dwbc_batch_field_bytes(self._h, fid)
+        assert nbytes == out.nbytes, (field, nbytes, out.nbytes)
+        _check(self._L.dwbc_batch_get(self._h, fid, out.ctypes.data, out.nbytes))
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.dwbc_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,478 @@
+// dwbc_capi.hip -- C-ABI (include/dwbc_batch.h) + kernel launch for the MI355X-native batched libdwbc hot path.
+// gfx950 only.  No CPU fallback: every compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dwbc_batch.h"
+#include "dwbc_cycle.h"
+#include "dwbc_model.h"
+#include "dwbc_setup.h"
+
+using namespace dwbc;
+
+// ------------------------------------------------------------------------------------------------
+// kernel: one workgroup (one 64-lane wavefront) per robot instance, everything between q and tau in LDS
+// ------------------------------------------------------------------------------------------------
+template <int N, int NB, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const BatchIO io) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    int *iL = reinterpret_cast<int *>(lds + Lds<N, NB>::total);
+    cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
+}
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string &s) {
+    g_err = s;
+    return 0;
+}
+#define HIP_OK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr int kNT = 64;
+
+struct KernelEntry {
+    int n, nb;
+    void (*fn)(const Setup, const BatchIO);
+    int lds_bytes;
+};
+// instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
+const KernelEntry kKernels[] = {
+    {39, 34, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes},
+};
+}  // namespace
+
+struct dwbc_model {
+    Model m;
+};
+
+struct dwbc_batch {
+    const dwbc_model *model = nullptr;
+    int B = 0, device = 0, n = 0, m = 0;
+    Setup su{};
+    const KernelEntry *kern = nullptr;
+    hipStream_t stream = nullptr;
+    // device buffers (owned unless bound)
+    double *d_q = nullptr, *d_fstar = nullptr, *d_tau = nullptr, *d_wrench = nullptr, *d_dump = nullptr, *d_body = nullptr;
+    unsigned char *d_flags = nullptr;
+    int *d_status = nullptr, *d_diag = nullptr, *d_topo = nullptr;
+    bool own_q = false, own_fstar = false, own_flags = false, own_tau = false, own_wrench = false, own_status = false;
+    int fstar_alloc = 0, flags_alloc = 0;
+    bool dump_on = false;
+    // host mirrors of the inputs
+    std::vector<double> h_q, h_fstar;
+    std::vector<unsigned char> h_flags;
+    bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
+    bool attr_set = false;
+    DumpLayout dl{};
+};
+
+extern "C" {
+
+const char *dwbc_last_error(void) { return g_err.c_str(); }
+
+int dwbc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+dwbc_model *dwbc_model_create_from_urdf(const char *path, int floating_base) {
+    auto *mm = new dwbc_model();
+    std::string err;
+    if (!load_urdf(path, floating_base != 0, mm->m, err)) {
+        g_err = err;
+        delete mm;
+        return nullptr;
+    }
+    return mm;
+}
+
+dwbc_model *dwbc_model_create_from_arrays(int nb, const int32_t *parent, const double *R_T, const double *p_T, const double *axis,
+                                          const double *mass, const double *com, const double *inertia) {
+    if (nb < 1 || nb > kMaxBodies) { g_err = "bad body count"; return nullptr; }
+    auto *mm = new dwbc_model();
+    Model &m = mm->m;
+    m.parent.assign(parent, parent + nb);
+    m.R_T.assign(R_T, R_T + 9 * nb);
+    m.p_T.assign(p_T, p_T + 3 * nb);
+    m.axis.assign(axis, axis + 3 * nb);
+    m.mass.assign(mass, mass + nb);
+    m.com.assign(com, com + 3 * nb);
+    m.inertia.assign(inertia, inertia + 9 * nb);
+    for (int i = 0; i < nb; i++) {
+        m.names.push_back("link" + std::to_string(i));
+        if (i > 0 && (parent[i] < 0 || parent[i] >= i)) { g_err = "parent[] must be a DFS pre-order"; delete mm; return nullptr; }
+    }
+    m.finalize();
+    return mm;
+}
+
+void dwbc_model_destroy(dwbc_model *m) { delete m; }
+int dwbc_model_num_links(const dwbc_model *m) { return m->m.nb; }
+int dwbc_model_system_dof(const dwbc_model *m) { return m->m.ndof; }
+double dwbc_model_total_mass(const dwbc_model *m) { return m->m.total_mass; }
+int dwbc_model_link_id(const dwbc_model *m, const char *name) { return m->m.link_id(name); }
+const char *dwbc_model_link_name(const dwbc_model *m, int link) {
+    return (link >= 0 && link < m->m.nb) ? m->m.names[link].c_str() : "";
+}
+int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, double *p_T, double *axis, double *mass, double *com,
+                          double *inertia) {
+    const Model &m = mm->m;
+    for (int i = 0; i < m.nb; i++) parent[i] = m.parent[i];
+    memcpy(R_T, m.R_T.data(), sizeof(double) * 9 * m.nb);
+    memcpy(p_T, m.p_T.data(), sizeof(double) * 3 * m.nb);
+    memcpy(axis, m.axis.data(), sizeof(double) * 3 * m.nb);
+    memcpy(mass, m.mass.data(), sizeof(double) * m.nb);
+    memcpy(com, m.com.data(), sizeof(double) * 3 * m.nb);
+    memcpy(inertia, m.inertia.data(), sizeof(double) * 9 * m.nb);
+    return 1;
+}
+
+dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype) {
+    if (!m || B < 1) { g_err = "bad arguments"; return nullptr; }
+    if (dtype != DWBC_F64) { g_err = "only DWBC_F64 is implemented"; return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
+    if (device < 0 || device >= ndev) { g_err = "bad device index"; return nullptr; }
+    const KernelEntry *ke = nullptr;
+    for (const auto &k : kKernels)
+        if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
+    if (!ke) {
+        g_err = "no kernel instantiated for a model with " + std::to_string(m->m.ndof) + " dof / " + std::to_string(m->m.nb) + " bodies";
+        return nullptr;
+    }
+    auto *b = new dwbc_batch();
+    b->model = m;
+    b->B = B;
+    b->device = device;
+    b->n = m->m.ndof;
+    b->m = b->n - 6;
+    b->kern = ke;
+    b->dl = DumpLayout::make(b->n);
+    setup_init(b->su, m->m.nb, b->n, m->m.maxdepth);
+    auto bad = [&](const char *what, hipError_t e) {
+        g_err = std::string(what) + ": " + hipGetErrorString(e);
+        dwbc_batch_destroy(b);
+        return (dwbc_batch *)nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bad("hipSetDevice", e);
+    std::vector<double> body;
+    std::vector<int> topo;
+    m->m.body_table(body);
+    m->m.topo_table(topo);
+    if ((e = hipMalloc(&b->d_body, body.size() * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
+    if ((e = hipMalloc(&b->d_topo, topo.size() * sizeof(int))) != hipSuccess) return bad("hipMalloc", e);
+    if ((e = hipMemcpy(b->d_body, body.data(), body.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy", e);
+    if ((e = hipMemcpy(b->d_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy", e);
+    if ((e = hipMalloc(&b->d_q, (size_t)B * (b->n + 1) * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
+    b->own_q = true;
+    if ((e = hipMalloc(&b->d_tau, (size_t)B * 3 * b->m * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
+    b->own_tau = true;
+    if ((e = hipMalloc(&b->d_wrench, (size_t)B * 12 * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
+    b->own_wrench = true;
+    if ((e = hipMalloc(&b->d_status, (size_t)B * sizeof(int))) != hipSuccess) return bad("hipMalloc", e);
+    b->own_status = true;
+    if ((e = hipMalloc(&b->d_diag, (size_t)B * DG_COUNT * sizeof(int))) != hipSuccess) return bad("hipMalloc", e);
+    hipMemset(b->d_diag, 0, (size_t)B * DG_COUNT * sizeof(int));
+    hipMemset(b->d_status, 0, (size_t)B * sizeof(int));
+    b->h_q.assign((size_t)B * (b->n + 1), 0.0);
+    return b;
+}
+
+void dwbc_batch_destroy(dwbc_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->device);
+    if (b->own_q) hipFree(b->d_q);
+    if (b->own_fstar) hipFree(b->d_fstar);
+    if (b->own_flags) hipFree(b->d_flags);
+    if (b->own_tau) hipFree(b->d_tau);
+    if (b->own_wrench) hipFree(b->d_wrench);
+    if (b->own_status) hipFree(b->d_status);
+    hipFree(b->d_diag);
+    hipFree(b->d_dump);
+    hipFree(b->d_body);
+    hipFree(b->d_topo);
+    delete b;
+}
+
+int dwbc_batch_size(const dwbc_batch *b) { return b->B; }
+
+int dwbc_batch_add_contact(dwbc_batch *b, int link, int contact_type, const double point[3], double lx, double ly, double mu,
+                           double mu_z) {
+    std::string err;
+    const int i = setup_add_contact(b->su, link, contact_type, point, lx, ly, mu, mu_z, err);
+    if (i < 0) { fail(err); return -1; }
+    b->h_flags.assign((size_t)b->B * b->su.n_contacts, 0);
+    b->dirty_flags = true;
+    return i;
+}
+
+int dwbc_batch_clear_contacts(dwbc_batch *b) {
+    b->su.n_contacts = 0;
+    b->h_flags.clear();
+    return 1;
+}
+
+int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const double point[3]) {
+    std::string err;
+    if (!setup_add_task(b->su, level, mode, link, point, err)) return fail(err);
+    b->h_fstar.assign((size_t)b->B * b->su.fstar_total, 0.0);
+    b->dirty_fstar = true;
+    return 1;
+}
+
+int dwbc_batch_clear_tasks(dwbc_batch *b) {
+    b->su.n_levels = 0;
+    setup_fstar_layout(b->su);
+    b->h_fstar.clear();
+    return 1;
+}
+
+int dwbc_batch_set_torque_limit(dwbc_batch *b, const double *tau_lim) {
+    if (!tau_lim) { b->su.has_tau_lim = 0; return 1; }
+    b->su.has_tau_lim = 1;
+    for (int i = 0; i < b->m; i++) b->su.tau_lim[i] = tau_lim[i];
+    return 1;
+}
+
+int dwbc_batch_fstar_size(const dwbc_batch *b) { return b->su.fstar_total; }
+int dwbc_batch_task_dof(const dwbc_batch *b, int level) { return (level >= 0 && level < b->su.n_levels) ? b->su.t_dof[level] : 0; }
+
+int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot) {
+    (void)qdot; (void)qddot;  // B_ (RNEA) is not on the OSF torque path
+    if (!q) return fail("q is NULL");
+    if (!b->own_q) return fail("q is bound to a device buffer");
+    memcpy(b->h_q.data(), q, b->h_q.size() * sizeof(double));
+    b->dirty_q = true;
+    return 1;
+}
+
+int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags) {
+    if (b->su.n_contacts == 0) return fail("Contact Constraint size mismatch");  // include/dwbc.h:438-441
+    if (b->d_flags && !b->own_flags) return fail("contact flags are bound to a device buffer");
+    memcpy(b->h_flags.data(), flags, b->h_flags.size());
+    b->dirty_flags = true;
+    return 1;
+}
+
+int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar) {
+    if (level < 0 || level >= b->su.n_levels) return fail("ERROR : task space size overflow");  // src/dwbc.cpp:668-671
+    if (b->d_fstar && !b->own_fstar) return fail("f* is bound to a device buffer");
+    const int t = b->su.t_dof[level], off = b->su.fstar_off[level], F = b->su.fstar_total;
+    for (int i = 0; i < b->B; i++) memcpy(b->h_fstar.data() + (size_t)i * F + off, fstar + (size_t)i * t, sizeof(double) * t);
+    b->dirty_fstar = true;
+    return 1;
+}
+
+int dwbc_batch_bind_device(dwbc_batch *b, int field, void *p) {
+    if (!p) return fail("NULL device pointer");
+    hipSetDevice(b->device);
+    switch (field) {
+        case DWBC_IN_Q: if (b->own_q) hipFree(b->d_q); b->d_q = (double *)p; b->own_q = false; b->dirty_q = false; return 1;
+        case DWBC_IN_CONTACT: if (b->own_flags) hipFree(b->d_flags); b->d_flags = (unsigned char *)p; b->own_flags = false; b->dirty_flags = false; return 1;
+        case DWBC_IN_FSTAR: if (b->own_fstar) hipFree(b->d_fstar); b->d_fstar = (double *)p; b->own_fstar = false; b->dirty_fstar = false; return 1;
+        case DWBC_TAU: if (b->own_tau) hipFree(b->d_tau); b->d_tau = (double *)p; b->own_tau = false; return 1;
+        case DWBC_WRENCH: if (b->own_wrench) hipFree(b->d_wrench); b->d_wrench = (double *)p; b->own_wrench = false; return 1;
+        case DWBC_STATUS: if (b->own_status) hipFree(b->d_status); b->d_status = (int *)p; b->own_status = false; return 1;
+        default: return fail("field cannot be bound");
+    }
+}
+
+int dwbc_batch_set_stream(dwbc_batch *b, void *s) { b->stream = (hipStream_t)s; return 1; }
+
+int dwbc_batch_enable_dump(dwbc_batch *b, int on) {
+    hipSetDevice(b->device);
+    if (on && !b->d_dump) HIP_OK(hipMalloc(&b->d_dump, (size_t)b->B * b->dl.total * sizeof(double)));
+    b->dump_on = on != 0;
+    return 1;
+}
+
+static int upload_inputs(dwbc_batch *b) {
+    if (b->su.n_contacts > 0 && (!b->d_flags || (b->own_flags && b->flags_alloc != b->su.n_contacts))) {
+        if (b->own_flags && b->d_flags) hipFree(b->d_flags);
+        HIP_OK(hipMalloc(&b->d_flags, (size_t)b->B * b->su.n_contacts));
+        b->own_flags = true;
+        b->flags_alloc = b->su.n_contacts;
+        b->dirty_flags = true;
+    }
+    if (b->su.fstar_total > 0 && (!b->d_fstar || (b->own_fstar && b->fstar_alloc != b->su.fstar_total))) {
+        if (b->own_fstar && b->d_fstar) hipFree(b->d_fstar);
+        HIP_OK(hipMalloc(&b->d_fstar, (size_t)b->B * b->su.fstar_total * sizeof(double)));
+        b->own_fstar = true;
+        b->fstar_alloc = b->su.fstar_total;
+        b->dirty_fstar = true;
+    }
+    if (b->dirty_q && b->own_q) HIP_OK(hipMemcpyAsync(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (b->dirty_flags && b->own_flags) HIP_OK(hipMemcpyAsync(b->d_flags, b->h_flags.data(), b->h_flags.size(), hipMemcpyHostToDevice, b->stream));
+    if (b->dirty_fstar && b->own_fstar) HIP_OK(hipMemcpyAsync(b->d_fstar, b->h_fstar.data(), b->h_fstar.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    b->dirty_q = b->dirty_flags = b->dirty_fstar = false;
+    return 1;
+}
+
+static int launch(dwbc_batch *b) {
+    BatchIO io{};
+    io.B = b->B;
+    io.q = b->d_q;
+    io.flags = b->d_flags;
+    io.fstar = b->d_fstar;
+    io.tau = b->d_tau;
+    io.wrench = b->d_wrench;
+    io.status = b->d_status;
+    io.diag = b->d_diag;
+    io.dump = b->dump_on ? b->d_dump : nullptr;
+    io.body = b->d_body;
+    io.topo = b->d_topo;
+    if (!b->attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
+        b->attr_set = true;
+    }
+    hipLaunchKernelGGL(b->kern->fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
+    if (!(flags & DWBC_SOLVE_HQP)) return fail("hqp=false (closed-form ContactRedistributetwomod) is not on the device path");
+    if (b->su.n_levels < 1) return fail("no task space");
+    if (b->su.n_contacts < 1) return fail("no contact constraint");
+    HIP_OK(hipSetDevice(b->device));
+    if (!upload_inputs(b)) return 0;
+    return launch(b);
+}
+
+int dwbc_batch_sync(dwbc_batch *b) {
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipStreamSynchronize(b->stream));
+    return 1;
+}
+
+int dwbc_batch_time_solves(dwbc_batch *b, unsigned flags, int steps, float *ms) {
+    HIP_OK(hipSetDevice(b->device));
+    if (!dwbc_batch_solve(b, flags)) return 0;  // uploads + warm launch
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, b->stream));
+    for (int i = 0; i < steps; i++)
+        if (!launch(b)) return 0;
+    HIP_OK(hipEventRecord(e1, b->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventElapsedTime(ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 1;
+}
+
+size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
+    const size_t B = b->B, n = b->n, m = b->m;
+    switch (field) {
+        case DWBC_IN_Q: return B * (n + 1) * 8;
+        case DWBC_IN_CONTACT: return B * b->su.n_contacts;
+        case DWBC_IN_FSTAR: return B * b->su.fstar_total * 8;
+        case DWBC_TAU: return B * 3 * m * 8;
+        case DWBC_WRENCH: return B * 12 * 8;
+        case DWBC_STATUS: return B * 4;
+        case DWBC_DIAG: return B * DG_COUNT * 4;
+        case DWBC_TAU_GRAV: case DWBC_TAU_TASK: case DWBC_TAU_CONTACT: case DWBC_TAU_TOTAL: return B * m * 8;
+        case DWBC_A: case DWBC_A_INV: case DWBC_A_INV_N_C: return B * n * n * 8;
+        case DWBC_J_C: case DWBC_J_C_INV_T: return B * 12 * n * 8;
+        case DWBC_LAMBDA_C: return B * 144 * 8;
+        case DWBC_W_INV: return B * m * m * 8;
+        case DWBC_NWJW: return B * m * 6 * 8;
+        case DWBC_G: return B * n * 8;
+        case DWBC_P_C: return B * 12 * 8;
+        case DWBC_LINK_R: return B * kMaxBodies * 9 * 8;
+        case DWBC_LINK_P: return B * kMaxBodies * 3 * 8;
+        case DWBC_FSTAR_QP: case DWBC_CONTACT_QP: return B * kMaxLevels * 6 * 8;
+        case DWBC_CF_REDIS: return B * 6 * 8;
+        case DWBC_J_TASK: return B * kMaxLevels * 6 * n * 8;
+        case DWBC_LAMBDA_TASK: return B * kMaxLevels * 36 * 8;
+        case DWBC_J_KT: return B * kMaxLevels * m * 6 * 8;
+        case DWBC_QP_VIOL: return B * (kMaxLevels + 1) * 8;
+        case DWBC_DUMP_RAW: return B * (size_t)b->dl.total * 8;
+        default: return 0;
+    }
+}
+
+int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
+    const size_t need = dwbc_batch_field_bytes(b, field);
+    if (need == 0) return fail("unknown field");
+    if (bytes < need) return fail("output buffer too small");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipStreamSynchronize(b->stream));
+    const size_t B = b->B, m = b->m;
+    auto d2h = [&](const void *src, size_t nbytes) -> int {
+        HIP_OK(hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost));
+        return 1;
+    };
+    switch (field) {
+        case DWBC_IN_Q: return d2h(b->d_q, need);
+        case DWBC_IN_CONTACT: return d2h(b->d_flags, need);
+        case DWBC_IN_FSTAR: return d2h(b->d_fstar, need);
+        case DWBC_TAU: return d2h(b->d_tau, need);
+        case DWBC_WRENCH: return d2h(b->d_wrench, need);
+        case DWBC_STATUS: return d2h(b->d_status, need);
+        case DWBC_DIAG: return d2h(b->d_diag, need);
+        case DWBC_TAU_GRAV: case DWBC_TAU_TASK: case DWBC_TAU_CONTACT: case DWBC_TAU_TOTAL: {
+            std::vector<double> t(B * 3 * m);
+            HIP_OK(hipMemcpy(t.data(), b->d_tau, t.size() * 8, hipMemcpyDeviceToHost));
+            double *o = (double *)out;
+            for (size_t i = 0; i < B; i++)
+                for (size_t j = 0; j < m; j++) {
+                    const double *s = t.data() + i * 3 * m;
+                    o[i * m + j] = field == DWBC_TAU_GRAV ? s[j] : field == DWBC_TAU_TASK ? s[m + j] : field == DWBC_TAU_CONTACT ? s[2 * m + j] : s[j] + s[m + j] + s[2 * m + j];
+                }
+            return 1;
+        }
+        default: break;
+    }
+    if (!b->d_dump || !b->dump_on) return fail("intermediates need dwbc_batch_enable_dump(b, 1) before the solve");
+    const DumpLayout &dl = b->dl;
+    int off = 0, len = 0;
+    const int n = b->n, K = 6, T = kMaxTaskDof, L = kMaxLevels;
+    switch (field) {
+        case DWBC_A: off = dl.A; len = n * n; break;
+        case DWBC_A_INV: off = dl.A_inv; len = n * n; break;
+        case DWBC_J_C: off = dl.J_C; len = 12 * n; break;
+        case DWBC_LAMBDA_C: off = dl.Lambda_c; len = 144; break;
+        case DWBC_J_C_INV_T: off = dl.J_C_INV_T; len = 12 * n; break;
+        case DWBC_A_INV_N_C: off = dl.A_inv_N_C; len = n * n; break;
+        case DWBC_W_INV: off = dl.W_inv; len = (int)(m * m); break;
+        case DWBC_NWJW: off = dl.NwJw; len = (int)m * K; break;
+        case DWBC_G: off = dl.G; len = n; break;
+        case DWBC_P_C: off = dl.P_C; len = 12; break;
+        case DWBC_LINK_R: off = dl.link_R; len = kMaxBodies * 9; break;
+        case DWBC_LINK_P: off = dl.link_p; len = kMaxBodies * 3; break;
+        case DWBC_FSTAR_QP: off = dl.fstar_qp; len = L * T; break;
+        case DWBC_CONTACT_QP: off = dl.contact_qp; len = L * K; break;
+        case DWBC_CF_REDIS: off = dl.cf_redis; len = K; break;
+        case DWBC_J_TASK: off = dl.J_task; len = L * T * n; break;
+        case DWBC_LAMBDA_TASK: off = dl.Lambda_task; len = L * T * T; break;
+        case DWBC_J_KT: off = dl.J_kt; len = L * (int)m * T; break;
+        case DWBC_QP_VIOL: off = dl.qp_viol; len = L + 1; break;
+        case DWBC_DUMP_RAW: off = 0; len = dl.total; break;
+        default: return fail("unknown field");
+    }
+    HIP_OK(hipMemcpy2D(out, (size_t)len * 8, b->d_dump + off, (size_t)dl.total * 8, (size_t)len * 8, B, hipMemcpyDeviceToHost));
+    return 1;
+}
+
+int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
+    if (threads) *threads = kNT;
+    if (lds) *lds = b->kern->lds_bytes;
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,1169 @@
+// dwbc_cycle.h -- the fused per-instance OSF/HQP control cycle as block-cooperative device code.
+//
+// One workgroup (NT threads, normally one 64-lane wavefront) owns ONE robot instance for the whole
+// cycle; every intermediate (M, M^-1, J_C, Lambda_c, J̄_c^T, A^-1 N_c, W^+, NwJw, per-level J_kt/Lambda_t,
+// the QP rows and the active-set state) lives in LDS and never touches HBM.  Only q, flags, f* are read
+// and tau / wrench / status written (about 1.4 KB per instance).
+//
+// The code is written NT-generic with strided loops and explicit barriers so that the SAME source can be
+// compiled by g++ with NT = 1 (tests/emu) to check the arithmetic on a machine without a GPU.  That build
+// is a test harness only; the product library has no CPU path.
+//
+// Reference functions restated here (file:line in the reference tree):
+//   RobotData::UpdateKinematics          src/dwbc.cpp:279-371   (FK, A_, A_inv_, G_)
+//   ContactConstraint::Update            src/contact_constraint.cpp:51-77
+//   CalculateContactConstraint           src/wbd.cpp:108-143
+//   CalculateGravityCompensation         src/wbd.cpp:186-192
+//   RobotData::UpdateTaskSpace           src/dwbc.cpp:685-793
+//   CalculateJKT / CalculateTaskNullSpace src/wbd.cpp:207-261
+//   RobotData::CalcSingleTaskTorqueWithQP src/dwbc.cpp:941-1127 (QP rows)  + cascade :818-873
+//   RobotData::CalcContactRedistribute   src/dwbc.cpp:1372-1568
+//   CalculateContactForce                src/wbd.cpp:268-271
+//   CQuadraticProgram::SolveQPoases      src/qp_wrapper.cpp:192-380 -> replaced by qp_solve() below
+#pragma once
+#include <math.h>
+
+#include "dwbc_types.h"
+
+#ifdef DWBC_HOST_EMU
+#define DWBC_DEV
+#define DWBC_SYNC() ((void)0)
+#else
+#define DWBC_DEV __device__ __forceinline__
+#define DWBC_SYNC() __syncthreads()
+#endif
+
+namespace dwbc {
+
+constexpr double kGrav = 9.81;
+constexpr double kQpScaleGI = 1.0e4;      // c = s * c_hat while the active set is searched
+constexpr double kQpScalePolish = 1.0e9;  // weight of the final (row-sorted, column-pivoted) least-norm solve
+constexpr double kQpTol = 1.0e-9;
+constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
+
+
+// ----------------------------------------------------------------------------------------------
+// LDS map (doubles).  N = system dof, M = N-6, C = 12 contact rows, K = 6
+// ----------------------------------------------------------------------------------------------
+template <int N, int NB>
+struct Lds {
+    static constexpr int M = N - 6;
+    static constexpr int C = 6 * kMaxActiveContacts;
+    static constexpr int K = C - 6;
+    static constexpr int T = kMaxTaskDof;
+    static constexpr int QR = 2 * M + 10 * kMaxActiveContacts;  // max QP rows
+    // persistent
+    static constexpr int bufA = 0;                    // A -> chol(A) -> A_inv ; later W_inv (M x M)
+    static constexpr int bufN = bufA + N * N;         // L^-1 -> A_inv N_c
+    static constexpr int Rw = bufN + N * N;           // body->world rotations
+    static constexpr int pw = Rw + NB * 9;
+    static constexpr int aw = pw + NB * 3;    // world joint axes
+    static constexpr int JC = aw + NB * 3;    // C x N
+    static constexpr int JbT = JC + C * N;            // J̄_c^T  C x N
+    static constexpr int Lam = JbT + C * N;           // C x C
+    static constexpr int NwJw = Lam + C * C;          // M x K
+    static constexpr int FNl = NwJw + M * K;          // A_rot * J̄[:,6:] * NwJw   C x K
+    static constexpr int G = FNl + C * K;
+    static constexpr int tg = G + N;                  // torque_grav_
+    static constexpr int tt = tg + M;                 // torque_task_
+    static constexpr int tc = tt + M;                 // torque_contact_
+    static constexpr int PC = tc + M;                 // C
+    static constexpr int q = PC + C;                  // N+1
+    static constexpr int Rc = q + N + 1;              // contact rotations (active) 2 x 9
+    static constexpr int Pc = Rc + kMaxActiveContacts * 9;  // contact points (world) 2 x 3
+    static constexpr int Xl = Pc + kMaxActiveContacts * 3;  // per level X = J_kt Lambda (M x T)
+    static constexpr int Yl = Xl + (kMaxLevels - 1) * M * T;  // per level Y = (J_t A^-1 N_c)[:,6:] (T x M)
+    static constexpr int tmp = Yl + (kMaxLevels - 1) * T * M;  // phase-local scratch
+    // --- scratch, kinematics phase
+    static constexpr int k_Rl = tmp;                  // local transforms nb x 9
+    static constexpr int k_Iw = k_Rl + NB * 9;  // nb x 10
+    static constexpr int k_Ic = k_Iw + NB * 10;
+    static constexpr int k_S = k_Ic + NB * 10;  // N x 6
+    static constexpr int k_F = k_S + N * 6;
+    static constexpr int k_end = k_F + N * 6;
+    // --- scratch, contact phase
+    static constexpr int c_Y = tmp;                   // J_C A^-1 (C x N)
+    static constexpr int c_Vb = c_Y + C * N;          // M x K
+    static constexpr int c_s1 = c_Vb + M * K;         // C x 2C gauss-jordan scratch
+    static constexpr int c_s2 = c_s1 + C * 2 * C;     // C x C
+    static constexpr int c_P = c_s2 + C * C;          // M x M projector
+    static constexpr int c_W1 = c_P + M * M;          // M x M
+    static constexpr int c_vec = c_W1 + M * M;        // N
+    static constexpr int c_end = c_vec + N;
+    // --- scratch, task / QP phase
+    static constexpr int t_Jt = tmp;                  // T x N
+    static constexpr int t_T1 = t_Jt + T * N;         // T x N
+    static constexpr int t_Lt = t_T1 + T * N;         // T x T
+    static constexpr int t_Q = t_Lt + T * T;          // T x M
+    static constexpr int t_QW = t_Q + T * M;          // T x M
+    static constexpr int t_Jkt = t_QW + T * M;        // M x T
+    static constexpr int t_U = t_Jkt + M * T;         // M x T
+    static constexpr int t_s1 = t_U + M * T;          // T x 2T
+    static constexpr int t_s2 = t_s1 + C * (T + 1);   // T x T   (t_s1 doubles as the C x (T+1) wrench-map scratch)
+    static constexpr int t_s3 = t_s2 + T * T;         // T x T
+    static constexpr int t_base = t_s3 + T * T;       // M
+    static constexpr int t_F = t_base + M;            // C x kQpLd
+    static constexpr int t_fv = t_F + C * kQpLd;      // C
+    static constexpr int qp_G = t_fv + C;             // rows x kQpLd
+    static constexpr int qp_ub = qp_G + QR * kQpLd;
+    static constexpr int qp_gn = qp_ub + QR;
+    static constexpr int qp_Nm = qp_gn + QR;  // kQpLd x kQpLd   active normals (columns)
+    static constexpr int qp_Np = qp_Nm + kQpLd * kQpLd;  // pseudo-inverse rows
+    static constexpr int qp_V = qp_Np + kQpLd * kQpLd;   // householder vectors
+    static constexpr int qp_x = qp_V + kQpLd * kQpLd;
+    static constexpr int qp_r = qp_x + kQpLd;
+    static constexpr int qp_z = qp_r + kQpLd;
+    static constexpr int qp_u = qp_z + kQpLd;
+    static constexpr int qp_b = qp_u + kQpLd;
+    static constexpr int qp_w = qp_b + kQpLd;
+    static constexpr int qp_beta = qp_w + kQpLd;
+    static constexpr int qp_red = qp_beta + kQpLd;    // cross-wave reduction scratch
+    static constexpr int t_end = qp_red + 16;
+    static constexpr int max2(int a, int b) { return a > b ? a : b; }
+    static constexpr int total = max2(max2(k_end, c_end), t_end);
+    static constexpr int total_bytes = total * 8 + 64 * 4 + 64;  // + int scratch
+};
+
+// ----------------------------------------------------------------------------------------------
+// tiny helpers
+// ----------------------------------------------------------------------------------------------
+struct Thr {
+    int tid;
+};
+
+template <int NT>
+DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    for (int idx = th.tid; idx < m * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        double s = 0.0;
+        for (int p = 0; p < k; p++) s += A[i * lda + p] * B[p * ldb + j];
+        Cm[i * ldc + j] = s;
+    }
+}
+// C = A * B^T   (A m x k, B n x k)
+template <int NT>
+DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    for (int idx = th.tid; idx < m * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        double s = 0.0;
+        for (int p = 0; p < k; p++) s += A[i * lda + p] * B[j * ldb + p];
+        Cm[i * ldc + j] = s;
+    }
+}
+// C = A^T * B   (A k x m, B k x n)
+template <int NT>
+DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    for (int idx = th.tid; idx < m * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        double s = 0.0;
+        for (int p = 0; p < k; p++) s += A[p * lda + i] * B[p * ldb + j];
+        Cm[i * ldc + j] = s;
+    }
+}
+template <int NT>
+DWBC_DEV void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
+    for (int i = th.tid; i < m; i += NT) {
+        double s = 0.0;
+        for (int j = 0; j < n; j++) s += A[i * lda + j] * x[j];
+        y[i] = s;
+    }
+}
+
+// In-place inverse of a small general matrix by Gauss-Jordan with partial pivoting (stands in for Eigen's
+// MatrixXd::inverse(), reference src/wbd.cpp:115,128,210).  W is an n x 2n scratch.  Returns min|pivot|/max|pivot|.
+template <int NT>
+DWBC_DEV double gj_inverse(Thr th, const double *A, int lda, int n, double *Ai, int ldi, double *W) {
+    const int w = 2 * n;
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < n * w; idx += NT) {
+        int i = idx / w, j = idx - i * w;
+        W[idx] = j < n ? A[i * lda + j] : (j - n == i ? 1.0 : 0.0);
+    }
+    double pmin = 1e300, pmax = 0.0;
+    for (int c = 0; c < n; c++) {
+        DWBC_SYNC();
+        int p = c;
+        double best = fabs(W[c * w + c]);
+        for (int i = c + 1; i < n; i++) {
+            double v = fabs(W[i * w + c]);
+            if (v > best) { best = v; p = i; }
+        }
+        pmin = best < pmin ? best : pmin;
+        pmax = best > pmax ? best : pmax;
+        DWBC_SYNC();
+        if (p != c)
+            for (int j = th.tid; j < w; j += NT) { double t = W[c * w + j]; W[c * w + j] = W[p * w + j]; W[p * w + j] = t; }
+        DWBC_SYNC();
+        double piv = W[c * w + c];
+        double inv = piv != 0.0 ? 1.0 / piv : 0.0;
+        DWBC_SYNC();
+        for (int j = th.tid; j < w; j += NT) W[c * w + j] *= inv;
+        DWBC_SYNC();
+        // eliminate: element (i,j) -= W[i][c] * W[c][j]; column c itself must be read before it is overwritten
+        for (int idx = th.tid; idx < n * w; idx += NT) {
+            int i = idx / w, j = idx - i * w;
+            if (i == c || j == c) continue;
+            W[idx] -= W[i * w + c] * W[c * w + j];
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < n; i += NT)
+            if (i != c) W[i * w + c] = 0.0;
+    }
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < n * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        Ai[i * ldi + j] = W[i * w + n + j];
+    }
+    DWBC_SYNC();
+    return pmax > 0.0 ? pmin / pmax : 0.0;
+}
+
+// SPD inverse of an n x n matrix held in LDS:  S (destroyed, ld n) -> Out (ld n); Tmp is n x n scratch.
+// Right-looking Cholesky, column-parallel forward substitution, then L^-T L^-1 -- the arithmetic of Eigen's
+// llt().solve(Identity) (reference src/dwbc.cpp:307).  Returns 0 when a pivot is not positive.
+template <int NT>
+DWBC_DEV int spd_inverse(Thr th, double *S, int n, double *Tmp, double *Out) {
+    int ok = 1;
+    for (int k = 0; k < n; k++) {
+        DWBC_SYNC();
+        double d = S[k * n + k];
+        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        d = sqrt(d);
+        double rd = 1.0 / d;
+        DWBC_SYNC();
+        for (int i = k + th.tid; i < n; i += NT) {
+            double v = (i == k) ? d : S[i * n + k] * rd;
+            S[i * n + k] = v;
+            S[k * n + i] = v;  // keep row k too: the update below reads L[j][k] as S[k][j]
+        }
+        DWBC_SYNC();
+        const int r = n - k - 1;
+        for (int idx = th.tid; idx < r * r; idx += NT) {
+            int i = k + 1 + idx / r, j = k + 1 + idx % r;
+            S[i * n + j] -= S[i * n + k] * S[k * n + j];
+        }
+    }
+    DWBC_SYNC();
+    // Tmp = L^-1 (lower), column c owned by one thread
+    for (int idx = th.tid; idx < n * n; idx += NT) Tmp[idx] = 0.0;
+    DWBC_SYNC();
+    for (int c = th.tid; c < n; c += NT) {
+        for (int i = c; i < n; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; k++) s -= S[i * n + k] * Tmp[k * n + c];
+            Tmp[i * n + c] = s / S[i * n + i];
+        }
+    }
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < n * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        int k0 = i > j ? i : j;
+        double s = 0.0;
+        for (int k = k0; k < n; k++) s += Tmp[k * n + i] * Tmp[k * n + j];
+        Out[idx] = s;
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
+DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, const double *w) {
+    // rows of [GetZMPConstMatrix; GetForceConstMatrix] (reference src/wbd.cpp:59-97) applied to a local wrench
+    switch (r) {
+        case 0: return -lx * w[2] - w[4];
+        case 1: return -lx * w[2] + w[4];
+        case 2: return -ly * w[2] - w[3];
+        case 3: return -ly * w[2] + w[3];
+        case 4: return w[0] - mu * w[2];
+        case 5: return -w[0] - mu * w[2];
+        case 6: return w[1] - mu * w[2];
+        case 7: return -w[1] - mu * w[2];
+        case 8: return w[5] - muz * w[2];
+        default: return -w[5] - muz * w[2];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// block-wide arg-min (value, index); every thread returns the same pair
+// ----------------------------------------------------------------------------------------------
+template <int NT>
+DWBC_DEV void block_argmin(Thr th, double &v, int &idx, double *red) {
+#ifdef DWBC_HOST_EMU
+    (void)th; (void)red;
+#else
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(v, off, 64);
+        int oi = __shfl_xor(idx, off, 64);
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (NT > 64) {
+        int *ired = reinterpret_cast<int *>(red + 8);
+        __syncthreads();
+        if ((th.tid & 63) == 0) { red[th.tid >> 6] = v; ired[th.tid >> 6] = idx; }
+        __syncthreads();
+        v = red[0]; idx = ired[0];
+        for (int w = 1; w < NT / 64; w++) {
+            double ov = red[w]; int oi = ired[w];
+            if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+// ----------------------------------------------------------------------------------------------
+// QP:  lexmin( 1/2|x[:t]|^2 , 1/2|x[t:]|^2 )  s.t.  A x <= ub     (H = diag(I_t, 0_k), g = 0)
+//
+// Replaces CQuadraticProgram::SolveQPoases (reference src/qp_wrapper.cpp:192-380).  Dual active set
+// (Goldfarb-Idnani) on the scaled least-distance form: starts at the unconstrained optimum x = 0, so a cycle
+// whose constraints are inactive costs one pass over the rows and no factorisation.  The projector onto the
+// active normals is kept as an explicit pseudo-inverse (Greville update on add, rebuild on drop) -- only
+// mat-vecs, no triangular solves on the critical path.  The final point is recomputed from the working set
+// alone by a row-sorted, column-pivoted Householder least-norm solve with the contact block weighted 1e9,
+// which is the lexicographic (min |f*_qp| first, then min |c|) optimum to ~1e-13 (DESIGN.md "QP canon").
+//   Gm  : rows x kQpLd, contact columns already multiplied by kQpScaleGI
+//   out : x (nv) in L[qp_x] unscaled;  returns 1 ok / 0 fail (infeasible or iteration cap)
+// ----------------------------------------------------------------------------------------------
+template <int N, int NB, int NT>
+DWBC_DEV void qp_greville_add(Thr th, double *L, const double *np, int q, int nv) {
+    using S = Lds<N, NB>;
+    double *Nm = L + S::qp_Nm, *Np = L + S::qp_Np, *rr = L + S::qp_r, *zz = L + S::qp_z;
+    // r = N^+ n ; z = n - N r
+    DWBC_SYNC();
+    for (int a = th.tid; a < q; a += NT) {
+        double s = 0.0;
+        for (int i = 0; i < nv; i++) s -= Np[a * kQpLd + i] * np[i];
+        rr[a] = s;
+    }
+    DWBC_SYNC();
+    for (int i = th.tid; i < nv; i += NT) {
+        double s = -np[i];
+        for (int a = 0; a < q; a++) s -= Nm[i * kQpLd + a] * rr[a];
+        zz[i] = s;
+    }
+    DWBC_SYNC();
+}
+template <int N, int NB, int NT>
+DWBC_DEV void qp_greville_commit(Thr th, double *L, const double *np, int q, int nv) {
+    using S = Lds<N, NB>;
+    double *Nm = L + S::qp_Nm, *Np = L + S::qp_Np, *rr = L + S::qp_r, *zz = L + S::qp_z;
+    double zn2 = 0.0;
+    for (int i = 0; i < nv; i++) zn2 += zz[i] * zz[i];
+    double inv = 1.0 / zn2;
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < q * nv; idx += NT) {
+        int a = idx / nv, i = idx - a * nv;
+        Np[a * kQpLd + i] -= rr[a] * zz[i] * inv;
+    }
+    for (int i = th.tid; i < nv; i += NT) {
+        Np[q * kQpLd + i] = zz[i] * inv;
+        Nm[i * kQpLd + q] = -np[i];
+    }
+    DWBC_SYNC();
+}
+
+template <int N, int NB, int NT>
+DWBC_DEV int qp_solve(Thr th, double *L, int *iL, int rows, int nv, int t, int max_iter, int *iters_out, int *nact_out,
+                      double *viol_out) {
+    using S = Lds<N, NB>;
+    double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *gn = L + S::qp_gn, *x = L + S::qp_x, *rr = L + S::qp_r, *zz = L + S::qp_z;
+    double *u = L + S::qp_u, *Nm = L + S::qp_Nm, *V = L + S::qp_V, *bb = L + S::qp_b, *ww = L + S::qp_w;
+    double *beta = L + S::qp_beta, *red = L + S::qp_red;
+    int *act = iL;          // [kQpLd]
+    int *perm = iL + 16;    // [kQpLd]
+    const int k = nv - t;
+    DWBC_SYNC();
+    for (int r = th.tid; r < rows; r += NT) {
+        double s = 0.0;
+        for (int j = 0; j < nv; j++) s += Gm[r * kQpLd + j] * Gm[r * kQpLd + j];
+        s = sqrt(s);
+        gn[r] = s < 1e-300 ? 1e-300 : s;
+    }
+    for (int j = th.tid; j < kQpLd; j += NT) { x[j] = 0.0; u[j] = 0.0; }
+    int q = 0, it = 0, status = 1;
+    for (;;) {
+        DWBC_SYNC();
+        // most violated inactive row (normalised slack)
+        double worst = 1e300;
+        int p = 0x7fffffff;
+        for (int r = th.tid; r < rows; r += NT) {
+            bool in = false;
+            for (int a = 0; a < q; a++) in = in || (act[a] == r);
+            if (in) continue;
+            double s = ub[r];
+            for (int j = 0; j < nv; j++) s -= Gm[r * kQpLd + j] * x[j];
+            s /= gn[r];
+            if (s < worst || (s == worst && r < p)) { worst = s; p = r; }
+        }
+        block_argmin<NT>(th, worst, p, red);
+        if (!(worst < -kQpTol)) break;
+        double up = 0.0;
+        bool done_inner = false;
+        while (!done_inner) {
+            if (++it > max_iter) { status = 0; break; }
+            const double *np = Gm + p * kQpLd;  // constraint normal is -np (GI is stated for n^T x >= b)
+            qp_greville_add<N, NB, NT>(th, L, np, q, nv);
+            double zn2 = 0.0, zg = 0.0, rmax = 1.0;
+            for (int i = 0; i < nv; i++) { zn2 += zz[i] * zz[i]; zg -= zz[i] * np[i]; }
+            for (int a = 0; a < q; a++) rmax = fabs(rr[a]) > rmax ? fabs(rr[a]) : rmax;
+            double t1 = INFINITY, t2 = INFINITY;
+            int l = -1;
+            for (int a = 0; a < q; a++)
+                if (rr[a] > 1e-13 * rmax) {
+                    double tj = u[a] / rr[a];
+                    if (tj < t1) { t1 = tj; l = a; }
+                }
+            double sp = ub[p];
+            for (int j = 0; j < nv; j++) sp -= Gm[p * kQpLd + j] * x[j];
+            const bool zok = sqrt(zn2) > 1e-10 * gn[p] && q < nv;
+            if (zok) t2 = -sp / zg;
+            double tstep = t1 < t2 ? t1 : t2;
+            if (!(tstep < INFINITY)) { status = 0; break; }
+            const bool full = zok && t2 <= t1;
+            DWBC_SYNC();
+            if (zok)
+                for (int i = th.tid; i < nv; i += NT) x[i] += tstep * zz[i];
+            for (int a = th.tid; a < q; a += NT) u[a] -= tstep * rr[a];
+            up += tstep;
+            DWBC_SYNC();
+            if (full) {
+                qp_greville_commit<N, NB, NT>(th, L, np, q, nv);
+                if (th.tid == 0) { act[q] = p; u[q] = up; }
+                q++;
+                done_inner = true;
+            } else {
+                // drop working-set member l and rebuild N, N^+ from the remaining columns
+                DWBC_SYNC();
+                if (th.tid == 0) {
+                    for (int a = l; a < q - 1; a++) { act[a] = act[a + 1]; u[a] = u[a + 1]; }
+                }
+                q--;
+                DWBC_SYNC();
+                for (int a = 0; a < q; a++) {
+                    const double *na = Gm + act[a] * kQpLd;
+                    qp_greville_add<N, NB, NT>(th, L, na, a, nv);
+                    qp_greville_commit<N, NB, NT>(th, L, na, a, nv);
+                }
+            }
+            DWBC_SYNC();
+        }
+        if (!status) break;
+    }
+    *iters_out = it;
+    *nact_out = q;
+    DWBC_SYNC();
+    if (!status) {
+        for (int j = th.tid; j < kQpLd; j += NT) x[j] = 0.0;
+        *viol_out = 0.0;
+        DWBC_SYNC();
+        return 0;
+    }
+    // ---- final least-norm solve on the working set: rows of N are variables, c-block first and weighted ----
+    const bool lex = (k > 0 && t > 0);
+    const double wsc = lex ? kQpScalePolish / kQpScaleGI : 1.0;
+    if (q > 0) {
+        // Nm[i][a]: i < k -> contact variable i (weighted), i >= k -> task variable i-k
+        for (int idx = th.tid; idx < nv * q; idx += NT) {
+            int i = idx / q, a = idx - i * q;
+            const int ra = act[a];
+            double v = (i < k) ? Gm[ra * kQpLd + t + i] * wsc : Gm[ra * kQpLd + (i - k)];
+            Nm[i * kQpLd + a] = v;
+        }
+        for (int a = th.tid; a < q; a += NT) { bb[a] = ub[act[a]]; perm[a] = a; }
+        for (int s = 0; s < q; s++) {
+            DWBC_SYNC();
+            // column pivot: largest remaining norm
+            int jp = s;
+            double bn = -1.0;
+            for (int a = s; a < q; a++) {
+                double c2 = 0.0;
+                for (int i = s; i < nv; i++) c2 += Nm[i * kQpLd + a] * Nm[i * kQpLd + a];
+                if (c2 > bn) { bn = c2; jp = a; }
+            }
+            DWBC_SYNC();
+            if (jp != s) {
+                for (int i = th.tid; i < nv; i += NT) { double tv = Nm[i * kQpLd + s]; Nm[i * kQpLd + s] = Nm[i * kQpLd + jp]; Nm[i * kQpLd + jp] = tv; }
+                if (th.tid == 0) { double tb = bb[s]; bb[s] = bb[jp]; bb[jp] = tb; }
+            }
+            DWBC_SYNC();
+            double nrm = 0.0;
+            for (int i = s; i < nv; i++) nrm += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
+            nrm = sqrt(nrm);
+            const double a0 = Nm[s * kQpLd + s];
+            const double alpha = a0 > 0 ? -nrm : nrm;
+            double vn2 = (a0 - alpha) * (a0 - alpha);
+            for (int i = s + 1; i < nv; i++) vn2 += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
+            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
+            DWBC_SYNC();
+            for (int i = th.tid; i < nv; i += NT) V[s * kQpLd + i] = i < s ? 0.0 : (i == s ? a0 - alpha : Nm[i * kQpLd + s]);
+            if (th.tid == 0) beta[s] = bt;
+            DWBC_SYNC();
+            for (int a = s + 1 + th.tid; a < q; a += NT) {
+                double d = 0.0;
+                for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * Nm[i * kQpLd + a];
+                d *= bt;
+                for (int i = s; i < nv; i++) Nm[i * kQpLd + a] -= d * V[s * kQpLd + i];
+            }
+            for (int i = s + th.tid; i < nv; i += NT) Nm[i * kQpLd + s] = (i == s) ? alpha : 0.0;
+        }
+        // y = R^-T b  (R = Nm[:q,:q] upper)
+        for (int c = 0; c < q; c++) {
+            DWBC_SYNC();
+            const double yc = bb[c] / Nm[c * kQpLd + c];
+            DWBC_SYNC();
+            if (th.tid == 0) bb[c] = yc;
+            for (int a = c + 1 + th.tid; a < q; a += NT) bb[a] -= Nm[c * kQpLd + a] * yc;
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < nv; i += NT) ww[i] = i < q ? bb[i] : 0.0;
+        for (int s = q - 1; s >= 0; s--) {
+            DWBC_SYNC();
+            double d = 0.0;
+            for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * ww[i];
+            d *= beta[s];
+            DWBC_SYNC();
+            for (int i = s + th.tid; i < nv; i += NT) ww[i] -= d * V[s * kQpLd + i];
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < nv; i += NT) x[i] = (i < t) ? ww[k + i] : ww[i - t] * (lex ? kQpScalePolish : kQpScaleGI);
+    } else {
+        for (int i = th.tid; i < nv; i += NT) x[i] = 0.0;
+    }
+    DWBC_SYNC();
+    // worst normalised violation of the returned point (diagnostic; rows are in GI scaling)
+    double wv = 1e300;
+    int wi = 0;
+    for (int r = th.tid; r < rows; r += NT) {
+        double s = ub[r];
+        for (int j = 0; j < nv; j++) s -= Gm[r * kQpLd + j] * (j < t ? x[j] : x[j] / kQpScaleGI);
+        s /= gn[r];
+        if (s < wv) { wv = s; wi = r; }
+    }
+    block_argmin<NT>(th, wv, wi, red);
+    *viol_out = wv;
+    DWBC_SYNC();
+    return 1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// point Jacobian (6 x N, rows [linear; angular]) of world point P fixed on body `link`
+// (CalcPointJacobian6D + row swap: reference src/link.cpp:98-119, src/contact_constraint.cpp:59-61)
+// ----------------------------------------------------------------------------------------------
+template <int N, int NB, int NT>
+DWBC_DEV void point_jacobian(Thr th, const double *L, const int *topo, int nb, int link, const double *P, double *J, int ld,
+                             int row0, int nrows, int rsel) {
+    using S = Lds<N, NB>;
+    const double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw;
+    // rsel: 0 -> rows 0..5, 1 -> linear rows only (0..2), 2 -> angular rows only (3..5)
+    for (int j = th.tid; j < N; j += NT) {
+        double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
+        if (j < 3) {
+            lin[j] = 1.0;
+        } else {
+            double w[3], o[3];
+            bool on = true;
+            if (j < 6) {
+                for (int a = 0; a < 3; a++) { w[a] = Rw[a * 3 + (j - 3)]; o[a] = pw[a]; }
+            } else {
+                const int b = j - 5;
+                on = (b <= link) && (link < b + topo[2 * nb + b]);
+                for (int a = 0; a < 3; a++) { w[a] = aw[b * 3 + a]; o[a] = pw[b * 3 + a]; }
+            }
+            if (on) {
+                const double d0 = P[0] - o[0], d1 = P[1] - o[1], d2 = P[2] - o[2];
+                lin[0] = w[1] * d2 - w[2] * d1;
+                lin[1] = w[2] * d0 - w[0] * d2;
+                lin[2] = w[0] * d1 - w[1] * d0;
+                ang[0] = w[0]; ang[1] = w[1]; ang[2] = w[2];
+            }
+        }
+        if (rsel == 0) {
+            for (int a = 0; a < 3; a++) { J[(row0 + a) * ld + j] = lin[a]; J[(row0 + 3 + a) * ld + j] = ang[a]; }
+        } else if (rsel == 1) {
+            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j] = lin[a];
+        } else {
+            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j] = ang[a];
+        }
+    }
+    (void)nrows;
+}
+
+// ----------------------------------------------------------------------------------------------
+// the fused cycle for one instance
+// ----------------------------------------------------------------------------------------------
+template <int N, int NB, int NT>
+DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int inst, double *L, int *iL) {
+    using S = Lds<N, NB>;
+    constexpr int M = S::M, C = S::C, T = S::T;
+    const int nb = su.nb;
+    const double *body = io.body;
+    const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
+    const double *qin = io.q + (size_t)inst * (N + 1);
+    const DumpLayout dl = DumpLayout::make(N);
+    double *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
+    int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
+
+    // ================= stage 0: kinematics, A, A_inv, G  (src/dwbc.cpp:279-371) =================
+    for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
+    for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = 0.0;
+    DWBC_SYNC();
+    {
+        double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw, *Rl = L + S::k_Rl;
+        const double *q = L + S::q;
+        // local joint transforms R_T * Rot(axis, q_i)
+        for (int i = th.tid; i < nb; i += NT) {
+            const double *bd = body + i * kBodyStride;
+            if (i == 0) {
+                const double x = q[3], y = q[4], z = q[5], w = q[N];
+                double *R = Rw;
+                R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+                R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
+                R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
+                pw[0] = q[0]; pw[1] = q[1]; pw[2] = q[2];
+            } else {
+                const double ax = bd[BF_AXIS], ay = bd[BF_AXIS + 1], az = bd[BF_AXIS + 2];
+                double sn, cs;
+                sincos(q[6 + i - 1], &sn, &cs);
+                const double c1 = 1.0 - cs;
+                double Rj[9];
+                Rj[0] = cs + ax * ax * c1; Rj[1] = ax * ay * c1 - az * sn; Rj[2] = ax * az * c1 + ay * sn;
+                Rj[3] = ay * ax * c1 + az * sn; Rj[4] = cs + ay * ay * c1; Rj[5] = ay * az * c1 - ax * sn;
+                Rj[6] = az * ax * c1 - ay * sn; Rj[7] = az * ay * c1 + ax * sn; Rj[8] = cs + az * az * c1;
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++)
+                        Rl[i * 9 + a * 3 + b] = bd[BF_RT + a * 3] * Rj[b] + bd[BF_RT + a * 3 + 1] * Rj[3 + b] + bd[BF_RT + a * 3 + 2] * Rj[6 + b];
+            }
+        }
+        for (int d = 1; d <= su.maxdepth; d++) {
+            DWBC_SYNC();
+            for (int i = th.tid; i < nb; i += NT) {
+                if (topo[nb + i] != d) continue;
+                const int par = topo[i];
+                const double *bd = body + i * kBodyStride;
+                const double *Rp = Rw + par * 9;
+                for (int a = 0; a < 3; a++) {
+                    for (int b = 0; b < 3; b++)
+                        Rw[i * 9 + a * 3 + b] = Rp[a * 3] * Rl[i * 9 + b] + Rp[a * 3 + 1] * Rl[i * 9 + 3 + b] + Rp[a * 3 + 2] * Rl[i * 9 + 6 + b];
+                    pw[i * 3 + a] = pw[par * 3 + a] + Rp[a * 3] * bd[BF_PT] + Rp[a * 3 + 1] * bd[BF_PT + 1] + Rp[a * 3 + 2] * bd[BF_PT + 2];
+                }
+            }
+        }
+        DWBC_SYNC();
+        // world axes, world-frame spatial inertia of each body about O = pelvis origin
+        double *Iw = L + S::k_Iw;
+        for (int i = th.tid; i < nb; i += NT) {
+            const double *bd = body + i * kBodyStride;
+            const double *R = Rw + i * 9;
+            for (int a = 0; a < 3; a++) aw[i * 3 + a] = R[a * 3] * bd[BF_AXIS] + R[a * 3 + 1] * bd[BF_AXIS + 1] + R[a * 3 + 2] * bd[BF_AXIS + 2];
+            const double m = bd[BF_MASS];
+            double r[3];
+            for (int a = 0; a < 3; a++)
+                r[a] = pw[i * 3 + a] + R[a * 3] * bd[BF_COM] + R[a * 3 + 1] * bd[BF_COM + 1] + R[a * 3 + 2] * bd[BF_COM + 2] - pw[a];
+            const double Ic[9] = {bd[BF_ICOM], bd[BF_ICOM + 1], bd[BF_ICOM + 2], bd[BF_ICOM + 1], bd[BF_ICOM + 3],
+                                  bd[BF_ICOM + 4], bd[BF_ICOM + 2], bd[BF_ICOM + 4], bd[BF_ICOM + 5]};
+            double Tm[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Tm[a * 3 + b] = R[a * 3] * Ic[b] + R[a * 3 + 1] * Ic[3 + b] + R[a * 3 + 2] * Ic[6 + b];
+            const double rr2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            double *o = Iw + i * 10;
+            o[0] = m;
+            o[1] = m * r[0]; o[2] = m * r[1]; o[3] = m * r[2];
+            int c = 4;
+            for (int a = 0; a < 3; a++)
+                for (int b = a; b < 3; b++) {
+                    double v = Tm[a * 3] * R[b * 3] + Tm[a * 3 + 1] * R[b * 3 + 1] + Tm[a * 3 + 2] * R[b * 3 + 2];
+                    v += m * ((a == b ? rr2 : 0.0) - r[a] * r[b]);
+                    o[c++] = v;
+                }
+        }
+        DWBC_SYNC();
+        // composite inertia: subtree of body i is the contiguous DFS range [i, i + subtree[i])
+        double *Icm = L + S::k_Ic;
+        for (int idx = th.tid; idx < nb * 10; idx += NT) {
+            const int i = idx / 10, c = idx - i * 10;
+            const int e = i + topo[2 * nb + i];
+            double s = 0.0;
+            for (int j = i; j < e; j++) s += Iw[j * 10 + c];
+            Icm[idx] = s;
+        }
+        // motion axes S_j = [omega; v_O] about O
+        double *Sm = L + S::k_S, *Fm = L + S::k_F;
+        for (int j = th.tid; j < N; j += NT) {
+            double w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+            if (j < 3) {
+                v[j] = 1.0;
+            } else if (j < 6) {
+                for (int a = 0; a < 3; a++) w[a] = Rw[a * 3 + (j - 3)];
+            } else {
+                const int b = j - 5;
+                for (int a = 0; a < 3; a++) w[a] = aw[b * 3 + a];
+                const double d0 = pw[b * 3] - pw[0], d1 = pw[b * 3 + 1] - pw[1], d2 = pw[b * 3 + 2] - pw[2];
+                v[0] = d1 * w[2] - d2 * w[1];
+                v[1] = d2 * w[0] - d0 * w[2];
+                v[2] = d0 * w[1] - d1 * w[0];
+            }
+            for (int a = 0; a < 3; a++) { Sm[j * 6 + a] = w[a]; Sm[j * 6 + 3 + a] = v[a]; }
+        }
+        for (int idx = th.tid; idx < N * N; idx += NT) L[S::bufA + idx] = 0.0;
+        DWBC_SYNC();
+        for (int j = th.tid; j < N; j += NT) {
+            const int b = j < 6 ? 0 : j - 5;
+            const double *I = Icm + b * 10;
+            const double *s = Sm + j * 6;
+            const double m = I[0], h0 = I[1], h1 = I[2], h2 = I[3];
+            const double w0 = s[0], w1 = s[1], w2 = s[2], v0 = s[3], v1 = s[4], v2 = s[5];
+            // L = I w + h x v ; p = m v + w x h
+            Fm[j * 6 + 0] = I[4] * w0 + I[5] * w1 + I[6] * w2 + (h1 * v2 - h2 * v1);
+            Fm[j * 6 + 1] = I[5] * w0 + I[7] * w1 + I[8] * w2 + (h2 * v0 - h0 * v2);
+            Fm[j * 6 + 2] = I[6] * w0 + I[8] * w1 + I[9] * w2 + (h0 * v1 - h1 * v0);
+            Fm[j * 6 + 3] = m * v0 + (w1 * h2 - w2 * h1);
+            Fm[j * 6 + 4] = m * v1 + (w2 * h0 - w0 * h2);
+            Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
+        }
+        DWBC_SYNC();
+        // A[j][k] = S_k . F_j for k on the path from j to the root (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm)
+        double *A = L + S::bufA;
+        for (int j = th.tid; j < N; j += NT) {
+            const double *f = Fm + j * 6;
+            int k = j;
+            for (;;) {
+                const double *s = Sm + k * 6;
+                const double v = s[0] * f[0] + s[1] * f[1] + s[2] * f[2] + s[3] * f[3] + s[4] * f[4] + s[5] * f[5];
+                A[j * N + k] = v;
+                A[k * N + j] = v;
+                if (k == 0) break;
+                if (k < 6) k = k - 1;
+                else {
+                    const int pb = topo[k - 5];
+                    k = pb == 0 ? 5 : pb + 5;
+                }
+            }
+        }
+        DWBC_SYNC();
+        for (int j = th.tid; j < N; j += NT) L[S::G + j] = kGrav * A[2 * N + j];  // G_ = -J_com_lin^T m g (dwbc.cpp:358)
+        if (dump) {
+            for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A + idx] = A[idx];
+            for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
+            for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
+        }
+    }
+    int st_contact = 1;
+    // A_inv = llt(A).solve(I)  (dwbc.cpp:307): bufA (A) -> bufA (A_inv), bufN scratch
+    {
+        int ok = spd_inverse<NT>(th, L + S::bufA, N, L + S::bufN, L + S::tmp + 0);  // Out into tmp (N*N fits: checked below)
+        static_assert(S::k_end - S::tmp >= 0, "");
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < N * N; idx += NT) L[S::bufA + idx] = L[S::tmp + idx];
+        DWBC_SYNC();
+        if (!ok) st_contact = 0;
+        if (dump) {
+            for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A_inv + idx] = L[S::bufA + idx];
+            for (int j = th.tid; j < N; j += NT) dump[dl.G + j] = L[S::G + j];
+        }
+    }
+
+    // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
+    const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
+    int act_c[kMaxActiveContacts];
+    int nc = 0;
+    for (int i = 0; i < su.n_contacts; i++)
+        if (fl[i] && nc < kMaxActiveContacts) act_c[nc++] = i;
+    const int cd = 6 * nc, k = cd > 6 ? cd - 6 : 0;
+    DWBC_SYNC();
+    for (int a = 0; a < nc; a++) {
+        const int ci = act_c[a], link = su.c_link[ci];
+        const double *R = L + S::Rw + link * 9;
+        for (int r = th.tid; r < 12; r += NT) {
+            if (r < 9) L[S::Rc + a * 9 + r] = R[r];
+            else {
+                const int x = r - 9;
+                L[S::Pc + a * 3 + x] = L[S::pw + link * 3 + x] + R[x * 3] * su.c_point[ci][0] + R[x * 3 + 1] * su.c_point[ci][1] + R[x * 3 + 2] * su.c_point[ci][2];
+            }
+        }
+    }
+    DWBC_SYNC();
+    for (int a = 0; a < nc; a++)
+        point_jacobian<N, NB, NT>(th, L, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, L + S::JC, N, 6 * a, 6, 0);
+    DWBC_SYNC();
+    {
+        double *Ai = L + S::bufA, *JC = L + S::JC, *Y = L + S::c_Y, *Lam = L + S::Lam, *JbT = L + S::JbT, *AiNc = L + S::bufN;
+        mm_nn<NT>(th, Y, N, JC, N, Ai, N, cd, N, N);                 // Y = J_C A^-1
+        DWBC_SYNC();
+        mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);      // J A^-1 J^T
+        if (cd > 0) {
+            double cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);  // Lambda_c (wbd.cpp:115)
+            if (!(cond > 1e-14)) st_contact = 0;
+        }
+        mm_nn<NT>(th, JbT, N, Lam, cd, Y, N, cd, cd, N);             // J̄^T = Lambda J A^-1 (wbd.cpp:116)
+        DWBC_SYNC();
+        // A^-1 N_c = A^-1 - Y^T J̄^T   (wbd.cpp:117-118 without materialising N_c)
+        for (int idx = th.tid; idx < N * N; idx += NT) {
+            const int i = idx / N, j = idx - i * N;
+            double s = Ai[idx];
+            for (int p = 0; p < cd; p++) s -= Y[p * N + i] * JbT[p * N + j];
+            AiNc[idx] = s;
+        }
+        DWBC_SYNC();
+        if (dump) {
+            for (int idx = th.tid; idx < cd * N; idx += NT) { dump[dl.J_C + idx] = JC[idx]; dump[dl.J_C_INV_T + idx] = JbT[idx]; }
+            for (int idx = th.tid; idx < cd * cd; idx += NT) dump[dl.Lambda_c + idx] = Lam[idx];
+            for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A_inv_N_C + idx] = AiNc[idx];
+        }
+        // ---- W^+ and NwJw.  null(W) is known in closed form: W = S A^-1 N_c S^T vanishes exactly on
+        //      { J_C[:,6:]^T lam : J_C[:,:6]^T lam = 0 } (internal wrenches), so V2's span needs no pivoted QR.
+        double *Winv = L + S::bufA;  // A_inv is dead from here on
+        double *W1 = L + S::c_W1, *P = L + S::c_P, *Vb = L + S::c_Vb;
+        if (k > 0) {
+            // basis of internal wrenches: (f_i, m_i) = e_a on contact i>=1, balanced on contact 0
+            const double *Pc = L + S::Pc;
+            for (int idx = th.tid; idx < M * k; idx += NT) {
+                const int r = idx / k, a = idx - r * k;
+                const int ci = 1 + a / 6, e = a % 6;
+                double f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+                if (e < 3) f2[e] = 1.0; else m2[e - 3] = 1.0;
+                const double d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
+                const double m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
+                const double m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
+                const double m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
+                const double *J0 = JC, *J1 = JC + 6 * ci * N;
+                const int col = 6 + r;
+                double s = -f2[0] * J0[0 * N + col] - f2[1] * J0[1 * N + col] - f2[2] * J0[2 * N + col];
+                s += m1x * J0[3 * N + col] + m1y * J0[4 * N + col] + m1z * J0[5 * N + col];
+                s += f2[0] * J1[0 * N + col] + f2[1] * J1[1 * N + col] + f2[2] * J1[2 * N + col];
+                s += m2[0] * J1[3 * N + col] + m2[1] * J1[4 * N + col] + m2[2] * J1[5 * N + col];
+                Vb[idx] = s;
+            }
+            DWBC_SYNC();
+            // NwJw = Vb (J̄[0:k,6:] Vb)^-1   (wbd.cpp:128; invariant to the choice of basis of span(V2^T))
+            for (int idx = th.tid; idx < k * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                double s = 0.0;
+                for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * Vb[c * k + j];
+                L[S::c_s2 + idx] = s;
+            }
+            double cond = gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+            if (!(cond > 1e-13)) st_contact = 0;
+            mm_nn<NT>(th, L + S::NwJw, k, Vb, k, L + S::c_s2, k, M, k, k);
+            DWBC_SYNC();
+            // projector on null(W):  P = Vb (Vb^T Vb)^-1 Vb^T
+            mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
+            gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+            // W1 (M x k) temporarily = Vb * Gi  (stored in first M*k of W1)
+            mm_nn<NT>(th, W1, k, Vb, k, L + S::c_s2, k, M, k, k);
+            DWBC_SYNC();
+            mm_nt<NT>(th, P, M, W1, k, Vb, k, M, k, M);
+            DWBC_SYNC();
+        }
+        // alpha = trace(W)/M ;  W + alpha P is SPD ;  W^+ = (W + alpha P)^-1 - P/alpha
+        double alpha = 0.0;
+        for (int i = 0; i < M; i++) alpha += AiNc[(6 + i) * N + 6 + i];
+        alpha /= M;
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < M * M; idx += NT) {
+            const int i = idx / M, j = idx - i * M;
+            // symmetrise: W is symmetric in exact arithmetic
+            double w = 0.5 * (AiNc[(6 + i) * N + 6 + j] + AiNc[(6 + j) * N + 6 + i]);
+            W1[idx] = w + (k > 0 ? alpha * P[idx] : 0.0);
+        }
+        DWBC_SYNC();
+        {
+            // spd_inverse scratch: reuse c_Y.. region? it is M*M <= C*N + M*K + ... : use c_Y (C*N=468 < M*M) -> not enough.
+            // Use bufA itself as Tmp and write the result to W1's neighbour P afterwards.
+            double *Tmp = L + S::bufA;
+            double *Out = L + S::c_Y;  // c_Y..c_s2 span: C*N + M*K + C*2C + C*C = 468+198+288+144 = 1098 >= M*M (1089) for N=39
+            static_assert(S::c_P - S::c_Y >= M * M, "scratch for W inverse too small");
+            // keep P: copy needed part first
+            int ok = spd_inverse<NT>(th, W1, M, Tmp, Out);
+            if (!ok) st_contact = 0;
+            DWBC_SYNC();
+            const double ia = alpha != 0.0 ? 1.0 / alpha : 0.0;
+            for (int idx = th.tid; idx < M * M; idx += NT) Winv[idx] = Out[idx] - (k > 0 ? P[idx] * ia : 0.0);
+            DWBC_SYNC();
+        }
+        if (dump) {
+            for (int idx = th.tid; idx < M * M; idx += NT) dump[dl.W_inv + idx] = Winv[idx];
+            for (int idx = th.tid; idx < M * k; idx += NT) { dump[dl.NwJw + idx] = L[S::NwJw + idx]; }
+        }
+        // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
+        if (k > 0) {
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < cd * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                double s = 0.0;
+                for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
+                L[S::c_s1 + idx] = s;
+            }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < cd * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+                const double *R = L + S::Rc + a * 9;
+                const double *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
+                L[S::FNl + idx] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[k] + R[2 * 3 + x] * src[2 * k];
+            }
+        }
+        DWBC_SYNC();
+        // ================= stage 2: gravity compensation (wbd.cpp:186-192) =================
+        mv_n<NT>(th, L + S::c_vec, AiNc + 6 * N, N, L + S::G, M, N);  // A^-1[6:,:] N_c G
+        DWBC_SYNC();
+        mv_n<NT>(th, L + S::tg, Winv, M, L + S::c_vec, M, M);
+        mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
+        DWBC_SYNC();
+        if (dump)
+            for (int i = th.tid; i < cd; i += NT) dump[dl.P_C + i] = L[S::PC + i];
+    }
+
+    // ================= stage 3: task cascade (dwbc.cpp:685-873, 941-1127; wbd.cpp:207-261) =================
+    const int nlim = su.has_tau_lim ? 2 * M : 0;
+    const int ncone = 10 * nc;
+    int st_task = 1, fail_level = -1;
+    const double *fs_in = io.fstar + (size_t)inst * su.fstar_total;
+    {
+        double *Winv = L + S::bufA, *AiNc = L + S::bufN, *JbT = L + S::JbT;
+        for (int lv = 0; lv < su.n_levels && st_task; lv++) {
+            const int t = su.t_dof[lv], nv = t + k;
+            double *Jt = L + S::t_Jt, *T1 = L + S::t_T1, *Lt = L + S::t_Lt, *Q = L + S::t_Q, *QW = L + S::t_QW, *Jkt = L + S::t_Jkt, *U = L + S::t_U;
+            // --- J_task rows by link mode (dwbc.cpp:709-788)
+            DWBC_SYNC();
+            int row = 0;
+            for (int li = 0; li < su.t_nlinks[lv]; li++) {
+                const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
+                double pl[3] = {0, 0, 0};
+                if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
+                    for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
+                else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
+                    for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
+                const double *R = L + S::Rw + link * 9;
+                double P[3];
+                for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+                if (mode <= TASK_LINK_6D_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 6, 0); row += 6; }
+                else if (mode <= TASK_LINK_POSITION_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 3, 1); row += 3; }
+                else { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 3, 2); row += 3; }
+            }
+            DWBC_SYNC();
+            // --- CalculateJKT (wbd.cpp:207-213)
+            mm_nn<NT>(th, T1, N, Jt, N, AiNc, N, t, N, N);           // J_t A^-1 N_c
+            DWBC_SYNC();
+            mm_nt<NT>(th, L + S::t_s2, t, T1, N, Jt, N, t, N, t);
+            gj_inverse<NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task
+            for (int idx = th.tid; idx < t * M; idx += NT) {             // Q = (Lambda J A^-1 N_c)[:,6:]
+                const int i = idx / M, j = idx - i * M;
+                double s = 0.0;
+                for (int p = 0; p < t; p++) s += Lt[i * t + p] * T1[p * N + 6 + j];
+                Q[idx] = s;
+            }
+            DWBC_SYNC();
+            mm_nn<NT>(th, QW, M, Q, M, Winv, M, t, M, M);              // Q W^+
+            DWBC_SYNC();
+            mm_nt<NT>(th, L + S::t_s2, t, QW, M, Q, M, t, M, t);       // Q W^+ Q^T
+            double cond = gj_inverse<NT>(th, L + S::t_s2, t, t, L + S::t_s3, t, L + S::t_s1);  // PinvCODWB (full rank case)
+            if (!(cond > 1e-6)) { st_task = 0; fail_level = lv; }
+            for (int idx = th.tid; idx < M * t; idx += NT) {             // J_kt = W^+ Q^T pinv(.)
+                const int i = idx / t, j = idx - i * t;
+                double s = 0.0;
+                for (int p = 0; p < t; p++) s += QW[p * M + i] * L[S::t_s3 + p * t + j];
+                Jkt[idx] = s;
+            }
+            DWBC_SYNC();
+            // X = J_kt Lambda ;  Y = (J_t A^-1 N_c)[:,6:]   => Null_i = Null_{i-1} (I - X Y)   (wbd.cpp:257-261)
+            double *X = (lv < kMaxLevels - 1) ? L + S::Xl + lv * M * T : L + S::t_QW;
+            for (int idx = th.tid; idx < M * t; idx += NT) {
+                const int i = idx / t, j = idx - i * t;
+                double s = 0.0;
+                for (int p = 0; p < t; p++) s += Jkt[i * t + p] * Lt[p * t + j];
+                X[i * T + j] = s;
+                U[i * T + j] = s;
+            }
+            if (lv < kMaxLevels - 1)
+                for (int idx = th.tid; idx < t * M; idx += NT) {
+                    const int i = idx / M, j = idx - i * M;
+                    L[S::Yl + lv * T * M + idx] = T1[i * N + 6 + j];
+                }
+            DWBC_SYNC();
+            if (dump) {
+                for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jt[idx];
+                for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
+                for (int idx = th.tid; idx < M * t; idx += NT) dump[dl.J_kt + lv * M * T + idx] = Jkt[idx];
+            }
+            // U = Null_{lv-1} X = (I - X0 Y0)(I - X1 Y1)...(I - X_{lv-1} Y_{lv-1}) X   -- applied right to left
+            for (int pl = lv - 1; pl >= 0; pl--) {
+                const int tp = su.t_dof[pl];
+                const double *Xp = L + S::Xl + pl * M * T, *Yp = L + S::Yl + pl * T * M;
+                DWBC_SYNC();
+                for (int idx = th.tid; idx < tp * t; idx += NT) {       // Z = Yp U  (tp x t)
+                    const int i = idx / t, j = idx - i * t;
+                    double s = 0.0;
+                    for (int c = 0; c < M; c++) s += Yp[i * M + c] * U[c * T + j];
+                    L[S::t_s2 + idx] = s;
+                }
+                DWBC_SYNC();
+                for (int idx = th.tid; idx < M * t; idx += NT) {
+                    const int i = idx / t, j = idx - i * t;
+                    double s = U[i * T + j];
+                    for (int p = 0; p < tp; p++) s -= Xp[i * T + p] * L[S::t_s2 + p * t + j];
+                    U[i * T + j] = s;
+                }
+            }
+            DWBC_SYNC();
+            // --- QP rows (dwbc.cpp:988-1053)
+            const double *fs = fs_in + su.fstar_off[lv];
+            double *base = L + S::t_base, *Gm = L + S::qp_G, *ub = L + S::qp_ub, *F = L + S::t_F, *fv = L + S::t_fv;
+            for (int i = th.tid; i < M; i += NT) {
+                double s = L[S::tg + i] + L[S::tt + i];
+                for (int j = 0; j < t; j++) s += U[i * T + j] * fs[j];
+                base[i] = s;
+            }
+            DWBC_SYNC();
+            if (nlim)
+                for (int idx = th.tid; idx < M * nv; idx += NT) {
+                    const int i = idx / nv, j = idx - i * nv;
+                    const double v = j < t ? U[i * T + j] : L[S::NwJw + i * k + (j - t)] * kQpScaleGI;
+                    Gm[i * kQpLd + j] = v;
+                    Gm[(M + i) * kQpLd + j] = -v;
+                    if (j == 0) { ub[i] = su.tau_lim[i] - base[i]; ub[M + i] = su.tau_lim[i] + base[i]; }
+                }
+            // contact wrench map in the contact-local frame: F (cd x t) = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
+            for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
+                const int i = idx / (t + 1), j = idx - i * (t + 1);
+                double s = 0.0;
+                if (j < t) { for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * U[c * T + j]; }
+                else { for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * base[c]; s -= L[S::PC + i]; }
+                L[S::t_s1 + i * (T + 1) + j] = s;  // T+1 = 7 columns; C x 7 = 84 <= T*2T = 72?  -> use qp_Nm.. as scratch
+            }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
+                const int i = idx / (t + 1), j = idx - i * (t + 1);
+                const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+                const double *R = L + S::Rc + a * 9;
+                const double *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
+                const double v = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[T + 1] + R[2 * 3 + x] * src[2 * (T + 1)];
+                if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
+            }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < ncone * (nv + 1); idx += NT) {
+                const int rr_ = idx / (nv + 1), j = idx - rr_ * (nv + 1);
+                const int a = rr_ / 10, r = rr_ % 10, ci = act_c[a];
+                double w[6];
+                if (j < t) for (int c = 0; c < 6; c++) w[c] = F[(6 * a + c) * kQpLd + j];
+                else if (j < nv) for (int c = 0; c < 6; c++) w[c] = L[S::FNl + (6 * a + c) * k + (j - t)] * kQpScaleGI;
+                else for (int c = 0; c < 6; c++) w[c] = fv[6 * a + c];
+                const double v = cone_row(r, su.c_lx[ci], su.c_ly[ci], su.c_mu[ci], su.c_muz[ci], w);
+                if (j < nv) Gm[(nlim + rr_) * kQpLd + j] = -v; else ub[nlim + rr_] = v;
+            }
+            DWBC_SYNC();
+            int iters = 0, nact = 0;
+            double viol = 0.0;
+            int ok = qp_solve<N, NB, NT>(th, L, iL, nlim + ncone, nv, t, su.qp_max_iter_task, &iters, &nact, &viol);
+            if (diag && th.tid == 0) {
+                diag[DG_QP_ITER + lv] = iters;
+                diag[DG_QP_NACT + lv] = nact;
+                for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = a < nact ? iL[a] : -1;
+            }
+            if (dump && th.tid == 0) dump[dl.qp_viol + lv] = viol;
+            if (!ok) { st_task = 0; fail_level = lv; break; }  // f_star_qp_, contact_qp_ zero; cascade aborts (dwbc.cpp:836,1119)
+            const double *x = L + S::qp_x;
+            // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp) ; torque_contact_ = NwJw contact_qp_ (dwbc.cpp:839-851)
+            for (int i = th.tid; i < M; i += NT) {
+                double s = 0.0;
+                for (int j = 0; j < t; j++) s += U[i * T + j] * (fs[j] + x[j]);
+                L[S::tt + i] += s;
+                double c = 0.0;
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
+                L[S::tc + i] = c;
+            }
+            if (dump) {
+                for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + lv * T + j] = x[j];
+                for (int j = th.tid; j < k; j += NT) dump[dl.contact_qp + lv * (C - 6) + j] = x[t + j];
+            }
+            DWBC_SYNC();
+        }
+    }
+
+    // ================= stage 4: contact redistribution (dwbc.cpp:1372-1568) =================
+    int st_redis = 1;
+    if (k > 0) {
+        double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *base = L + S::t_base, *fv = L + S::t_fv, *JbT = L + S::JbT;
+        DWBC_SYNC();
+        for (int i = th.tid; i < M; i += NT) base[i] = L[S::tg + i] + L[S::tt + i] + L[S::tc + i];
+        DWBC_SYNC();
+        if (nlim)
+            for (int idx = th.tid; idx < M * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                const double v = L[S::NwJw + i * k + j];
+                Gm[i * kQpLd + j] = v;
+                Gm[(M + i) * kQpLd + j] = -v;
+                if (j == 0) { ub[i] = su.tau_lim[i] - base[i]; ub[M + i] = su.tau_lim[i] + base[i]; }
+            }
+        for (int i = th.tid; i < cd; i += NT) {
+            double s = -L[S::PC + i];
+            for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * base[c];
+            L[S::t_s1 + i] = s;
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < cd; i += NT) {
+            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+            const double *R = L + S::Rc + a * 9;
+            const double *src = L + S::t_s1 + 6 * a + 3 * h;
+            fv[i] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[1] + R[2 * 3 + x] * src[2];
+        }
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < ncone * (k + 1); idx += NT) {
+            const int rr_ = idx / (k + 1), j = idx - rr_ * (k + 1);
+            const int a = rr_ / 10, r = rr_ % 10, ci = act_c[a];
+            double w[6];
+            if (j < k) for (int c = 0; c < 6; c++) w[c] = L[S::FNl + (6 * a + c) * k + j];
+            else for (int c = 0; c < 6; c++) w[c] = fv[6 * a + c];
+            const double v = cone_row(r, su.c_lx[ci], su.c_ly[ci], su.c_mu[ci], su.c_muz[ci], w);
+            if (j < k) Gm[(nlim + rr_) * kQpLd + j] = -v; else ub[nlim + rr_] = v;
+        }
+        DWBC_SYNC();
+        int iters = 0, nact = 0;
+        double viol = 0.0;
+        int ok = qp_solve<N, NB, NT>(th, L, iL, nlim + ncone, k, k, su.qp_max_iter_contact, &iters, &nact, &viol);
+        if (diag && th.tid == 0) {
+            diag[DG_QP_ITER + kMaxLevels] = iters;
+            diag[DG_QP_NACT + kMaxLevels] = nact;
+            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = a < nact ? iL[a] : -1;
+        }
+        if (dump && th.tid == 0) dump[dl.qp_viol + kMaxLevels] = viol;
+        const double *x = L + S::qp_x;
+        if (ok) {
+            for (int i = th.tid; i < M; i += NT) {
+                double c = 0.0;
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
+                L[S::tc + i] += c;
+            }
+            if (dump)
+                for (int j = th.tid; j < k; j += NT) dump[dl.cf_redis + j] = x[j];
+        } else {
+            st_redis = 0;
+            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;
+        }
+    } else {
+        for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1562-1567
+    }
+    DWBC_SYNC();
+
+    // ================= outputs =================
+    double *tau = io.tau + (size_t)inst * 3 * M;
+    for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
+    double *wr = io.wrench + (size_t)inst * 12;
+    for (int i = th.tid; i < 12; i += NT) {
+        double s = 0.0;
+        if (i < cd) {
+            s = -L[S::PC + i];
+            for (int c = 0; c < M; c++) s += L[S::JbT + i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);
+        }
+        wr[i] = s;  // getContactForce(tau_total), wbd.cpp:268-271
+    }
+    if (th.tid == 0) {
+        io.status[inst] = (st_contact && st_task && st_redis) ? 1 : 0;
+        if (diag) {
+            diag[DG_ST_CONTACT] = st_contact;
+            diag[DG_ST_TASK] = st_task;
+            diag[DG_ST_REDIS] = st_redis;
+            diag[DG_FAIL_LEVEL] = fail_level;
+        }
+    }
+}
+
+}  // namespace dwbc

@@ -1,0 +1,76 @@
+// dwbc_setup.h -- host-side construction of the shared problem Setup (contacts, task hierarchy, limits).
+// Mirrors RobotData::AddContactConstraint / AddTaskSpace / SetTorqueLimit (reference src/dwbc.cpp:377-427,
+// 522-601, 254-258).  Used by the C-ABI layer and by the CPU emulation harness under tests/emu.
+#pragma once
+#include <string>
+
+#include "dwbc_types.h"
+
+namespace dwbc {
+
+inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
+    su = Setup{};
+    su.nb = nb;
+    su.ndof = ndof;
+    su.maxdepth = maxdepth;
+    su.qp_max_iter_task = 1000;    // reference src/dwbc.cpp:1080
+    su.qp_max_iter_contact = 300;  // reference src/dwbc.cpp:1546
+}
+
+inline int task_mode_dof(int mode) { return mode <= TASK_LINK_6D_CUSTOM_FRAME ? 6 : 3; }  // reference src/task.cpp:14-31
+
+inline void setup_fstar_layout(Setup &su) {
+    int off = 0;
+    for (int l = 0; l < su.n_levels; l++) {
+        int t = 0;
+        for (int j = 0; j < su.t_nlinks[l]; j++) t += task_mode_dof(su.t_mode[l][j]);
+        su.t_dof[l] = t;
+        su.fstar_off[l] = off;
+        off += t;
+    }
+    su.fstar_total = off;
+}
+
+// returns contact index or -1 (err filled)
+inline int setup_add_contact(Setup &su, int link, int contact_type, const double point[3], double lx, double ly, double mu,
+                             double mu_z, std::string &err) {
+    if (contact_type != 0) { err = "only CONTACT_6D is implemented on the device path"; return -1; }
+    if (link < 0 || link >= su.nb) { err = "bad link id"; return -1; }
+    if (su.n_contacts >= kMaxContacts) { err = "too many contacts"; return -1; }
+    for (int i = 0; i < su.n_contacts; i++)
+        if (su.c_link[i] == link) { err = "Contact Constraint Already Exist for Link"; return -1; }  // src/dwbc.cpp:379-386
+    const int i = su.n_contacts++;
+    su.c_link[i] = link;
+    for (int a = 0; a < 3; a++) su.c_point[i][a] = point[a];
+    su.c_lx[i] = lx;
+    su.c_ly[i] = ly;
+    su.c_mu[i] = mu;
+    su.c_muz[i] = mu_z;
+    return i;
+}
+
+inline bool setup_add_task(Setup &su, int level, int mode, int link, const double *point, std::string &err) {
+    if (level < 0 || level > su.n_levels || level >= kMaxLevels) { err = "bad task level (levels must be added in order)"; return false; }
+    if (mode < 0 || mode > TASK_LINK_ROTATION_CUSTOM_FRAME) { err = "bad task mode"; return false; }
+    if (link < 0 || link >= su.nb) { err = "bad link id"; return false; }
+    for (int l = 0; l < su.n_levels; l++)
+        for (int j = 0; j < su.t_nlinks[l]; j++)
+            if (su.t_link[l][j] == link) { err = "Task Space Already Exist for Link"; return false; }  // src/dwbc.cpp:536-546
+    const int j = level == su.n_levels ? 0 : su.t_nlinks[level];
+    if (j >= kMaxTaskLinks) { err = "too many links in one task level"; return false; }
+    int cur = 0;
+    for (int a = 0; a < j; a++) cur += task_mode_dof(su.t_mode[level][a]);
+    if (cur + task_mode_dof(mode) > kMaxTaskDof) { err = "task level exceeds 6 dof"; return false; }
+    if (level == su.n_levels) {
+        su.n_levels++;
+        su.t_nlinks[level] = 0;
+    }
+    su.t_mode[level][j] = mode;
+    su.t_link[level][j] = link;
+    for (int a = 0; a < 3; a++) su.t_point[level][j][a] = point ? point[a] : 0.0;
+    su.t_nlinks[level]++;
+    setup_fstar_layout(su);
+    return true;
+}
+
+}  // namespace dwbc

@@ -1,0 +1,112 @@
+// dwbc_types.h -- POD structures shared by the host C-ABI layer and the HIP kernels.
+// MI355X-native batched libdwbc hot path; see DESIGN.md.  No torch / Eigen types here.
+#pragma once
+#include <stdint.h>
+#if !defined(__HIPCC__) && !defined(__host__)
+#define __host__
+#define __device__
+#endif
+
+namespace dwbc {
+
+constexpr int kMaxBodies = 48;
+constexpr int kMaxContacts = 4;       // registered contacts (reference tests register 4: tests/dwbc_test.cpp:66-69)
+constexpr int kMaxActiveContacts = 2; // simultaneously active 6D contacts the fused kernel is sized for
+constexpr int kMaxLevels = 4;
+constexpr int kMaxTaskLinks = 2;
+constexpr int kMaxTaskDof = 6;        // per level (one 6D link or two 3-dof links)
+constexpr int kBodyStride = 25;       // doubles per body in the device model table
+
+// per-body record (doubles): R_T[9] p_T[3] axis[3] mass com[3] Icom[6]{xx,xy,xz,yy,yz,zz}
+enum BodyField { BF_RT = 0, BF_PT = 9, BF_AXIS = 12, BF_MASS = 15, BF_COM = 16, BF_ICOM = 19 };
+
+// task link modes -- same numbering as reference include/dwbc_task.h:23-33
+enum TaskMode {
+    TASK_LINK_6D = 0, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME,
+    TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME, TASK_LINK_POSITION_CUSTOM_FRAME,
+    TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME
+};
+
+// Problem setup shared by every instance of a batch (kernel argument, read through scalar loads).
+struct Setup {
+    int nb, ndof, maxdepth;
+    int n_contacts;
+    int c_link[kMaxContacts];
+    double c_point[kMaxContacts][3];
+    double c_lx[kMaxContacts], c_ly[kMaxContacts], c_mu[kMaxContacts], c_muz[kMaxContacts];
+    int n_levels;
+    int t_nlinks[kMaxLevels];
+    int t_mode[kMaxLevels][kMaxTaskLinks];
+    int t_link[kMaxLevels][kMaxTaskLinks];
+    double t_point[kMaxLevels][kMaxTaskLinks][3];
+    int t_dof[kMaxLevels];
+    int fstar_off[kMaxLevels];
+    int fstar_total;
+    int has_tau_lim;
+    double tau_lim[48];
+    int qp_max_iter_task;   // 1000, reference src/dwbc.cpp:1080
+    int qp_max_iter_contact; // 300,  reference src/dwbc.cpp:1546
+};
+
+// per-instance diagnostics (int32)
+enum DiagField {
+    DG_ST_CONTACT = 0, DG_ST_TASK, DG_ST_REDIS, DG_FAIL_LEVEL,
+    DG_QP_ITER = 4,  // [kMaxLevels+1]
+    DG_QP_NACT = 9,  // [kMaxLevels+1]
+    DG_QP_ACT = 14,  // [kMaxLevels+1][12]
+    DG_COUNT = 14 + 5 * 12
+};
+
+// dump layout (doubles per instance) for the debug / facade getters; N = ndof, M = N-6, C = 12
+struct DumpLayout {
+    int N, M;
+    int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, total;
+    __host__ __device__ static DumpLayout make(int n) {
+        DumpLayout d;
+        d.N = n;
+        d.M = n - 6;
+        int o = 0;
+        const int C = 6 * kMaxActiveContacts, K = C - 6, T = kMaxTaskDof, L = kMaxLevels;
+        d.A = o; o += n * n;
+        d.A_inv = o; o += n * n;
+        d.J_C = o; o += C * n;
+        d.Lambda_c = o; o += C * C;
+        d.J_C_INV_T = o; o += C * n;
+        d.A_inv_N_C = o; o += n * n;
+        d.W_inv = o; o += d.M * d.M;
+        d.NwJw = o; o += d.M * K;
+        d.Vb = o; o += d.M * K;
+        d.G = o; o += n;
+        d.P_C = o; o += C;
+        d.link_R = o; o += kMaxBodies * 9;
+        d.link_p = o; o += kMaxBodies * 3;
+        d.J_task = o; o += L * T * n;
+        d.Lambda_task = o; o += L * T * T;
+        d.J_kt = o; o += L * d.M * T;
+        d.X = o; o += L * d.M * T;
+        d.Y = o; o += L * T * d.M;
+        d.fstar_qp = o; o += L * T;
+        d.contact_qp = o; o += L * K;
+        d.cf_redis = o; o += K;
+        d.qp_viol = o; o += L + 1;
+        d.total = o;
+        return d;
+    }
+};
+
+struct BatchIO {
+    int B;
+    const double *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
+    const unsigned char *flags;  // B x n_contacts
+    const double *fstar;         // B x fstar_total
+    double *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
+    double *wrench;              // B x 12    : getContactForce(tau_total), zero padded
+    int *status;                 // B         : 1 ok / 0 fail (reference int returns ANDed)
+    int *diag;                   // B x DG_COUNT
+    double *dump;                // B x DumpLayout::total or nullptr
+    const double *body;          // nb x kBodyStride
+    const int *topo;             // parent[nb], depth[nb], subtree[nb]
+};
+
+}  // namespace dwbc

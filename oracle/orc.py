@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("OMP_STACKSIZE", "32M")  # orc_cycle keeps ~0.5 MB of matrices on the stack
 MAXB, MAXN, MAXM, MAXCON, MAXC, MAXL, MAXTL, MAXT, MAXV, MAXR = 48, 54, 48, 4, 24, 4, 2, 12, 30, 160
 
 d = C.c_double

@@ -1,0 +1,86 @@
+"""ctypes loader of the CPU emulation of the kernel source (tests/emu/emu_cycle.cpp).  TEST HARNESS ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        L = C.CDLL(os.path.join(_HERE, "libdwbc_emu.so"))
+        L.emu_create.restype = C.c_void_p
+        L.emu_create.argtypes = [C.c_char_p]
+        L.emu_error.restype = C.c_char_p
+        L.emu_error.argtypes = [C.c_void_p]
+        for f in ("emu_destroy", "emu_nb", "emu_ndof", "emu_fstar_total", "emu_dump_total"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.emu_link_id.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_get_model.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.emu_add_contact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.emu_add_task.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.emu_set_tau_lim.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_dump_offset.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        _lib = L
+    return _lib
+
+
+class Emu:
+    def __init__(self, urdf, contacts, tasks, tau_lim=None):
+        L = lib()
+        self.L = L
+        self.h = L.emu_create(urdf.encode())
+        err = L.emu_error(self.h).decode()
+        if err:
+            raise RuntimeError(err)
+        self.n = L.emu_ndof(self.h)
+        self.nb = L.emu_nb(self.h)
+        self.m = self.n - 6
+        for c in contacts:
+            pt = np.asarray(c["point"], dtype=np.float64)
+            assert L.emu_add_contact(self.h, c["link"], pt.ctypes.data, c["lx"], c["ly"], c.get("mu", 0.2), c.get("muz", 0.2)) >= 0
+        for lv, links in enumerate(tasks):
+            for mode, link, pt in links:
+                p = np.asarray(pt, dtype=np.float64)
+                assert L.emu_add_task(self.h, lv, mode, link, p.ctypes.data) == 1, L.emu_error(self.h)
+        if tau_lim is not None:
+            t = np.asarray(tau_lim, dtype=np.float64)
+            L.emu_set_tau_lim(self.h, t.ctypes.data)
+        self.ncon = len(contacts)
+        self.F = L.emu_fstar_total(self.h)
+        self.D = L.emu_dump_total(self.h)
+
+    def model_arrays(self):
+        nb = self.nb
+        out = dict(parent=np.zeros(nb, np.int32), R_T=np.zeros((nb, 3, 3)), p_T=np.zeros((nb, 3)), axis=np.zeros((nb, 3)),
+                   mass=np.zeros(nb), com=np.zeros((nb, 3)), inertia=np.zeros((nb, 3, 3)))
+        self.L.emu_get_model(self.h, *[out[k].ctypes.data for k in ("parent", "R_T", "p_T", "axis", "mass", "com", "inertia")])
+        return out
+
+    def run(self, q, flags, fstar, dump=False):
+        B = q.shape[0]
+        q = np.ascontiguousarray(q, np.float64)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        assert flags.shape == (B, self.ncon) and fstar.shape == (B, self.F)
+        tau = np.zeros((B, 3, self.m))
+        wr = np.zeros((B, 12))
+        st = np.zeros(B, np.int32)
+        diag = np.zeros((B, 74), np.int32)
+        dmp = np.zeros((B, self.D)) if dump else None
+        ok = self.L.emu_run(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
+                            st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)
+        assert ok == 1, self.L.emu_error(self.h)
+        return dict(tau=tau, wrench=wr, status=st, diag=diag, dump=dmp)
+
+    def dump_field(self, dmp, name, shape):
+        off = self.L.emu_dump_offset(self.h, name.encode())
+        assert off >= 0
+        n = int(np.prod(shape))
+        return dmp[:, off : off + n].reshape((dmp.shape[0],) + tuple(shape))

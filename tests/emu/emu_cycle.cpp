@@ -1,0 +1,95 @@
+// emu_cycle.cpp -- TEST HARNESS ONLY.  Compiles the kernel source libdwbc_amd/csrc/dwbc_cycle.h for the host with
+// one "thread" per workgroup (NT = 1, barriers are no-ops) so that the arithmetic and indexing of the fused
+// cycle can be checked against the oracle on a machine without a GPU (pytest -m "not gpu").  It shares the
+// product's URDF reader and Setup builder, which this also covers.  It is never linked into libdwbc_hip.so and
+// is not a fallback: the product has no CPU path.
+#define DWBC_HOST_EMU 1
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../libdwbc_amd/csrc/dwbc_cycle.h"
+#include "../../libdwbc_amd/csrc/dwbc_model.h"
+#include "../../libdwbc_amd/csrc/dwbc_setup.h"
+
+using namespace dwbc;
+
+struct EmuCtx {
+    Model model;
+    Setup su;
+    std::vector<double> body;
+    std::vector<int> topo;
+    std::string err;
+};
+
+extern "C" {
+
+EmuCtx *emu_create(const char *urdf) {
+    auto *c = new EmuCtx();
+    if (!load_urdf(urdf, true, c->model, c->err)) return c;
+    setup_init(c->su, c->model.nb, c->model.ndof, c->model.maxdepth);
+    c->model.body_table(c->body);
+    c->model.topo_table(c->topo);
+    return c;
+}
+const char *emu_error(EmuCtx *c) { return c->err.c_str(); }
+void emu_destroy(EmuCtx *c) { delete c; }
+int emu_nb(EmuCtx *c) { return c->model.nb; }
+int emu_ndof(EmuCtx *c) { return c->model.ndof; }
+int emu_link_id(EmuCtx *c, const char *name) { return c->model.link_id(name); }
+void emu_get_model(EmuCtx *c, int *parent, double *R_T, double *p_T, double *axis, double *mass, double *com, double *inertia) {
+    const Model &m = c->model;
+    for (int i = 0; i < m.nb; i++) parent[i] = m.parent[i];
+    memcpy(R_T, m.R_T.data(), 8 * 9 * m.nb);
+    memcpy(p_T, m.p_T.data(), 8 * 3 * m.nb);
+    memcpy(axis, m.axis.data(), 8 * 3 * m.nb);
+    memcpy(mass, m.mass.data(), 8 * m.nb);
+    memcpy(com, m.com.data(), 8 * 3 * m.nb);
+    memcpy(inertia, m.inertia.data(), 8 * 9 * m.nb);
+}
+int emu_add_contact(EmuCtx *c, int link, const double *pt, double lx, double ly, double mu, double muz) {
+    return setup_add_contact(c->su, link, 0, pt, lx, ly, mu, muz, c->err);
+}
+int emu_add_task(EmuCtx *c, int level, int mode, int link, const double *pt) { return setup_add_task(c->su, level, mode, link, pt, c->err) ? 1 : 0; }
+void emu_set_tau_lim(EmuCtx *c, const double *lim) {
+    c->su.has_tau_lim = lim != nullptr;
+    if (lim) for (int i = 0; i < c->model.ndof - 6; i++) c->su.tau_lim[i] = lim[i];
+}
+int emu_fstar_total(EmuCtx *c) { return c->su.fstar_total; }
+int emu_dump_total(EmuCtx *c) { return DumpLayout::make(c->model.ndof).total; }
+int emu_dump_offset(EmuCtx *c, const char *name) {
+    DumpLayout d = DumpLayout::make(c->model.ndof);
+    std::string n(name);
+#define F(x) if (n == #x) return d.x;
+    F(A) F(A_inv) F(J_C) F(Lambda_c) F(J_C_INV_T) F(A_inv_N_C) F(W_inv) F(NwJw) F(Vb) F(G) F(P_C) F(link_R) F(link_p)
+    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol)
+#undef F
+    return -1;
+}
+int emu_diag_count() { return DG_COUNT; }
+int emu_lds_bytes() { return Lds<39, 34>::total_bytes; }
+
+int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
+            int *status, int *diag, double *dump) {
+    if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
+    BatchIO io{};
+    io.B = B;
+    io.q = q;
+    io.flags = flags;
+    io.fstar = fstar;
+    io.tau = tau;
+    io.wrench = wrench;
+    io.status = status;
+    io.diag = diag;
+    io.dump = dump;
+    io.body = c->body.data();
+    io.topo = c->topo.data();
+    std::vector<double> lds(Lds<39, 34>::total + 64);
+    std::vector<int> ilds(64);
+    for (int b = 0; b < B; b++) {
+        Thr th{0};
+        cycle_instance<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
+    }
+    return 1;
+}
+}

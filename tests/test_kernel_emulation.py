@@ -1,0 +1,65 @@
+"""not-gpu: the kernel source (libdwbc_amd/csrc/dwbc_cycle.h) compiled for the host with one thread per workgroup
+(tests/emu) against the oracle.  This checks the arithmetic / indexing of the fused cycle, the closed-form null
+space of W, the Greville active set and the weighted least-norm polish without a GPU.  It is a test harness, not a
+product path."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests import cases
+from tests.emu.emu import Emu
+
+
+def _oracle(q, flags, fstar, contacts, tasks, tau_lim):
+    M = orc.make_model(cases.tocabi_model())
+    S = orc.make_setup(contacts, tasks, tau_lim)
+    return orc.cycle_batch(M, S, q, flags, fstar, 0)
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_emulated_kernel_on_golden_cases(case):
+    e = Emu(cases.URDF, cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    q = np.array([cases.Q_CASE[case]], dtype=float)
+    fl = np.array([[1, 1, 0, 0]], dtype=np.uint8)
+    fs = np.array([list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])])
+    r = e.run(q, fl, fs, dump=True)
+    g = lambda n: cases.golden(case, n)
+    er = lambda a, b: float(np.abs(a - b).max())
+    d = r["dump"]
+    assert r["status"][0] == 1
+    assert er(e.dump_field(d, "A", (39, 39))[0], g("Acontact_mat")) < 1e-10
+    assert er(e.dump_field(d, "A_inv", (39, 39))[0], g("A_inv_")) < 1e-9
+    assert er(e.dump_field(d, "J_C", (12, 39))[0], g("J_C")) < 1e-12
+    assert er(e.dump_field(d, "W_inv", (33, 33))[0], g("W_inv")) < 1e-8
+    assert er(e.dump_field(d, "NwJw", (33, 6))[0], g("NwJw")) < 1e-9
+    assert er(r["tau"][0, 0], g("torque_grav_")[:, 0]) < 1e-8
+    assert er(r["tau"][0, 1], g("torque_task_")[:, 0]) < 1e-6
+    assert er(r["tau"][0, 2], g("torque_contact_")[:, 0]) < (1e-8 if case == 1 else 1e-3)
+
+
+@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit"])
+def test_emulated_kernel_vs_oracle_batches(cfg):
+    B = 48
+    contacts, tasks, lim = cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM
+    kw = dict(seed=1234)
+    if cfg == "ds_yaw":
+        kw["yaw"] = True
+    elif cfg == "ss_L":
+        kw.update(contact_mode="L", levels=3)
+        tasks = cases.TASKS_3LEVEL_SWING_R
+    elif cfg == "ss_R":
+        kw.update(contact_mode="R", levels=3)
+        tasks = cases.TASKS_3LEVEL_SWING_L
+    elif cfg == "mixed":
+        kw["contact_mode"] = "mixed"
+    elif cfg == "nolimit":
+        lim = None
+    q, fl, fs = cases.synth_batch(B, **kw)
+    e = Emu(cases.URDF, contacts, tasks, lim)
+    r = e.run(q, fl, fs)
+    tau_r, wr_r, st_r, _ = _oracle(q, fl, fs, contacts, tasks, lim)
+    assert (r["status"] == st_r).all()
+    ok = st_r == 1
+    assert ok.mean() > 0.5
+    assert np.abs(r["tau"][ok] - tau_r[ok]).max() < 1e-6
+    assert np.abs(r["wrench"][ok] - wr_r[ok][:, :12]).max() < 1e-5
