@@ -45,7 +45,7 @@ enum dwbc_field {
     DWBC_TAU = 10,        /* (3, m) f64: torque_grav_, torque_task_, torque_contact_  (include/dwbc.h:115-117) */
     DWBC_WRENCH = 11,     /* (12)   f64: getContactForce(tau_total), zero padded       (src/dwbc.cpp:891-896) */
     DWBC_STATUS = 12,     /* (1)    i32: 1 ok / 0 failed                               */
-    DWBC_DIAG = 13,       /* (74)   i32: stage status, QP iterations, working sets     */
+    DWBC_DIAG = 13,       /* (90)   i32: stage status, QP iterations, working sets, stage stamps */
     /* derived getters (host only) */
     DWBC_TAU_GRAV = 20, DWBC_TAU_TASK = 21, DWBC_TAU_CONTACT = 22, DWBC_TAU_TOTAL = 23,
     /* intermediates, available after a solve with dwbc_batch_enable_dump(b, 1) -- the RobotData public fields */

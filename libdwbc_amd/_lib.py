@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdwbc_hip.so")
+# DWBC_TIMED=1 selects the diagnostic build with in-kernel stage stamps (never used for reported numbers)
+LIB_PATH = os.path.join(_HERE, "libdwbc_hip_timed.so" if os.environ.get("DWBC_TIMED") == "1" else "libdwbc_hip.so")
 
 # every symbol include/dwbc_batch.h declares: (name, restype, argtypes)
 _vp, _i, _d, _cp = C.c_void_p, C.c_int, C.c_double, C.c_char_p

@@ -190,7 +190,7 @@ class Batch:
         return t.value, l.value
 
     _SHAPES = dict(
-        tau=lambda s: (3, s.m), wrench=lambda s: (12,), status=lambda s: (), diag=lambda s: (74,),
+        tau=lambda s: (3, s.m), wrench=lambda s: (12,), status=lambda s: (), diag=lambda s: (90,),
         tau_grav=lambda s: (s.m,), tau_task=lambda s: (s.m,), tau_contact=lambda s: (s.m,), tau_total=lambda s: (s.m,),
         A=lambda s: (s.n, s.n), A_inv=lambda s: (s.n, s.n), A_inv_N_C=lambda s: (s.n, s.n), J_C=lambda s: (12, s.n),
         J_C_INV_T=lambda s: (12, s.n), Lambda_c=lambda s: (144,), W_inv=lambda s: (s.m, s.m), NwJw=lambda s: (s.m, 6),

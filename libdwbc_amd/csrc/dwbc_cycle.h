@@ -25,6 +25,19 @@
 
 #include "dwbc_types.h"
 
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+// diagnostic build only (libdwbc_hip_timed.so): stage stamps in shader cycles, written to diag[DG_TIME..]
+#define DWBC_STAMP(i)                                                                   \
+    do {                                                                                \
+        DWBC_SYNC();                                                                    \
+        if (diag && th.tid == 0) diag[DG_TIME + (i)] = (int)(clock64() - t_start_);     \
+    } while (0)
+#define DWBC_STAMP_INIT() const long long t_start_ = clock64()
+#else
+#define DWBC_STAMP(i) ((void)0)
+#define DWBC_STAMP_INIT() ((void)0)
+#endif
+
 #ifdef DWBC_HOST_EMU
 #define DWBC_DEV
 #define DWBC_SYNC() ((void)0)
@@ -602,6 +615,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     double *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
 
+    DWBC_STAMP_INIT();
     // ================= stage 0: kinematics, A, A_inv, G  (src/dwbc.cpp:279-371) =================
     for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
     for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = 0.0;
@@ -746,6 +760,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
         }
     }
+    DWBC_STAMP(0);  // kinematics + CRBA done
     int st_contact = 1;
     // A_inv = llt(A).solve(I)  (dwbc.cpp:307): bufA (A) -> bufA (A_inv), bufN scratch
     {
@@ -761,6 +776,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         }
     }
 
+    DWBC_STAMP(1);  // A_inv done
     // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
     const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
     int act_c[kMaxActiveContacts];
@@ -808,6 +824,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < cd * cd; idx += NT) dump[dl.Lambda_c + idx] = Lam[idx];
             for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A_inv_N_C + idx] = AiNc[idx];
         }
+        DWBC_STAMP(2);  // J_C, Lambda_c, J̄, A^-1 N_c done
         // ---- W^+ and NwJw.  null(W) is known in closed form: W = S A^-1 N_c S^T vanishes exactly on
         //      { J_C[:,6:]^T lam : J_C[:,:6]^T lam = 0 } (internal wrenches), so V2's span needs no pivoted QR.
         double *Winv = L + S::bufA;  // A_inv is dead from here on
@@ -853,6 +870,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             mm_nt<NT>(th, P, M, W1, k, Vb, k, M, k, M);
             DWBC_SYNC();
         }
+        DWBC_STAMP(3);  // NwJw + projector done
         // alpha = trace(W)/M ;  W + alpha P is SPD ;  W^+ = (W + alpha P)^-1 - P/alpha
         double alpha = 0.0;
         for (int i = 0; i < M; i++) alpha += AiNc[(6 + i) * N + 6 + i];
@@ -883,6 +901,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < M * M; idx += NT) dump[dl.W_inv + idx] = Winv[idx];
             for (int idx = th.tid; idx < M * k; idx += NT) { dump[dl.NwJw + idx] = L[S::NwJw + idx]; }
         }
+        DWBC_STAMP(4);  // W^+ done
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
         if (k > 0) {
             DWBC_SYNC();
@@ -912,6 +931,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int i = th.tid; i < cd; i += NT) dump[dl.P_C + i] = L[S::PC + i];
     }
 
+    DWBC_STAMP(5);  // gravity compensation done
     // ================= stage 3: task cascade (dwbc.cpp:685-873, 941-1127; wbd.cpp:207-261) =================
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
@@ -1004,6 +1024,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 }
             }
             DWBC_SYNC();
+            DWBC_STAMP(6 + 3 * lv);  // level lv: J_kt, Lambda, null-space chain done
             // --- QP rows (dwbc.cpp:988-1053)
             const double *fs = fs_in + su.fstar_off[lv];
             double *base = L + S::t_base, *Gm = L + S::qp_G, *ub = L + S::qp_ub, *F = L + S::t_F, *fv = L + S::t_fv;
@@ -1050,6 +1071,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 if (j < nv) Gm[(nlim + rr_) * kQpLd + j] = -v; else ub[nlim + rr_] = v;
             }
             DWBC_SYNC();
+            DWBC_STAMP(7 + 3 * lv);  // level lv: QP rows assembled
             int iters = 0, nact = 0;
             double viol = 0.0;
             int ok = qp_solve<N, NB, NT>(th, L, iL, nlim + ncone, nv, t, su.qp_max_iter_task, &iters, &nact, &viol);
@@ -1059,6 +1081,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = a < nact ? iL[a] : -1;
             }
             if (dump && th.tid == 0) dump[dl.qp_viol + lv] = viol;
+            DWBC_STAMP(8 + 3 * lv);  // level lv: QP solved
             if (!ok) { st_task = 0; fail_level = lv; break; }  // f_star_qp_, contact_qp_ zero; cascade aborts (dwbc.cpp:836,1119)
             const double *x = L + S::qp_x;
             // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp) ; torque_contact_ = NwJw contact_qp_ (dwbc.cpp:839-851)
@@ -1078,6 +1101,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         }
     }
 
+    DWBC_STAMP(14);  // (levels 0..2 use stamps 6..14)
     // ================= stage 4: contact redistribution (dwbc.cpp:1372-1568) =================
     int st_redis = 1;
     if (k > 0) {
@@ -1143,6 +1167,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     }
     DWBC_SYNC();
 
+    DWBC_STAMP(15);  // contact redistribution done
     // ================= outputs =================
     double *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];

@@ -54,7 +54,8 @@ enum DiagField {
     DG_QP_ITER = 4,  // [kMaxLevels+1]
     DG_QP_NACT = 9,  // [kMaxLevels+1]
     DG_QP_ACT = 14,  // [kMaxLevels+1][12]
-    DG_COUNT = 14 + 5 * 12
+    DG_TIME = 14 + 5 * 12,  // [16] stage stamps (shader cycles since kernel start), only in the DWBC_STAGE_TIMERS build
+    DG_COUNT = 14 + 5 * 12 + 16
 };
 
 // dump layout (doubles per instance) for the debug / facade getters; N = ndof, M = N-6, C = 12

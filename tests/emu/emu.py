@@ -72,7 +72,7 @@ class Emu:
         tau = np.zeros((B, 3, self.m))
         wr = np.zeros((B, 12))
         st = np.zeros(B, np.int32)
-        diag = np.zeros((B, 74), np.int32)
+        diag = np.zeros((B, 90), np.int32)
         dmp = np.zeros((B, self.D)) if dump else None
         ok = self.L.emu_run(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
                             st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)

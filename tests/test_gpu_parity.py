@@ -98,9 +98,11 @@ def test_double_support_batch_vs_oracle(yaw):
     wbc = _make(B)
     tau, wr, st = _run(wbc, q, flags, fstar)
     tau_r, wr_r, st_r, _ = _oracle(B, q, flags, fstar)
-    assert (st == st_r).all() and st.all()
-    assert np.abs(tau - tau_r).max() < TOL
-    assert np.abs(wr - wr_r).max() < 1e-5  # wrench ~ 1e3 N: 1e-8 relative
+    assert (st == st_r).all()
+    ok = st_r == 1
+    assert ok.mean() > 0.9 and (ok.all() or yaw)  # tilted bases (roll/pitch +-0.1) make a few cone QPs infeasible
+    assert np.abs(tau[ok] - tau_r[ok]).max() < TOL
+    assert np.abs(wr[ok] - wr_r[ok]).max() < 1e-5  # wrench ~ 1e3 N: 1e-8 relative
     # the QPs really bite on this distribution: at least one active constraint somewhere
     assert wbc.get("diag")[:, 9:12].sum() > 0
 

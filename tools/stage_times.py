@@ -1,0 +1,36 @@
+"""Diagnostic: per-stage shader-cycle breakdown from the DWBC_STAGE_TIMERS build (run with DWBC_TIMED=1)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import libdwbc_amd as D  # noqa: E402
+from tests import cases  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+model = D.Model.from_urdf(cases.URDF)
+wbc = D.Batch(model, B)
+for c in cases.CONTACTS_2:
+    wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"])
+wbc.add_task(0, D.TASK_LINK_6D, 0)
+wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+wbc.set_torque_limit(np.array(cases.TAU_LIM))
+q, fl, fs = cases.synth_batch(B, seed=20251226 + 2)
+wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
+for _ in range(3):
+    wbc.solve()
+wbc.sync()
+d = wbc.get("diag")
+t = d[:, 74:90].astype(np.float64)
+names = ["kin+CRBA", "A_inv", "JC/Lam/Jbar/AiNc", "NwJw+proj", "W_inv", "grav", "L0 jkt", "L0 qp rows", "L0 qp solve",
+         "L1 jkt", "L1 qp rows", "L1 qp solve", "L2 jkt", "L2 rows", "(to redis)", "redis qp"]
+med = np.median(t, axis=0)
+prev = 0.0
+print("stage                      median cycles   cumulative")
+for i, n in enumerate(names):
+    if med[i] <= 0:
+        continue
+    print(f"{n:26s} {med[i]-prev:12.0f} {med[i]:12.0f}")
+    prev = med[i]
+print("qp iters median", np.median(d[:, 4:9], axis=0), "nact", np.median(d[:, 9:14], axis=0))
