@@ -52,6 +52,7 @@ constexpr double kGrav = 9.81;
 constexpr double kQpScaleGI = 1.0e4;      // c = s * c_hat while the active set is searched
 constexpr double kQpScalePolish = 1.0e9;  // weight of the final (row-sorted, column-pivoted) least-norm solve
 constexpr double kQpTol = 1.0e-9;
+constexpr double kQpFeasTol = 1.0e-7;     // acceptance of the lexicographic point (slack / |row|)
 constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
 
 
@@ -374,6 +375,88 @@ DWBC_DEV void qp_greville_commit(Thr th, double *L, const double *np, int q, int
     DWBC_SYNC();
 }
 
+// least-norm point of the working set's equalities: min |x~| s.t. N^T x~ = b, N = working-set normals with the
+// contact block first and multiplied by wsc, solved by a column-pivoted Householder QR (row-sorted weighting is
+// what makes the 1e9 weight stable).  Writes the unscaled x to L[qp_x].
+template <int N, int NB, int NT>
+DWBC_DEV void qp_least_norm(Thr th, double *L, int *iL, int q, int nv, int t, double wsc, double cscale) {
+    using S = Lds<N, NB>;
+    double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *x = L + S::qp_x, *Nm = L + S::qp_Nm, *V = L + S::qp_V, *bb = L + S::qp_b;
+    double *ww = L + S::qp_w, *beta = L + S::qp_beta;
+    int *act = iL;
+    const int k = nv - t;
+    DWBC_SYNC();
+    if (q > 0) {
+        // Nm[i][a]: i < k -> contact variable i (weighted), i >= k -> task variable i-k
+        for (int idx = th.tid; idx < nv * q; idx += NT) {
+            int i = idx / q, a = idx - i * q;
+            const int ra = act[a];
+            double v = (i < k) ? Gm[ra * kQpLd + t + i] * wsc : Gm[ra * kQpLd + (i - k)];
+            Nm[i * kQpLd + a] = v;
+        }
+        for (int a = th.tid; a < q; a += NT) bb[a] = ub[act[a]];
+        for (int s = 0; s < q; s++) {
+            DWBC_SYNC();
+            // column pivot: largest remaining norm
+            int jp = s;
+            double bn = -1.0;
+            for (int a = s; a < q; a++) {
+                double c2 = 0.0;
+                for (int i = s; i < nv; i++) c2 += Nm[i * kQpLd + a] * Nm[i * kQpLd + a];
+                if (c2 > bn) { bn = c2; jp = a; }
+            }
+            DWBC_SYNC();
+            if (jp != s) {
+                for (int i = th.tid; i < nv; i += NT) { double tv = Nm[i * kQpLd + s]; Nm[i * kQpLd + s] = Nm[i * kQpLd + jp]; Nm[i * kQpLd + jp] = tv; }
+                if (th.tid == 0) { double tb = bb[s]; bb[s] = bb[jp]; bb[jp] = tb; }
+            }
+            DWBC_SYNC();
+            double nrm = 0.0;
+            for (int i = s; i < nv; i++) nrm += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
+            nrm = sqrt(nrm);
+            const double a0 = Nm[s * kQpLd + s];
+            const double alpha = a0 > 0 ? -nrm : nrm;
+            double vn2 = (a0 - alpha) * (a0 - alpha);
+            for (int i = s + 1; i < nv; i++) vn2 += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
+            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
+            DWBC_SYNC();
+            for (int i = th.tid; i < nv; i += NT) V[s * kQpLd + i] = i < s ? 0.0 : (i == s ? a0 - alpha : Nm[i * kQpLd + s]);
+            if (th.tid == 0) beta[s] = bt;
+            DWBC_SYNC();
+            for (int a = s + 1 + th.tid; a < q; a += NT) {
+                double d = 0.0;
+                for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * Nm[i * kQpLd + a];
+                d *= bt;
+                for (int i = s; i < nv; i++) Nm[i * kQpLd + a] -= d * V[s * kQpLd + i];
+            }
+            for (int i = s + th.tid; i < nv; i += NT) Nm[i * kQpLd + s] = (i == s) ? alpha : 0.0;
+        }
+        // y = R^-T b  (R = Nm[:q,:q] upper)
+        for (int c = 0; c < q; c++) {
+            DWBC_SYNC();
+            const double yc = bb[c] / Nm[c * kQpLd + c];
+            DWBC_SYNC();
+            if (th.tid == 0) bb[c] = yc;
+            for (int a = c + 1 + th.tid; a < q; a += NT) bb[a] -= Nm[c * kQpLd + a] * yc;
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < nv; i += NT) ww[i] = i < q ? bb[i] : 0.0;
+        for (int s = q - 1; s >= 0; s--) {
+            DWBC_SYNC();
+            double d = 0.0;
+            for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * ww[i];
+            d *= beta[s];
+            DWBC_SYNC();
+            for (int i = s + th.tid; i < nv; i += NT) ww[i] -= d * V[s * kQpLd + i];
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < nv; i += NT) x[i] = (i < t) ? ww[k + i] : ww[i - t] * cscale;
+    } else {
+        for (int i = th.tid; i < nv; i += NT) x[i] = 0.0;
+    }
+    DWBC_SYNC();
+}
+
 template <int N, int NB, int NT>
 DWBC_DEV int qp_solve(Thr th, double *L, int *iL, int rows, int nv, int t, int max_iter, int *iters_out, int *nact_out,
                       double *viol_out) {
@@ -470,88 +553,32 @@ DWBC_DEV int qp_solve(Thr th, double *L, int *iL, int rows, int nv, int t, int m
         DWBC_SYNC();
         return 0;
     }
-    // ---- final least-norm solve on the working set: rows of N are variables, c-block first and weighted ----
+    // ---- final point, recomputed from the working set alone (DESIGN.md "QP canon") ----
+    //  lexicographic least-norm point (contact block weighted 1e9) if it is feasible, else the Tikhonov point
     const bool lex = (k > 0 && t > 0);
-    const double wsc = lex ? kQpScalePolish / kQpScaleGI : 1.0;
-    if (q > 0) {
-        // Nm[i][a]: i < k -> contact variable i (weighted), i >= k -> task variable i-k
-        for (int idx = th.tid; idx < nv * q; idx += NT) {
-            int i = idx / q, a = idx - i * q;
-            const int ra = act[a];
-            double v = (i < k) ? Gm[ra * kQpLd + t + i] * wsc : Gm[ra * kQpLd + (i - k)];
-            Nm[i * kQpLd + a] = v;
-        }
-        for (int a = th.tid; a < q; a += NT) { bb[a] = ub[act[a]]; perm[a] = a; }
-        for (int s = 0; s < q; s++) {
-            DWBC_SYNC();
-            // column pivot: largest remaining norm
-            int jp = s;
-            double bn = -1.0;
-            for (int a = s; a < q; a++) {
-                double c2 = 0.0;
-                for (int i = s; i < nv; i++) c2 += Nm[i * kQpLd + a] * Nm[i * kQpLd + a];
-                if (c2 > bn) { bn = c2; jp = a; }
+    double wv = 0.0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool weighted = lex && attempt == 0;
+        qp_least_norm<N, NB, NT>(th, L, iL, q, nv, t, weighted ? kQpScalePolish / kQpScaleGI : 1.0,
+                                 weighted ? kQpScalePolish : kQpScaleGI);
+        // worst slack of the returned point, normalised by the unscaled row norm
+        wv = 1e300;
+        int wi = 0;
+        for (int r = th.tid; r < rows; r += NT) {
+            double sl = ub[r], nr = 0.0;
+            for (int j = 0; j < nv; j++) {
+                const double a = j < t ? Gm[r * kQpLd + j] : Gm[r * kQpLd + j] * (1.0 / kQpScaleGI);
+                sl -= a * x[j];
+                nr += a * a;
             }
-            DWBC_SYNC();
-            if (jp != s) {
-                for (int i = th.tid; i < nv; i += NT) { double tv = Nm[i * kQpLd + s]; Nm[i * kQpLd + s] = Nm[i * kQpLd + jp]; Nm[i * kQpLd + jp] = tv; }
-                if (th.tid == 0) { double tb = bb[s]; bb[s] = bb[jp]; bb[jp] = tb; }
-            }
-            DWBC_SYNC();
-            double nrm = 0.0;
-            for (int i = s; i < nv; i++) nrm += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
-            nrm = sqrt(nrm);
-            const double a0 = Nm[s * kQpLd + s];
-            const double alpha = a0 > 0 ? -nrm : nrm;
-            double vn2 = (a0 - alpha) * (a0 - alpha);
-            for (int i = s + 1; i < nv; i++) vn2 += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
-            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
-            DWBC_SYNC();
-            for (int i = th.tid; i < nv; i += NT) V[s * kQpLd + i] = i < s ? 0.0 : (i == s ? a0 - alpha : Nm[i * kQpLd + s]);
-            if (th.tid == 0) beta[s] = bt;
-            DWBC_SYNC();
-            for (int a = s + 1 + th.tid; a < q; a += NT) {
-                double d = 0.0;
-                for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * Nm[i * kQpLd + a];
-                d *= bt;
-                for (int i = s; i < nv; i++) Nm[i * kQpLd + a] -= d * V[s * kQpLd + i];
-            }
-            for (int i = s + th.tid; i < nv; i += NT) Nm[i * kQpLd + s] = (i == s) ? alpha : 0.0;
+            nr = sqrt(nr);
+            sl /= (nr < 1e-300 ? 1e-300 : nr);
+            if (sl < wv) { wv = sl; wi = r; }
         }
-        // y = R^-T b  (R = Nm[:q,:q] upper)
-        for (int c = 0; c < q; c++) {
-            DWBC_SYNC();
-            const double yc = bb[c] / Nm[c * kQpLd + c];
-            DWBC_SYNC();
-            if (th.tid == 0) bb[c] = yc;
-            for (int a = c + 1 + th.tid; a < q; a += NT) bb[a] -= Nm[c * kQpLd + a] * yc;
-        }
+        block_argmin<NT>(th, wv, wi, red);
         DWBC_SYNC();
-        for (int i = th.tid; i < nv; i += NT) ww[i] = i < q ? bb[i] : 0.0;
-        for (int s = q - 1; s >= 0; s--) {
-            DWBC_SYNC();
-            double d = 0.0;
-            for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * ww[i];
-            d *= beta[s];
-            DWBC_SYNC();
-            for (int i = s + th.tid; i < nv; i += NT) ww[i] -= d * V[s * kQpLd + i];
-        }
-        DWBC_SYNC();
-        for (int i = th.tid; i < nv; i += NT) x[i] = (i < t) ? ww[k + i] : ww[i - t] * (lex ? kQpScalePolish : kQpScaleGI);
-    } else {
-        for (int i = th.tid; i < nv; i += NT) x[i] = 0.0;
+        if (!weighted || !(wv < -kQpFeasTol)) break;
     }
-    DWBC_SYNC();
-    // worst normalised violation of the returned point (diagnostic; rows are in GI scaling)
-    double wv = 1e300;
-    int wi = 0;
-    for (int r = th.tid; r < rows; r += NT) {
-        double s = ub[r];
-        for (int j = 0; j < nv; j++) s -= Gm[r * kQpLd + j] * (j < t ? x[j] : x[j] / kQpScaleGI);
-        s /= gn[r];
-        if (s < wv) { wv = s; wi = r; }
-    }
-    block_argmin<NT>(th, wv, wi, red);
     *viol_out = wv;
     DWBC_SYNC();
     return 1;

@@ -328,8 +328,19 @@ def _lex_eqp(Ad, Ac, b):
     return d, c
 
 
+QP_FEAS_TOL = 1.0e-7  # acceptance of the lexicographic point: slack / |row| >= -QP_FEAS_TOL on every row
+
+
+def _worst_slack(A, ub, x):
+    nrm = np.maximum(np.linalg.norm(A, axis=1), 1e-300)
+    return float(((ub - A @ x) / nrm).min()) if A.shape[0] else 0.0
+
+
 def solve_qp(A, ub, t, max_iter=1000):
-    """x = [d (t); c (k)].  Returns (status, x, active_rows)."""
+    """x = [d (t); c (k)].  Returns (status, x, active_rows).   (DESIGN.md "QP canon")
+      1. working set W := active set of  min 1/2|d|^2 + 1/2 eps |c|^2  (eps = QP_SCALE^-2), Goldfarb-Idnani;
+      2. x := lexicographic least-norm point on W (min |d| first, then min |c|) if it is feasible to QP_FEAS_TOL,
+      3. otherwise x := the Tikhonov point on W (near-singular contact blocks make the lexicographic point blow up)."""
     m, nv = A.shape
     k = nv - t
     G = A.copy()
@@ -338,16 +349,23 @@ def solve_qp(A, ub, t, max_iter=1000):
     if st == 0:
         return 0, np.zeros(nv), []
     act_sorted = list(act)
+
+    def tikhonov_point():
+        if not act_sorted:
+            return np.zeros(nv)
+        N = G[act_sorted]
+        xs = N.T @ np.linalg.solve(N @ N.T, ub[act_sorted])
+        xs = xs.copy()
+        xs[t:] *= QP_SCALE
+        return xs
+
     if k > 0 and t > 0:
         d, c = _lex_eqp(A[act_sorted, :t], A[act_sorted, t:], ub[act_sorted])
         x = np.concatenate([d, c])
+        if _worst_slack(A, ub, x) < -QP_FEAS_TOL:
+            x = tikhonov_point()
     else:
-        # strictly convex: re-solve the EQP on the final working set to shed drift
-        if act_sorted:
-            N = G[act_sorted]
-            xh = N.T @ np.linalg.solve(N @ N.T, ub[act_sorted])
-        x = xh.copy()
-        x[t:] *= QP_SCALE
+        x = tikhonov_point()  # strictly convex: re-solve on the final working set to shed drift
     return 1, x, sorted(act_sorted)
 
 

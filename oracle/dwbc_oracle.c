@@ -21,6 +21,7 @@
 #define GRAV 9.81
 #define QP_SCALE 1.0e4
 #define QP_TOL 1.0e-9
+#define QP_FEAS_TOL 1.0e-7
 
 int orc_sizeof_model(void) { return (int)sizeof(orc_model); }
 int orc_sizeof_setup(void) { return (int)sizeof(orc_setup); }
@@ -436,7 +437,10 @@ int orc_solve_qp(const double *A, const double *ub, int rows, int nv, int t, int
         for (int j = 0; j < nv; j++) x[j] = 0.0;
         return 0;
     }
-    if (k > 0 && t > 0) {
+    /* DESIGN.md "QP canon": lexicographic least-norm point on the working set if it is feasible, else the
+     * Tikhonov point on the working set (near-singular contact blocks make the lexicographic point blow up). */
+    int use_tikhonov = !(k > 0 && t > 0);
+    if (!use_tikhonov) {
         double Ad[ORC_MAXV * ORC_MAXV], Ac[ORC_MAXV * ORC_MAXV], b[ORC_MAXV];
         for (int a = 0; a < q; a++) {
             for (int j = 0; j < t; j++) Ad[a * t + j] = A[act[a] * nv + j];
@@ -444,21 +448,31 @@ int orc_solve_qp(const double *A, const double *ub, int rows, int nv, int t, int
             b[a] = ub[act[a]];
         }
         lex_eqp(Ad, Ac, b, q, t, k, x, x + t);
-    } else {
-        if (q > 0) { /* re-solve the EQP on the final working set: x = N^T (N N^T)^-1 b */
-            double M[ORC_MAXV * ORC_MAXV], y[ORC_MAXV];
-            for (int a = 0; a < q; a++) {
-                for (int c = 0; c < q; c++) {
-                    double s = 0.0;
-                    for (int j = 0; j < nv; j++) s += G[act[a] * nv + j] * G[act[c] * nv + j];
-                    M[a * q + c] = s;
-                }
-                y[a] = ub[act[a]];
+        double worst = 0.0;
+        for (int i = 0; i < rows; i++) {
+            double sl = ub[i], nr = 0.0;
+            for (int j = 0; j < nv; j++) { sl -= A[i * nv + j] * x[j]; nr += A[i * nv + j] * A[i * nv + j]; }
+            nr = sqrt(nr);
+            if (nr < 1e-300) nr = 1e-300;
+            if (sl / nr < worst) worst = sl / nr;
+        }
+        if (worst < -QP_FEAS_TOL) use_tikhonov = 1;
+    }
+    if (use_tikhonov) {
+        if (q > 0) { /* least-norm point of N^T x = b on the final working set, by pivoted QR of N (nv x q) */
+            double Nq[ORC_MAXV * ORC_MAXV], Q[ORC_MAXV * ORC_MAXV], y[ORC_MAXV];
+            int piv[ORC_MAXV];
+            for (int i = 0; i < nv; i++)
+                for (int a = 0; a < q; a++) Nq[i * q + a] = G[act[a] * nv + i];
+            qrcp(Nq, nv, q, Q, piv, 1);
+            for (int a = 0; a < q; a++) { /* R^T y = b[piv] */
+                double s = ub[act[piv[a]]];
+                for (int c = 0; c < a; c++) s -= Nq[c * q + a] * y[c];
+                y[a] = s / Nq[a * q + a];
             }
-            spd_solve_small(M, q, y);
             for (int j = 0; j < nv; j++) {
                 double s = 0.0;
-                for (int a = 0; a < q; a++) s += G[act[a] * nv + j] * y[a];
+                for (int a = 0; a < q; a++) s += Q[j * nv + a] * y[a];
                 xh[j] = s;
             }
         }
