@@ -58,6 +58,14 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  libdwbc_amd has no CPU fallback."
             )
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  When
+        # torch is going to share device buffers / streams with this library it must be the first to load the
+        # runtime, otherwise torch.cuda fails with "No HIP GPUs are available".  torch is optional.
+        if os.environ.get("DWBC_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
