@@ -54,6 +54,9 @@ constexpr double kQpScalePolish = 1.0e9;  // weight of the final (row-sorted, co
 constexpr double kQpTol = 1.0e-9;
 constexpr double kQpFeasTol = 1.0e-7;     // acceptance of the lexicographic point (slack / |row|)
 constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
+}  // namespace dwbc
+#include "dwbc_qp_wave.h"
+namespace dwbc {
 
 
 // ----------------------------------------------------------------------------------------------
@@ -118,21 +121,9 @@ struct Lds {
     static constexpr int t_base = t_s3 + T * T;       // M
     static constexpr int t_F = t_base + M;            // C x kQpLd
     static constexpr int t_fv = t_F + C * kQpLd;      // C
-    static constexpr int qp_G = t_fv + C;             // rows x kQpLd
-    static constexpr int qp_ub = qp_G + QR * kQpLd;
-    static constexpr int qp_gn = qp_ub + QR;
-    static constexpr int qp_Nm = qp_gn + QR;  // kQpLd x kQpLd   active normals (columns)
-    static constexpr int qp_Np = qp_Nm + kQpLd * kQpLd;  // pseudo-inverse rows
-    static constexpr int qp_V = qp_Np + kQpLd * kQpLd;   // householder vectors
-    static constexpr int qp_x = qp_V + kQpLd * kQpLd;
-    static constexpr int qp_r = qp_x + kQpLd;
-    static constexpr int qp_z = qp_r + kQpLd;
-    static constexpr int qp_u = qp_z + kQpLd;
-    static constexpr int qp_b = qp_u + kQpLd;
-    static constexpr int qp_w = qp_b + kQpLd;
-    static constexpr int qp_beta = qp_w + kQpLd;
-    static constexpr int qp_red = qp_beta + kQpLd;    // cross-wave reduction scratch
-    static constexpr int t_end = qp_red + 16;
+    static constexpr int qp_V = t_fv + C;             // householder vectors of the final least-norm solve (12 x 12)
+    static constexpr int qp_x = qp_V + kQpLd * kQpLd; // QP solution (uniform copy for the torque updates)
+    static constexpr int t_end = qp_x + kQpLd;
     static constexpr int max2(int a, int b) { return a > b ? a : b; }
     static constexpr int total = max2(max2(k_end, c_end), t_end);
     static constexpr int total_bytes = total * 8 + 64 * 4 + 64;  // + int scratch
@@ -297,294 +288,6 @@ DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, con
 }
 
 // ----------------------------------------------------------------------------------------------
-// block-wide arg-min (value, index); every thread returns the same pair
-// ----------------------------------------------------------------------------------------------
-template <int NT>
-DWBC_DEV void block_argmin(Thr th, double &v, int &idx, double *red) {
-#ifdef DWBC_HOST_EMU
-    (void)th; (void)red;
-#else
-    for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(v, off, 64);
-        int oi = __shfl_xor(idx, off, 64);
-        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-    if (NT > 64) {
-        int *ired = reinterpret_cast<int *>(red + 8);
-        __syncthreads();
-        if ((th.tid & 63) == 0) { red[th.tid >> 6] = v; ired[th.tid >> 6] = idx; }
-        __syncthreads();
-        v = red[0]; idx = ired[0];
-        for (int w = 1; w < NT / 64; w++) {
-            double ov = red[w]; int oi = ired[w];
-            if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-        __syncthreads();
-    }
-#endif
-}
-
-// ----------------------------------------------------------------------------------------------
-// QP:  lexmin( 1/2|x[:t]|^2 , 1/2|x[t:]|^2 )  s.t.  A x <= ub     (H = diag(I_t, 0_k), g = 0)
-//
-// Replaces CQuadraticProgram::SolveQPoases (reference src/qp_wrapper.cpp:192-380).  Dual active set
-// (Goldfarb-Idnani) on the scaled least-distance form: starts at the unconstrained optimum x = 0, so a cycle
-// whose constraints are inactive costs one pass over the rows and no factorisation.  The projector onto the
-// active normals is kept as an explicit pseudo-inverse (Greville update on add, rebuild on drop) -- only
-// mat-vecs, no triangular solves on the critical path.  The final point is recomputed from the working set
-// alone by a row-sorted, column-pivoted Householder least-norm solve with the contact block weighted 1e9,
-// which is the lexicographic (min |f*_qp| first, then min |c|) optimum to ~1e-13 (DESIGN.md "QP canon").
-//   Gm  : rows x kQpLd, contact columns already multiplied by kQpScaleGI
-//   out : x (nv) in L[qp_x] unscaled;  returns 1 ok / 0 fail (infeasible or iteration cap)
-// ----------------------------------------------------------------------------------------------
-template <int N, int NB, int NT>
-DWBC_DEV void qp_greville_add(Thr th, double *L, const double *np, int q, int nv) {
-    using S = Lds<N, NB>;
-    double *Nm = L + S::qp_Nm, *Np = L + S::qp_Np, *rr = L + S::qp_r, *zz = L + S::qp_z;
-    // r = N^+ n ; z = n - N r
-    DWBC_SYNC();
-    for (int a = th.tid; a < q; a += NT) {
-        double s = 0.0;
-        for (int i = 0; i < nv; i++) s -= Np[a * kQpLd + i] * np[i];
-        rr[a] = s;
-    }
-    DWBC_SYNC();
-    for (int i = th.tid; i < nv; i += NT) {
-        double s = -np[i];
-        for (int a = 0; a < q; a++) s -= Nm[i * kQpLd + a] * rr[a];
-        zz[i] = s;
-    }
-    DWBC_SYNC();
-}
-template <int N, int NB, int NT>
-DWBC_DEV void qp_greville_commit(Thr th, double *L, const double *np, int q, int nv) {
-    using S = Lds<N, NB>;
-    double *Nm = L + S::qp_Nm, *Np = L + S::qp_Np, *rr = L + S::qp_r, *zz = L + S::qp_z;
-    double zn2 = 0.0;
-    for (int i = 0; i < nv; i++) zn2 += zz[i] * zz[i];
-    double inv = 1.0 / zn2;
-    DWBC_SYNC();
-    for (int idx = th.tid; idx < q * nv; idx += NT) {
-        int a = idx / nv, i = idx - a * nv;
-        Np[a * kQpLd + i] -= rr[a] * zz[i] * inv;
-    }
-    for (int i = th.tid; i < nv; i += NT) {
-        Np[q * kQpLd + i] = zz[i] * inv;
-        Nm[i * kQpLd + q] = -np[i];
-    }
-    DWBC_SYNC();
-}
-
-// least-norm point of the working set's equalities: min |x~| s.t. N^T x~ = b, N = working-set normals with the
-// contact block first and multiplied by wsc, solved by a column-pivoted Householder QR (row-sorted weighting is
-// what makes the 1e9 weight stable).  Writes the unscaled x to L[qp_x].
-template <int N, int NB, int NT>
-DWBC_DEV void qp_least_norm(Thr th, double *L, int *iL, int q, int nv, int t, double wsc, double cscale) {
-    using S = Lds<N, NB>;
-    double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *x = L + S::qp_x, *Nm = L + S::qp_Nm, *V = L + S::qp_V, *bb = L + S::qp_b;
-    double *ww = L + S::qp_w, *beta = L + S::qp_beta;
-    int *act = iL;
-    const int k = nv - t;
-    DWBC_SYNC();
-    if (q > 0) {
-        // Nm[i][a]: i < k -> contact variable i (weighted), i >= k -> task variable i-k
-        for (int idx = th.tid; idx < nv * q; idx += NT) {
-            int i = idx / q, a = idx - i * q;
-            const int ra = act[a];
-            double v = (i < k) ? Gm[ra * kQpLd + t + i] * wsc : Gm[ra * kQpLd + (i - k)];
-            Nm[i * kQpLd + a] = v;
-        }
-        for (int a = th.tid; a < q; a += NT) bb[a] = ub[act[a]];
-        for (int s = 0; s < q; s++) {
-            DWBC_SYNC();
-            // column pivot: largest remaining norm
-            int jp = s;
-            double bn = -1.0;
-            for (int a = s; a < q; a++) {
-                double c2 = 0.0;
-                for (int i = s; i < nv; i++) c2 += Nm[i * kQpLd + a] * Nm[i * kQpLd + a];
-                if (c2 > bn) { bn = c2; jp = a; }
-            }
-            DWBC_SYNC();
-            if (jp != s) {
-                for (int i = th.tid; i < nv; i += NT) { double tv = Nm[i * kQpLd + s]; Nm[i * kQpLd + s] = Nm[i * kQpLd + jp]; Nm[i * kQpLd + jp] = tv; }
-                if (th.tid == 0) { double tb = bb[s]; bb[s] = bb[jp]; bb[jp] = tb; }
-            }
-            DWBC_SYNC();
-            double nrm = 0.0;
-            for (int i = s; i < nv; i++) nrm += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
-            nrm = sqrt(nrm);
-            const double a0 = Nm[s * kQpLd + s];
-            const double alpha = a0 > 0 ? -nrm : nrm;
-            double vn2 = (a0 - alpha) * (a0 - alpha);
-            for (int i = s + 1; i < nv; i++) vn2 += Nm[i * kQpLd + s] * Nm[i * kQpLd + s];
-            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
-            DWBC_SYNC();
-            for (int i = th.tid; i < nv; i += NT) V[s * kQpLd + i] = i < s ? 0.0 : (i == s ? a0 - alpha : Nm[i * kQpLd + s]);
-            if (th.tid == 0) beta[s] = bt;
-            DWBC_SYNC();
-            for (int a = s + 1 + th.tid; a < q; a += NT) {
-                double d = 0.0;
-                for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * Nm[i * kQpLd + a];
-                d *= bt;
-                for (int i = s; i < nv; i++) Nm[i * kQpLd + a] -= d * V[s * kQpLd + i];
-            }
-            for (int i = s + th.tid; i < nv; i += NT) Nm[i * kQpLd + s] = (i == s) ? alpha : 0.0;
-        }
-        // y = R^-T b  (R = Nm[:q,:q] upper)
-        for (int c = 0; c < q; c++) {
-            DWBC_SYNC();
-            const double yc = bb[c] / Nm[c * kQpLd + c];
-            DWBC_SYNC();
-            if (th.tid == 0) bb[c] = yc;
-            for (int a = c + 1 + th.tid; a < q; a += NT) bb[a] -= Nm[c * kQpLd + a] * yc;
-        }
-        DWBC_SYNC();
-        for (int i = th.tid; i < nv; i += NT) ww[i] = i < q ? bb[i] : 0.0;
-        for (int s = q - 1; s >= 0; s--) {
-            DWBC_SYNC();
-            double d = 0.0;
-            for (int i = s; i < nv; i++) d += V[s * kQpLd + i] * ww[i];
-            d *= beta[s];
-            DWBC_SYNC();
-            for (int i = s + th.tid; i < nv; i += NT) ww[i] -= d * V[s * kQpLd + i];
-        }
-        DWBC_SYNC();
-        for (int i = th.tid; i < nv; i += NT) x[i] = (i < t) ? ww[k + i] : ww[i - t] * cscale;
-    } else {
-        for (int i = th.tid; i < nv; i += NT) x[i] = 0.0;
-    }
-    DWBC_SYNC();
-}
-
-template <int N, int NB, int NT>
-DWBC_DEV int qp_solve(Thr th, double *L, int *iL, int rows, int nv, int t, int max_iter, int *iters_out, int *nact_out,
-                      double *viol_out) {
-    using S = Lds<N, NB>;
-    double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *gn = L + S::qp_gn, *x = L + S::qp_x, *rr = L + S::qp_r, *zz = L + S::qp_z;
-    double *u = L + S::qp_u, *Nm = L + S::qp_Nm, *V = L + S::qp_V, *bb = L + S::qp_b, *ww = L + S::qp_w;
-    double *beta = L + S::qp_beta, *red = L + S::qp_red;
-    int *act = iL;          // [kQpLd]
-    int *perm = iL + 16;    // [kQpLd]
-    const int k = nv - t;
-    DWBC_SYNC();
-    for (int r = th.tid; r < rows; r += NT) {
-        double s = 0.0;
-        for (int j = 0; j < nv; j++) s += Gm[r * kQpLd + j] * Gm[r * kQpLd + j];
-        s = sqrt(s);
-        gn[r] = s < 1e-300 ? 1e-300 : s;
-    }
-    for (int j = th.tid; j < kQpLd; j += NT) { x[j] = 0.0; u[j] = 0.0; }
-    int q = 0, it = 0, status = 1;
-    for (;;) {
-        DWBC_SYNC();
-        // most violated inactive row (normalised slack)
-        double worst = 1e300;
-        int p = 0x7fffffff;
-        for (int r = th.tid; r < rows; r += NT) {
-            bool in = false;
-            for (int a = 0; a < q; a++) in = in || (act[a] == r);
-            if (in) continue;
-            double s = ub[r];
-            for (int j = 0; j < nv; j++) s -= Gm[r * kQpLd + j] * x[j];
-            s /= gn[r];
-            if (s < worst || (s == worst && r < p)) { worst = s; p = r; }
-        }
-        block_argmin<NT>(th, worst, p, red);
-        if (!(worst < -kQpTol)) break;
-        double up = 0.0;
-        bool done_inner = false;
-        while (!done_inner) {
-            if (++it > max_iter) { status = 0; break; }
-            const double *np = Gm + p * kQpLd;  // constraint normal is -np (GI is stated for n^T x >= b)
-            qp_greville_add<N, NB, NT>(th, L, np, q, nv);
-            double zn2 = 0.0, zg = 0.0, rmax = 1.0;
-            for (int i = 0; i < nv; i++) { zn2 += zz[i] * zz[i]; zg -= zz[i] * np[i]; }
-            for (int a = 0; a < q; a++) rmax = fabs(rr[a]) > rmax ? fabs(rr[a]) : rmax;
-            double t1 = INFINITY, t2 = INFINITY;
-            int l = -1;
-            for (int a = 0; a < q; a++)
-                if (rr[a] > 1e-13 * rmax) {
-                    double tj = u[a] / rr[a];
-                    if (tj < t1) { t1 = tj; l = a; }
-                }
-            double sp = ub[p];
-            for (int j = 0; j < nv; j++) sp -= Gm[p * kQpLd + j] * x[j];
-            const bool zok = sqrt(zn2) > 1e-10 * gn[p] && q < nv;
-            if (zok) t2 = -sp / zg;
-            double tstep = t1 < t2 ? t1 : t2;
-            if (!(tstep < INFINITY)) { status = 0; break; }
-            const bool full = zok && t2 <= t1;
-            DWBC_SYNC();
-            if (zok)
-                for (int i = th.tid; i < nv; i += NT) x[i] += tstep * zz[i];
-            for (int a = th.tid; a < q; a += NT) u[a] -= tstep * rr[a];
-            up += tstep;
-            DWBC_SYNC();
-            if (full) {
-                qp_greville_commit<N, NB, NT>(th, L, np, q, nv);
-                if (th.tid == 0) { act[q] = p; u[q] = up; }
-                q++;
-                done_inner = true;
-            } else {
-                // drop working-set member l and rebuild N, N^+ from the remaining columns
-                DWBC_SYNC();
-                if (th.tid == 0) {
-                    for (int a = l; a < q - 1; a++) { act[a] = act[a + 1]; u[a] = u[a + 1]; }
-                }
-                q--;
-                DWBC_SYNC();
-                for (int a = 0; a < q; a++) {
-                    const double *na = Gm + act[a] * kQpLd;
-                    qp_greville_add<N, NB, NT>(th, L, na, a, nv);
-                    qp_greville_commit<N, NB, NT>(th, L, na, a, nv);
-                }
-            }
-            DWBC_SYNC();
-        }
-        if (!status) break;
-    }
-    *iters_out = it;
-    *nact_out = q;
-    DWBC_SYNC();
-    if (!status) {
-        for (int j = th.tid; j < kQpLd; j += NT) x[j] = 0.0;
-        *viol_out = 0.0;
-        DWBC_SYNC();
-        return 0;
-    }
-    // ---- final point, recomputed from the working set alone (DESIGN.md "QP canon") ----
-    //  lexicographic least-norm point (contact block weighted 1e9) if it is feasible, else the Tikhonov point
-    const bool lex = (k > 0 && t > 0);
-    double wv = 0.0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const bool weighted = lex && attempt == 0;
-        qp_least_norm<N, NB, NT>(th, L, iL, q, nv, t, weighted ? kQpScalePolish / kQpScaleGI : 1.0,
-                                 weighted ? kQpScalePolish : kQpScaleGI);
-        // worst slack of the returned point, normalised by the unscaled row norm
-        wv = 1e300;
-        int wi = 0;
-        for (int r = th.tid; r < rows; r += NT) {
-            double sl = ub[r], nr = 0.0;
-            for (int j = 0; j < nv; j++) {
-                const double a = j < t ? Gm[r * kQpLd + j] : Gm[r * kQpLd + j] * (1.0 / kQpScaleGI);
-                sl -= a * x[j];
-                nr += a * a;
-            }
-            nr = sqrt(nr);
-            sl /= (nr < 1e-300 ? 1e-300 : nr);
-            if (sl < wv) { wv = sl; wi = r; }
-        }
-        block_argmin<NT>(th, wv, wi, red);
-        DWBC_SYNC();
-        if (!weighted || !(wv < -kQpFeasTol)) break;
-    }
-    *viol_out = wv;
-    DWBC_SYNC();
-    return 1;
-}
-
-// ----------------------------------------------------------------------------------------------
 // point Jacobian (6 x N, rows [linear; angular]) of world point P fixed on body `link`
 // (CalcPointJacobian6D + row swap: reference src/link.cpp:98-119, src/contact_constraint.cpp:59-61)
 // ----------------------------------------------------------------------------------------------
@@ -625,6 +328,72 @@ DWBC_DEV void point_jacobian(Thr th, const double *L, const int *topo, int nb, i
         }
     }
     (void)nrows;
+}
+
+// ----------------------------------------------------------------------------------------------
+// QP rows into lanes + solve.  Lane r < M owns torque-limit row r (two sided), lane M + rr owns cone row rr.
+//   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)
+//   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053)
+// W1/W2/fv are the contact wrench maps already rotated into the contact frames (A_rot applied).
+// ----------------------------------------------------------------------------------------------
+template <int N, int NB>
+DWBC_DEV void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
+                                int t1, const double *P2, int ld2, int t2, double s2, const double *W1, int ldw1,
+                                const double *W2, int ldw2, const double *fv, const double *base, int tvars, int max_iter,
+                                QpResult &res) {
+    using S = Lds<N, NB>;
+    constexpr int M = S::M;
+    QpRows R;
+    const int nv = t1 + t2;
+    LANES {
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) LV(R.g)[j] = 0.0;
+        LV(R.hi) = DWBC_QP_INF;
+        LV(R.lo) = DWBC_QP_INF;
+        LV(R.id_hi) = -1;
+        LV(R.id_lo) = -1;
+        if (lane < M) {
+            if (nlim) {
+#pragma unroll
+                for (int j = 0; j < kQpN; j++) {
+                    double v = 0.0;
+                    if (j < t1) v = P1[lane * ld1 + j];
+                    else if (j < nv) v = P2[lane * ld2 + (j - t1)] * s2;
+                    LV(R.g)[j] = v;
+                }
+                LV(R.hi) = su.tau_lim[lane] - base[lane];
+                LV(R.lo) = su.tau_lim[lane] + base[lane];
+                LV(R.id_hi) = lane;
+                LV(R.id_lo) = M + lane;
+            }
+        } else if (lane - M < ncone) {
+            const int rr = lane - M, a = rr / 10, r10 = rr - 10 * a;
+            const int ci = a ? ci1 : ci0;
+            const double lx = su.c_lx[ci], ly = su.c_ly[ci], mu = su.c_mu[ci], muz = su.c_muz[ci];
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) {
+                double w[6] = {0, 0, 0, 0, 0, 0};
+                if (j < t1) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) w[c] = W1[(6 * a + c) * ldw1 + j];
+                } else if (j < nv) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) w[c] = W2[(6 * a + c) * ldw2 + (j - t1)] * s2;
+                }
+                LV(R.g)[j] = (j < nv) ? -cone_row(r10, lx, ly, mu, muz, w) : 0.0;
+            }
+            double wf[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) wf[c] = fv[6 * a + c];
+            LV(R.hi) = cone_row(r10, lx, ly, mu, muz, wf);
+            LV(R.id_hi) = nlim + rr;
+        }
+    }
+    qp_solve_wave<0>(R, nv, tvars, max_iter, res, L + S::qp_V);
+    LANES {
+        if (lane < kQpN) L[S::qp_x + lane] = pick12(res.x, lane);
+    }
+    DWBC_SYNC();
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -806,7 +575,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     DWBC_STAMP(1);  // A_inv done
     // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
     const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
-    int act_c[kMaxActiveContacts];
+    int act_c[kMaxActiveContacts] = {0, 0};
     int nc = 0;
     for (int i = 0; i < su.n_contacts; i++)
         if (fl[i] && nc < kMaxActiveContacts) act_c[nc++] = i;
@@ -1054,21 +823,13 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             DWBC_STAMP(6 + 3 * lv);  // level lv: J_kt, Lambda, null-space chain done
             // --- QP rows (dwbc.cpp:988-1053)
             const double *fs = fs_in + su.fstar_off[lv];
-            double *base = L + S::t_base, *Gm = L + S::qp_G, *ub = L + S::qp_ub, *F = L + S::t_F, *fv = L + S::t_fv;
+            double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
             for (int i = th.tid; i < M; i += NT) {
                 double s = L[S::tg + i] + L[S::tt + i];
                 for (int j = 0; j < t; j++) s += U[i * T + j] * fs[j];
                 base[i] = s;
             }
             DWBC_SYNC();
-            if (nlim)
-                for (int idx = th.tid; idx < M * nv; idx += NT) {
-                    const int i = idx / nv, j = idx - i * nv;
-                    const double v = j < t ? U[i * T + j] : L[S::NwJw + i * k + (j - t)] * kQpScaleGI;
-                    Gm[i * kQpLd + j] = v;
-                    Gm[(M + i) * kQpLd + j] = -v;
-                    if (j == 0) { ub[i] = su.tau_lim[i] - base[i]; ub[M + i] = su.tau_lim[i] + base[i]; }
-                }
             // contact wrench map in the contact-local frame: F (cd x t) = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
             for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
                 const int i = idx / (t + 1), j = idx - i * (t + 1);
@@ -1087,25 +848,16 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
             }
             DWBC_SYNC();
-            for (int idx = th.tid; idx < ncone * (nv + 1); idx += NT) {
-                const int rr_ = idx / (nv + 1), j = idx - rr_ * (nv + 1);
-                const int a = rr_ / 10, r = rr_ % 10, ci = act_c[a];
-                double w[6];
-                if (j < t) for (int c = 0; c < 6; c++) w[c] = F[(6 * a + c) * kQpLd + j];
-                else if (j < nv) for (int c = 0; c < 6; c++) w[c] = L[S::FNl + (6 * a + c) * k + (j - t)] * kQpScaleGI;
-                else for (int c = 0; c < 6; c++) w[c] = fv[6 * a + c];
-                const double v = cone_row(r, su.c_lx[ci], su.c_ly[ci], su.c_mu[ci], su.c_muz[ci], w);
-                if (j < nv) Gm[(nlim + rr_) * kQpLd + j] = -v; else ub[nlim + rr_] = v;
-            }
-            DWBC_SYNC();
-            DWBC_STAMP(7 + 3 * lv);  // level lv: QP rows assembled
-            int iters = 0, nact = 0;
-            double viol = 0.0;
-            int ok = qp_solve<N, NB, NT>(th, L, iL, nlim + ncone, nv, t, su.qp_max_iter_task, &iters, &nact, &viol);
+            DWBC_STAMP(7 + 3 * lv);  // level lv: QP inputs assembled
+            QpResult qres;
+            qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, kQpLd,
+                                     L + S::FNl, k, fv, base, t, su.qp_max_iter_task, qres);
+            const int ok = qres.status;
+            const double viol = qres.viol;
             if (diag && th.tid == 0) {
-                diag[DG_QP_ITER + lv] = iters;
-                diag[DG_QP_NACT + lv] = nact;
-                for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = a < nact ? iL[a] : -1;
+                diag[DG_QP_ITER + lv] = qres.iters;
+                diag[DG_QP_NACT + lv] = qres.nact;
+                for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = qres.act[a];
             }
             if (dump && th.tid == 0) dump[dl.qp_viol + lv] = viol;
             DWBC_STAMP(8 + 3 * lv);  // level lv: QP solved
@@ -1132,18 +884,10 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     // ================= stage 4: contact redistribution (dwbc.cpp:1372-1568) =================
     int st_redis = 1;
     if (k > 0) {
-        double *Gm = L + S::qp_G, *ub = L + S::qp_ub, *base = L + S::t_base, *fv = L + S::t_fv, *JbT = L + S::JbT;
+        double *base = L + S::t_base, *fv = L + S::t_fv, *JbT = L + S::JbT;
         DWBC_SYNC();
         for (int i = th.tid; i < M; i += NT) base[i] = L[S::tg + i] + L[S::tt + i] + L[S::tc + i];
         DWBC_SYNC();
-        if (nlim)
-            for (int idx = th.tid; idx < M * k; idx += NT) {
-                const int i = idx / k, j = idx - i * k;
-                const double v = L[S::NwJw + i * k + j];
-                Gm[i * kQpLd + j] = v;
-                Gm[(M + i) * kQpLd + j] = -v;
-                if (j == 0) { ub[i] = su.tau_lim[i] - base[i]; ub[M + i] = su.tau_lim[i] + base[i]; }
-            }
         for (int i = th.tid; i < cd; i += NT) {
             double s = -L[S::PC + i];
             for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * base[c];
@@ -1157,23 +901,15 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             fv[i] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[1] + R[2 * 3 + x] * src[2];
         }
         DWBC_SYNC();
-        for (int idx = th.tid; idx < ncone * (k + 1); idx += NT) {
-            const int rr_ = idx / (k + 1), j = idx - rr_ * (k + 1);
-            const int a = rr_ / 10, r = rr_ % 10, ci = act_c[a];
-            double w[6];
-            if (j < k) for (int c = 0; c < 6; c++) w[c] = L[S::FNl + (6 * a + c) * k + j];
-            else for (int c = 0; c < 6; c++) w[c] = fv[6 * a + c];
-            const double v = cone_row(r, su.c_lx[ci], su.c_ly[ci], su.c_mu[ci], su.c_muz[ci], w);
-            if (j < k) Gm[(nlim + rr_) * kQpLd + j] = -v; else ub[nlim + rr_] = v;
-        }
-        DWBC_SYNC();
-        int iters = 0, nact = 0;
-        double viol = 0.0;
-        int ok = qp_solve<N, NB, NT>(th, L, iL, nlim + ncone, k, k, su.qp_max_iter_contact, &iters, &nact, &viol);
+        QpResult qres;
+        qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], L + S::NwJw, k, k, L + S::NwJw, k, 0, 1.0, L + S::FNl, k,
+                                 L + S::FNl, k, fv, base, k, su.qp_max_iter_contact, qres);
+        const int ok = qres.status;
+        const double viol = qres.viol;
         if (diag && th.tid == 0) {
-            diag[DG_QP_ITER + kMaxLevels] = iters;
-            diag[DG_QP_NACT + kMaxLevels] = nact;
-            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = a < nact ? iL[a] : -1;
+            diag[DG_QP_ITER + kMaxLevels] = qres.iters;
+            diag[DG_QP_NACT + kMaxLevels] = qres.nact;
+            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = qres.act[a];
         }
         if (dump && th.tid == 0) dump[dl.qp_viol + kMaxLevels] = viol;
         const double *x = L + S::qp_x;

@@ -1,0 +1,368 @@
+// dwbc_qp_wave.h -- register-resident batched active-set QP, one wavefront per problem.
+//
+//   lexmin( 1/2|x[:t]|^2 , 1/2|x[t:]|^2 )  s.t.  lo_r <= g_r . x <= hi_r      (H = diag(I_t, 0_k), g = 0)
+//
+// Replaces CQuadraticProgram::SolveQPoases (reference src/qp_wrapper.cpp:192-380) for the QPs assembled by
+// CalcSingleTaskTorqueWithQP / CalcContactRedistribute (reference src/dwbc.cpp:988-1053, 1458-1517).
+//
+// Layout: lane r owns constraint row r in registers -- the 33 torque-limit rows are stored once as two-sided rows
+// (+/-(row) <= tau_lim -/+ base), the 20 friction/CoP cone rows one-sided -- so 53 lanes hold the whole 86-row QP and
+// a slack evaluation is 12 FMAs per lane against the uniform iterate.  The Goldfarb-Idnani working-set state lives in
+// lanes 0..11: lane a holds row a of the pseudo-inverse N^+ of the active normals and lane i row i of N; every step is
+// a 12-term dot product per lane plus v_readlane broadcasts -- no LDS round trips, no triangular solves.
+// See DESIGN.md "QP canon" for the definition of the returned point.
+#pragma once
+#include "dwbc_wave.h"
+
+namespace dwbc {
+
+constexpr int kQpN = 12;  // max variables (6 task + 6 contact-null)
+
+struct QpRows {
+    PLA(double, g, kQpN);  // row coefficients, contact columns already scaled by kQpScaleGI, zero padded
+    PL(double, hi);        // g.x <= hi
+    PL(double, lo);        // -g.x <= lo   (lo = +inf: one-sided row)
+    PL(int, id_hi);        // reference row index of the hi side (for diagnostics)
+    PL(int, id_lo);
+};
+
+struct QpResult {
+    int status, iters, nact;
+    double viol;
+    double x[kQpN];   // uniform, unscaled [delta (t); c (k)]
+    int act[kQpN];    // reference row indices of the working set
+};
+
+#define DWBC_QP_INF 1.0e300
+
+// one Greville step: given uniform normal n[12], compute per-lane r (lane a<q) and uniform ru[], zu[]
+#define DWBC_QP_PROJECT(q_)                                                                 \
+    LANES {                                                                                  \
+        double s_ = 0.0;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < kQpN; i++) s_ += LV(Np)[i] * n[i];             \
+        LV(r) = (lane < (q_)) ? s_ : 0.0;                                                    \
+    }                                                                                        \
+    _Pragma("unroll") for (int a = 0; a < kQpN; a++) ru[a] = BCAST(r, a);                    \
+    LANES {                                                                                  \
+        double s_ = pick12(n, lane);                                                         \
+        _Pragma("unroll") for (int a = 0; a < kQpN; a++) s_ -= LV(Nr)[a] * ru[a];            \
+        LV(z) = (lane < nv) ? s_ : 0.0;                                                      \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < kQpN; i++) zu[i] = BCAST(z, i);
+
+// append the current normal as column q_ of N and update N^+ (Greville)
+#define DWBC_QP_COMMIT(q_)                                                                   \
+    {                                                                                        \
+        double zn2_ = 0.0;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < kQpN; i++) zn2_ += zu[i] * zu[i];              \
+        const double inv_ = 1.0 / zn2_;                                                      \
+        LANES {                                                                              \
+            const double ra_ = LV(r) * inv_;                                                 \
+            const bool newrow_ = (lane == (q_));                                             \
+            _Pragma("unroll") for (int i = 0; i < kQpN; i++) {                               \
+                const double upd_ = LV(Np)[i] - ra_ * zu[i];                                 \
+                LV(Np)[i] = newrow_ ? zu[i] * inv_ : ((lane < (q_)) ? upd_ : 0.0);           \
+            }                                                                                \
+            setidx12(LV(Nr), (q_), pick12(n, lane));                                         \
+        }                                                                                    \
+    }
+
+template <int DUMMY>
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS 12x12 */) {
+    const int k = nv - t;
+    PLA(double, Np, kQpN);
+    PLA(double, Nr, kQpN);
+    PL(double, r);
+    PL(double, z);
+    PL(double, u);
+    PL(double, rgn);   // 1 / |g|
+    PL(int, akey);     // lane a < q: (owner lane << 1) | side of the a-th working-set member
+    PL(int, actf);     // bit0: hi side in the working set, bit1: lo side
+    PL(double, val);
+    PL(int, key);
+    double xu[kQpN], n[kQpN], ru[kQpN], zu[kQpN];
+#pragma unroll
+    for (int i = 0; i < kQpN; i++) xu[i] = 0.0;
+    LANES {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) { s += LV(R.g)[j] * LV(R.g)[j]; LV(Np)[j] = 0.0; LV(Nr)[j] = 0.0; }
+        s = sqrt(s);
+        LV(rgn) = 1.0 / (s < 1e-300 ? 1e-300 : s);
+        LV(u) = 0.0;
+        LV(r) = 0.0;
+        LV(z) = 0.0;
+        LV(akey) = 0;
+        LV(actf) = 0;
+    }
+    int q = 0, it = 0, status = 1;
+    for (;;) {
+        // most violated row not in the working set (normalised slack)
+        LANES {
+            double d = 0.0;
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) d += LV(R.g)[j] * xu[j];
+            double sh = (LV(actf) & 1) ? DWBC_QP_INF : (LV(R.hi) - d) * LV(rgn);
+            double sl = ((LV(actf) & 2) || LV(R.lo) >= DWBC_QP_INF) ? DWBC_QP_INF : (LV(R.lo) + d) * LV(rgn);
+            if (LV(R.hi) >= DWBC_QP_INF) sh = DWBC_QP_INF;
+            const bool lo_side = sl < sh;
+            LV(val) = lo_side ? sl : sh;
+            LV(key) = (lane << 1) | (lo_side ? 1 : 0);
+        }
+        double worst;
+        int kmin;
+        WAVE_ARGMIN(val, key, worst, kmin);
+        if (!(worst < -kQpTol)) break;
+        const int p = kmin >> 1, side = kmin & 1;
+        double gp[kQpN];
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
+        const double bp = side ? BCAST(R.lo, p) : BCAST(R.hi, p);
+        const double gnp = 1.0 / BCAST(rgn, p);
+        // GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) n[j] = side ? gp[j] : -gp[j];
+        double up = 0.0;
+        bool done_inner = false;
+        while (!done_inner) {
+            if (++it > max_iter) { status = 0; break; }
+            DWBC_QP_PROJECT(q);
+            double zn2 = 0.0, zg = 0.0, rmax = 1.0;
+#pragma unroll
+            for (int i = 0; i < kQpN; i++) { zn2 += zu[i] * zu[i]; zg += zu[i] * n[i]; }
+#pragma unroll
+            for (int a = 0; a < kQpN; a++) rmax = fabs(ru[a]) > rmax ? fabs(ru[a]) : rmax;
+            // dual ratio test (per lane, then broadcast)
+            LANES {
+                const bool ok = (lane < q) && (LV(r) > 1e-13 * rmax);
+                LV(val) = ok ? LV(u) / LV(r) : DWBC_QP_INF;
+                LV(key) = lane;
+            }
+            double t1 = DWBC_QP_INF;
+            int l = -1;
+#pragma unroll
+            for (int a = 0; a < kQpN; a++) {
+                const double ta = BCAST(val, a);
+                if (ta < t1) { t1 = ta; l = a; }
+            }
+            double gx = 0.0;
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) gx += gp[j] * xu[j];
+            const double sp = side ? (bp + gx) : (bp - gx);  // slack of the violated side (negative)
+            const bool zok = sqrt(zn2) > 1e-10 * gnp && q < nv;
+            const double t2 = zok ? -sp / zg : DWBC_QP_INF;
+            const double tstep = t1 < t2 ? t1 : t2;
+            if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
+            const bool full = zok && t2 <= t1;
+            if (zok) {
+#pragma unroll
+                for (int i = 0; i < kQpN; i++) xu[i] += tstep * zu[i];
+            }
+            LANES { LV(u) -= tstep * LV(r); }
+            up += tstep;
+            if (full) {
+                DWBC_QP_COMMIT(q);
+                LANES {
+                    if (lane == q) { LV(u) = up; LV(akey) = kmin; }
+                    if (lane == p) LV(actf) |= (side ? 2 : 1);
+                }
+                q++;
+                done_inner = true;
+            } else {
+                // drop working-set member l, compact, rebuild N and N^+ from the remaining members
+                const int kl = BCASTI(akey, l);
+                PL(double, un);
+                PL(int, kn);
+                LANES {
+                    const int src = (lane >= l && lane < q - 1) ? lane + 1 : lane;
+                    LV(un) = SHFL(u, src);
+                    LV(kn) = SHFL(akey, src);
+                }
+                LANES {
+                    LV(u) = LV(un);
+                    LV(akey) = LV(kn);
+                    if (lane == (kl >> 1)) LV(actf) &= ~((kl & 1) ? 2 : 1);
+#pragma unroll
+                    for (int j = 0; j < kQpN; j++) { LV(Np)[j] = 0.0; LV(Nr)[j] = 0.0; }
+                }
+                q--;
+                double nsave[kQpN];
+#pragma unroll
+                for (int j = 0; j < kQpN; j++) nsave[j] = n[j];
+                for (int a = 0; a < q; a++) {
+                    const int ka = BCASTI(akey, a);
+#pragma unroll
+                    for (int j = 0; j < kQpN; j++) {
+                        const double gj = BCASTA(R.g, j, ka >> 1);
+                        n[j] = (ka & 1) ? gj : -gj;
+                    }
+                    DWBC_QP_PROJECT(a);
+                    DWBC_QP_COMMIT(a);
+                }
+#pragma unroll
+                for (int j = 0; j < kQpN; j++) n[j] = nsave[j];
+            }
+        }
+        if (!status) break;
+    }
+    out.iters = it;
+    out.nact = q;
+    out.status = status;
+    out.viol = 0.0;
+#pragma unroll
+    for (int a = 0; a < kQpN; a++) {
+        const int ka = BCASTI(akey, a);
+        const int ow = ka >> 1;
+        const int idh = BCASTI(R.id_hi, ow), idl = BCASTI(R.id_lo, ow);
+        out.act[a] = a < q ? ((ka & 1) ? idl : idh) : -1;
+    }
+    if (!status) {
+#pragma unroll
+        for (int i = 0; i < kQpN; i++) out.x[i] = 0.0;
+        return;
+    }
+    // ---- final point from the working set alone: lexicographic least-norm point (contact block weighted) if it is
+    //      feasible, else the Tikhonov point (DESIGN.md "QP canon").  Column a of the weighted normal matrix lives in
+    //      lane a; column-pivoted Householder QR, rows = variables with the contact block first.
+    const bool lex = (k > 0 && t > 0);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool weighted = lex && attempt == 0;
+        const double wsc = weighted ? kQpScalePolish / kQpScaleGI : 1.0;
+        const double cscale = weighted ? kQpScalePolish : kQpScaleGI;
+        PLA(double, c, kQpN);
+        PL(double, bb);
+        PL(int, done);
+        PL(double, w);
+        LANES {
+            const int ka = LV(akey);
+            const int ow = (lane < q) ? (ka >> 1) : lane;
+            const double sg = (ka & 1) ? -1.0 : 1.0;  // row as  (sg*g).x = b
+            double grow[kQpN];
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) grow[j] = SHFLA(R.g, j, ow);
+            const double bh = SHFL(R.hi, ow), bl = SHFL(R.lo, ow);
+            // variable order: contact block first (weighted), then the task block
+#pragma unroll
+            for (int i = 0; i < kQpN; i++) {
+                const int var = (i < k) ? (t + i) : (i - k);
+                const double gv = pick12(grow, var);
+                LV(c)[i] = (lane < q && i < nv) ? sg * gv * ((i < k) ? wsc : 1.0) : 0.0;
+            }
+            LV(bb) = (lane < q) ? ((ka & 1) ? bl : bh) : 0.0;
+            LV(done) = (lane < q) ? 0 : 1;
+            LV(w) = 0.0;
+        }
+        double beta[kQpN], yu[kQpN];
+        int order[kQpN];
+#pragma unroll
+        for (int s = 0; s < kQpN; s++) {
+            beta[s] = 0.0;
+            yu[s] = 0.0;
+            order[s] = 0;
+            if (s < q) {
+                LANES {
+                    double c2 = 0.0;
+#pragma unroll
+                    for (int i = s; i < kQpN; i++) c2 += LV(c)[i] * LV(c)[i];
+                    LV(val) = LV(done) ? DWBC_QP_INF : -c2;
+                    LV(key) = lane;
+                }
+                double bn;
+                int jp;
+                WAVE_ARGMIN(val, key, bn, jp);
+                order[s] = jp;
+                double v[kQpN];
+                double nrm = 0.0;
+#pragma unroll
+                for (int i = 0; i < kQpN; i++) {
+                    v[i] = (i >= s) ? BCASTA(c, i, jp) : 0.0;
+                    nrm += v[i] * v[i];
+                }
+                nrm = sqrt(nrm);
+                const double a0 = v[s];
+                const double alpha = a0 > 0 ? -nrm : nrm;
+                v[s] = a0 - alpha;
+                double vn2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < kQpN; i++) vn2 += v[i] * v[i];
+                const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
+                beta[s] = bt;
+                LANES {
+                    if (lane < kQpN) V[s * kQpN + lane] = pick12(v, lane);
+                    if (lane == jp) {
+                        LV(done) = 1;
+                        LV(c)[s] = alpha;
+                    } else if (!LV(done)) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int i = s; i < kQpN; i++) d += v[i] * LV(c)[i];
+                        d *= bt;
+#pragma unroll
+                        for (int i = s; i < kQpN; i++) LV(c)[i] -= d * v[i];
+                    }
+                }
+            }
+        }
+        // R^T y = b in pivot order: column of R for pivot s is lane order[s]'s c[0..s]
+#pragma unroll
+        for (int s = 0; s < kQpN; s++) {
+            if (s < q) {
+                LANES {
+                    double sacc = LV(bb);
+#pragma unroll
+                    for (int cidx = 0; cidx < s; cidx++) sacc -= LV(c)[cidx] * yu[cidx];
+                    LV(val) = sacc / LV(c)[s];
+                }
+                yu[s] = BCAST(val, order[s]);
+            }
+        }
+        LANES { LV(w) = (lane < q) ? pick12(yu, lane) : 0.0; }
+        WSYNC();
+#pragma unroll
+        for (int s = kQpN - 1; s >= 0; s--) {
+            if (s < q) {
+                PL(double, vs);
+                LANES {
+                    LV(vs) = (lane < kQpN) ? V[s * kQpN + lane] : 0.0;
+                    LV(val) = LV(vs) * LV(w);
+                }
+                double d = 0.0;
+#pragma unroll
+                for (int i = 0; i < kQpN; i++) d += BCAST(val, i);
+                d *= beta[s];
+                LANES { LV(w) -= d * LV(vs); }
+            }
+        }
+        WSYNC();
+        // x[j]: task variable j sits at position k + j, contact variable j at position j
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) {
+            const int pos = (j < t) ? (k + j) : (j - t);
+            const double wj = BCAST(w, (pos < kQpN && pos >= 0) ? pos : 0);
+            out.x[j] = (j < nv) ? ((j < t) ? wj : wj * cscale) : 0.0;
+        }
+        // worst slack of the returned point, normalised by the unscaled row norm
+        LANES {
+            double d = 0.0, nr = 0.0;
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) {
+                const double a = (j < t) ? LV(R.g)[j] : LV(R.g)[j] * (1.0 / kQpScaleGI);
+                d += a * out.x[j];
+                nr += a * a;
+            }
+            nr = sqrt(nr);
+            const double rn = 1.0 / (nr < 1e-300 ? 1e-300 : nr);
+            const double sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - d) * rn;
+            const double sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + d) * rn;
+            LV(val) = sl < sh ? sl : sh;
+            LV(key) = lane;
+        }
+        double wv;
+        int wi;
+        WAVE_ARGMIN(val, key, wv, wi);
+        out.viol = wv >= DWBC_QP_INF ? 0.0 : wv;
+        if (!weighted || !(wv < -kQpFeasTol)) break;
+    }
+}
+
+}  // namespace dwbc

@@ -1,0 +1,88 @@
+// dwbc_wave.h -- wave-synchronous programming helpers (one 64-lane wavefront = one robot instance).
+//
+// Device build: a "per-lane" variable is an ordinary register variable, LANES{...} is a plain block executed by all
+// 64 lanes in lockstep, cross-lane traffic uses v_readlane / ds_bpermute.
+// Host emulation build (tests/emu, DWBC_HOST_EMU): a per-lane variable is an array of 64, LANES{...} loops over the
+// lanes, cross-lane primitives index that array.  The emulation is exact as long as a LANES block never reads a
+// per-lane value that another lane writes inside the same block -- the same rule the hardware needs a barrier or a
+// cross-lane instruction for.
+#pragma once
+#include <math.h>
+
+#ifdef DWBC_HOST_EMU
+#define PL(type, x) type x[64]
+#define PLA(type, x, n) type x[64][n]
+#define LV(x) x[lane]
+#define LANES for (int lane = 0; lane < 64; ++lane)
+#define WSYNC() ((void)0)
+#define BCAST(x, src) ((x)[(src)])                 /* uniform value of per-lane scalar x in lane src */
+#define BCASTA(x, j, src) ((x)[(src)][(j)])        /* uniform value of per-lane array element x[j] in lane src */
+#define SHFLA(x, j, src) ((x)[(src)][(j)])         /* inside LANES: x[j] of lane `src` (src may differ per lane) */
+#define SHFL(x, src) ((x)[(src)])
+#define DWBC_WDEV inline
+#else
+#define PL(type, x) type x
+#define PLA(type, x, n) type x[n]
+#define LV(x) x
+#define LANES
+#define WSYNC() __syncthreads()
+#define BCAST(x, src) dwbc::readlane_f64((x), (src))
+#define BCASTA(x, j, src) dwbc::readlane_f64((x)[(j)], (src))
+#define SHFLA(x, j, src) __shfl((x)[(j)], (src), 64)
+#define SHFL(x, src) __shfl((x), (src), 64)
+#define DWBC_WDEV __device__ __forceinline__
+#endif
+
+namespace dwbc {
+
+#ifndef DWBC_HOST_EMU
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int readlane_i32(int v, int srclane) { return __builtin_amdgcn_readlane(v, srclane); }
+#define BCASTI(x, src) dwbc::readlane_i32((x), (src))
+#else
+#define BCASTI(x, src) ((x)[(src)])
+#endif
+
+// element `lane` of a uniform 12-array (avoids dynamic register indexing on the device)
+DWBC_WDEV double pick12(const double *a, int lane) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) v = (lane == i) ? a[i] : v;
+    return v;
+}
+// arr[q] = v for a per-lane 12-array with a (uniform or per-lane) dynamic index
+DWBC_WDEV void setidx12(double *arr, int q, double v) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) arr[i] = (i == q) ? v : arr[i];
+}
+
+}  // namespace dwbc
+
+// wave-wide arg-min over a per-lane (value, key): results are uniform.  Ties go to the smaller key.
+#ifdef DWBC_HOST_EMU
+#define WAVE_ARGMIN(val, key, out_v, out_k)                                                        \
+    do {                                                                                           \
+        out_v = (val)[0];                                                                          \
+        out_k = (key)[0];                                                                          \
+        for (int l_ = 1; l_ < 64; l_++)                                                            \
+            if ((val)[l_] < out_v || ((val)[l_] == out_v && (key)[l_] < out_k)) { out_v = (val)[l_]; out_k = (key)[l_]; } \
+    } while (0)
+#else
+#define WAVE_ARGMIN(val, key, out_v, out_k)                                                        \
+    do {                                                                                           \
+        double v_ = (val);                                                                         \
+        int k_ = (key);                                                                            \
+        _Pragma("unroll") for (int off_ = 32; off_ > 0; off_ >>= 1) {                              \
+            const double ov_ = __shfl_xor(v_, off_, 64);                                           \
+            const int ok_ = __shfl_xor(k_, off_, 64);                                              \
+            if (ov_ < v_ || (ov_ == v_ && ok_ < k_)) { v_ = ov_; k_ = ok_; }                       \
+        }                                                                                          \
+        out_v = v_;                                                                                \
+        out_k = k_;                                                                                \
+    } while (0)
+#endif
