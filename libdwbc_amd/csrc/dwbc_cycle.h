@@ -343,6 +343,7 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone,
                                 QpResult &res) {
     using S = Lds<N, NB>;
     constexpr int M = S::M;
+    DWBC_LANE_DECL;
     QpRows R;
     const int nv = t1 + t2;
     LANES {

@@ -69,6 +69,7 @@ struct QpResult {
 
 template <int DUMMY>
 DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS 12x12 */) {
+    DWBC_LANE_DECL;
     const int k = nv - t;
     PLA(double, Np, kQpN);
     PLA(double, Nr, kQpN);

@@ -15,6 +15,7 @@
 #define LV(x) x[lane]
 #define LANES for (int lane = 0; lane < 64; ++lane)
 #define WSYNC() ((void)0)
+#define DWBC_LANE_DECL ((void)0)
 #define BCAST(x, src) ((x)[(src)])                 /* uniform value of per-lane scalar x in lane src */
 #define BCASTA(x, j, src) ((x)[(src)][(j)])        /* uniform value of per-lane array element x[j] in lane src */
 #define SHFLA(x, j, src) ((x)[(src)][(j)])         /* inside LANES: x[j] of lane `src` (src may differ per lane) */
@@ -26,6 +27,7 @@
 #define LV(x) x
 #define LANES
 #define WSYNC() __syncthreads()
+#define DWBC_LANE_DECL const int lane = (int)threadIdx.x
 #define BCAST(x, src) dwbc::readlane_f64((x), (src))
 #define BCASTA(x, j, src) dwbc::readlane_f64((x)[(j)], (src))
 #define SHFLA(x, j, src) __shfl((x)[(j)], (src), 64)
