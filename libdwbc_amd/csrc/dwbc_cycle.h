@@ -271,6 +271,60 @@ DWBC_DEV int spd_inverse(Thr th, double *S, int n, double *Tmp, double *Out) {
     return ok;
 }
 
+// SPD inverse with one matrix column per lane held in registers (symmetric Gauss-Jordan "sweep", no pivoting needed for
+// SPD).  Per pivot k: lane k publishes its column to LDS, every lane j reads c_j = S[j][k] and the uniform column c_i,
+// and applies  S[i][j] -= (c_i - delta_ik) * h_j  with h_j = c_j / d (h_k = 1 - 1/d): one FMA per element, the row-k
+// and column-k special cases of the sweep fall out of the modified multiplier.  The diagonal is tracked separately
+// (dg) so that no register is indexed dynamically.  Same arithmetic role as Eigen's llt().solve(I) (reference
+// src/dwbc.cpp:307).  Sin: NN x NN row-major LDS (ld), Out: NN x NN (ldo), colbuf: NN doubles of LDS.
+template <int NN>
+DWBC_DEV int spd_inverse_wave(const double *Sin, int ld, double *Out, int ldo, double *colbuf) {
+    DWBC_LANE_DECL;
+    PLA(double, s, NN);
+    PL(double, dg);
+    DWBC_SYNC();
+    LANES {
+        const int col = lane < NN ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (lane < NN) ? Sin[i * ld + col] : 0.0;
+        LV(dg) = (lane < NN) ? Sin[col * ld + col] : 1.0;
+    }
+    int ok = 1;
+    for (int k = 0; k < NN; k++) {
+        double d = BCAST(dg, k);
+        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        const double rp = 1.0 / d;
+        DWBC_SYNC();
+        LANES {
+            if (lane == k) {
+#pragma unroll
+                for (int i = 0; i < NN; i++) colbuf[i] = LV(s)[i];
+            }
+        }
+        DWBC_SYNC();
+        LANES {
+            if (lane == k) colbuf[k] = d - 1.0;
+        }
+        DWBC_SYNC();
+        LANES {
+            const double cj = colbuf[lane < NN ? lane : 0];
+            const double h = (lane == k) ? (1.0 - rp) : cj * rp;
+#pragma unroll
+            for (int i = 0; i < NN; i++) LV(s)[i] -= colbuf[i] * h;
+            LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
+        }
+    }
+    DWBC_SYNC();
+    LANES {
+        if (lane < NN) {
+#pragma unroll
+            for (int i = 0; i < NN; i++) Out[i * ldo + lane] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        }
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
 DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, const double *w) {
     // rows of [GetZMPConstMatrix; GetForceConstMatrix] (reference src/wbd.cpp:59-97) applied to a local wrench
     switch (r) {
@@ -561,11 +615,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     int st_contact = 1;
     // A_inv = llt(A).solve(I)  (dwbc.cpp:307): bufA (A) -> bufA (A_inv), bufN scratch
     {
-        int ok = spd_inverse<NT>(th, L + S::bufA, N, L + S::bufN, L + S::tmp + 0);  // Out into tmp (N*N fits: checked below)
-        static_assert(S::k_end - S::tmp >= 0, "");
-        DWBC_SYNC();
-        for (int idx = th.tid; idx < N * N; idx += NT) L[S::bufA + idx] = L[S::tmp + idx];
-        DWBC_SYNC();
+        const int ok = spd_inverse_wave<N>(L + S::bufA, N, L + S::bufA, N, L + S::tmp);  // in place (columns live in registers)
         if (!ok) st_contact = 0;
         if (dump) {
             for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A_inv + idx] = L[S::bufA + idx];
@@ -683,11 +733,8 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         {
             // spd_inverse scratch: reuse c_Y.. region? it is M*M <= C*N + M*K + ... : use c_Y (C*N=468 < M*M) -> not enough.
             // Use bufA itself as Tmp and write the result to W1's neighbour P afterwards.
-            double *Tmp = L + S::bufA;
-            double *Out = L + S::c_Y;  // c_Y..c_s2 span: C*N + M*K + C*2C + C*C = 468+198+288+144 = 1098 >= M*M (1089) for N=39
-            static_assert(S::c_P - S::c_Y >= M * M, "scratch for W inverse too small");
-            // keep P: copy needed part first
-            int ok = spd_inverse<NT>(th, W1, M, Tmp, Out);
+            double *Out = W1;
+            const int ok = spd_inverse_wave<M>(W1, M, W1, M, L + S::c_Y);
             if (!ok) st_contact = 0;
             DWBC_SYNC();
             const double ia = alpha != 0.0 ? 1.0 / alpha : 0.0;

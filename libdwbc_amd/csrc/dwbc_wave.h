@@ -75,16 +75,41 @@ DWBC_WDEV void setidx12(double *arr, int q, double v) {
             if ((val)[l_] < out_v || ((val)[l_] == out_v && (key)[l_] < out_k)) { out_v = (val)[l_]; out_k = (key)[l_]; } \
     } while (0)
 #else
+namespace dwbc {
+// min over the wave of a 64-bit unsigned key with DPP row shifts / row broadcasts (gfx9 family), result uniform
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x) {
+#define DWBC_DPP_STEP(ctrl, rmask)                                                                         \
+    {                                                                                                      \
+        const int lo_ = (int)(unsigned)(x & 0xffffffffull), hi_ = (int)(unsigned)(x >> 32);                \
+        const int olo_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, rmask, 0xf, false);                   \
+        const int ohi_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, rmask, 0xf, false);                   \
+        const unsigned long long o_ = ((unsigned long long)(unsigned)ohi_ << 32) | (unsigned)olo_;         \
+        x = o_ < x ? o_ : x;                                                                               \
+    }
+    DWBC_DPP_STEP(0x111, 0xf)  // row_shr:1
+    DWBC_DPP_STEP(0x112, 0xf)  // row_shr:2
+    DWBC_DPP_STEP(0x114, 0xf)  // row_shr:4
+    DWBC_DPP_STEP(0x118, 0xf)  // row_shr:8   -> lane 15 of each row holds the row minimum
+    DWBC_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    DWBC_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+#undef DWBC_DPP_STEP
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(x & 0xffffffffull), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// order-preserving map double -> u64, low 7 bits replaced by the lane so that keys are unique
+__device__ __forceinline__ unsigned long long argmin_key(double v, int lane) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    return (b & ~127ull) | (unsigned)lane;
+}
+}  // namespace dwbc
+// values are compared with their 7 lowest mantissa bits dropped (1.4e-14 relative); the winner's exact value is returned
 #define WAVE_ARGMIN(val, key, out_v, out_k)                                                        \
     do {                                                                                           \
-        double v_ = (val);                                                                         \
-        int k_ = (key);                                                                            \
-        _Pragma("unroll") for (int off_ = 32; off_ > 0; off_ >>= 1) {                              \
-            const double ov_ = __shfl_xor(v_, off_, 64);                                           \
-            const int ok_ = __shfl_xor(k_, off_, 64);                                              \
-            if (ov_ < v_ || (ov_ == v_ && ok_ < k_)) { v_ = ov_; k_ = ok_; }                       \
-        }                                                                                          \
-        out_v = v_;                                                                                \
-        out_k = k_;                                                                                \
+        const unsigned long long m_ = dwbc::wave_min_u64(dwbc::argmin_key((val), lane));           \
+        const int wl_ = (int)(m_ & 127ull);                                                        \
+        out_v = dwbc::readlane_f64((val), wl_);                                                    \
+        out_k = dwbc::readlane_i32((key), wl_);                                                    \
     } while (0)
 #endif
