@@ -40,9 +40,11 @@
 
 #ifdef DWBC_HOST_EMU
 #define DWBC_DEV
+#define DWBC_DEVN
 #define DWBC_SYNC() ((void)0)
 #else
 #define DWBC_DEV __device__ __forceinline__
+#define DWBC_DEVN __device__ __noinline__  /* shared helpers: keep the kernel inside the instruction cache */
 #define DWBC_SYNC() __syncthreads()
 #endif
 
@@ -137,7 +139,7 @@ struct Thr {
 };
 
 template <int NT>
-DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEVN void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -147,7 +149,7 @@ DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const
 }
 // C = A * B^T   (A m x k, B n x k)
 template <int NT>
-DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEVN void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -157,7 +159,7 @@ DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const
 }
 // C = A^T * B   (A k x m, B k x n)
 template <int NT>
-DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEVN void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -166,7 +168,7 @@ DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const
     }
 }
 template <int NT>
-DWBC_DEV void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
+DWBC_DEVN void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
     for (int i = th.tid; i < m; i += NT) {
         double s = 0.0;
         for (int j = 0; j < n; j++) s += A[i * lda + j] * x[j];
@@ -177,7 +179,7 @@ DWBC_DEV void mv_n(Thr th, double *y, const double *A, int lda, const double *x,
 // In-place inverse of a small general matrix by Gauss-Jordan with partial pivoting (stands in for Eigen's
 // MatrixXd::inverse(), reference src/wbd.cpp:115,128,210).  W is an n x 2n scratch.  Returns min|pivot|/max|pivot|.
 template <int NT>
-DWBC_DEV double gj_inverse(Thr th, const double *A, int lda, int n, double *Ai, int ldi, double *W) {
+DWBC_DEVN double gj_inverse(Thr th, const double *A, int lda, int n, double *Ai, int ldi, double *W) {
     const int w = 2 * n;
     DWBC_SYNC();
     for (int idx = th.tid; idx < n * w; idx += NT) {
@@ -278,7 +280,7 @@ DWBC_DEV int spd_inverse(Thr th, double *S, int n, double *Tmp, double *Out) {
 // (dg) so that no register is indexed dynamically.  Same arithmetic role as Eigen's llt().solve(I) (reference
 // src/dwbc.cpp:307).  Sin: NN x NN row-major LDS (ld), Out: NN x NN (ldo), colbuf: NN doubles of LDS.
 template <int NN>
-DWBC_DEV int spd_inverse_wave(const double *Sin, int ld, double *Out, int ldo, double *colbuf) {
+DWBC_DEVN int spd_inverse_wave(const double *Sin, int ld, double *Out, int ldo, double *colbuf) {
     DWBC_LANE_DECL;
     PLA(double, s, NN);
     PL(double, dg);
@@ -346,7 +348,7 @@ DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, con
 // (CalcPointJacobian6D + row swap: reference src/link.cpp:98-119, src/contact_constraint.cpp:59-61)
 // ----------------------------------------------------------------------------------------------
 template <int N, int NB, int NT>
-DWBC_DEV void point_jacobian(Thr th, const double *L, const int *topo, int nb, int link, const double *P, double *J, int ld,
+DWBC_DEVN void point_jacobian(Thr th, const double *L, const int *topo, int nb, int link, const double *P, double *J, int ld,
                              int row0, int nrows, int rsel) {
     using S = Lds<N, NB>;
     const double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw;
@@ -391,7 +393,7 @@ DWBC_DEV void point_jacobian(Thr th, const double *L, const int *topo, int nb, i
 // W1/W2/fv are the contact wrench maps already rotated into the contact frames (A_rot applied).
 // ----------------------------------------------------------------------------------------------
 template <int N, int NB>
-DWBC_DEV void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
+DWBC_DEVN void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
                                 int t1, const double *P2, int ld2, int t2, double s2, const double *W1, int ldw1,
                                 const double *W2, int ldw2, const double *fv, const double *base, int tvars, int max_iter,
                                 QpResult &res) {
@@ -422,25 +424,22 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone,
                 LV(R.id_lo) = M + lane;
             }
         } else if (lane - M < ncone) {
+            // cone row r10 of contact a acts on the local wrench w as  c2 * w[2] + sg * w[oi]   (reference src/wbd.cpp:59-97)
             const int rr = lane - M, a = rr / 10, r10 = rr - 10 * a;
             const int ci = a ? ci1 : ci0;
-            const double lx = su.c_lx[ci], ly = su.c_ly[ci], mu = su.c_mu[ci], muz = su.c_muz[ci];
+            const int pr = r10 >> 1;
+            const double c2 = -(pr == 0 ? su.c_lx[ci] : pr == 1 ? su.c_ly[ci] : pr == 4 ? su.c_muz[ci] : su.c_mu[ci]);
+            const int oi = pr == 0 ? 4 : pr == 1 ? 3 : pr == 2 ? 0 : pr == 3 ? 1 : 5;
+            const double sg = (pr < 2) ? ((r10 & 1) ? 1.0 : -1.0) : ((r10 & 1) ? -1.0 : 1.0);
+            const int row2 = 6 * a + 2, rowo = 6 * a + oi;
 #pragma unroll
             for (int j = 0; j < kQpN; j++) {
-                double w[6] = {0, 0, 0, 0, 0, 0};
-                if (j < t1) {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) w[c] = W1[(6 * a + c) * ldw1 + j];
-                } else if (j < nv) {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) w[c] = W2[(6 * a + c) * ldw2 + (j - t1)] * s2;
-                }
-                LV(R.g)[j] = (j < nv) ? -cone_row(r10, lx, ly, mu, muz, w) : 0.0;
+                double v = 0.0;
+                if (j < t1) v = c2 * W1[row2 * ldw1 + j] + sg * W1[rowo * ldw1 + j];
+                else if (j < nv) v = (c2 * W2[row2 * ldw2 + (j - t1)] + sg * W2[rowo * ldw2 + (j - t1)]) * s2;
+                LV(R.g)[j] = -v;
             }
-            double wf[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) wf[c] = fv[6 * a + c];
-            LV(R.hi) = cone_row(r10, lx, ly, mu, muz, wf);
+            LV(R.hi) = c2 * fv[row2] + sg * fv[rowo];
             LV(R.id_hi) = nlim + rr;
         }
     }

@@ -1,6 +1,6 @@
 // dwbc_qp_wave.h -- register-resident batched active-set QP, one wavefront per problem.
 //
-//   lexmin( 1/2|x[:t]|^2 , 1/2|x[t:]|^2 )  s.t.  lo_r <= g_r . x <= hi_r      (H = diag(I_t, 0_k), g = 0)
+//   lexmin( 1/2|x[:t]|^2 , 1/2|x[t:]|^2 )  s.t.  -lo_r <= g_r . x <= hi_r      (H = diag(I_t, 0_k), g = 0)
 //
 // Replaces CQuadraticProgram::SolveQPoases (reference src/qp_wrapper.cpp:192-380) for the QPs assembled by
 // CalcSingleTaskTorqueWithQP / CalcContactRedistribute (reference src/dwbc.cpp:988-1053, 1458-1517).
@@ -9,7 +9,9 @@
 // (+/-(row) <= tau_lim -/+ base), the 20 friction/CoP cone rows one-sided -- so 53 lanes hold the whole 86-row QP and
 // a slack evaluation is 12 FMAs per lane against the uniform iterate.  The Goldfarb-Idnani working-set state lives in
 // lanes 0..11: lane a holds row a of the pseudo-inverse N^+ of the active normals and lane i row i of N; every step is
-// a 12-term dot product per lane plus v_readlane broadcasts -- no LDS round trips, no triangular solves.
+// a 12-term dot product per lane plus v_readlane broadcasts -- no LDS round trips, no triangular solves.  Loops that
+// would otherwise be unrolled over the working-set size run over a uniform counter with lane masks, so the whole solver
+// stays a few KB of code (the kernel must fit the instruction cache).
 // See DESIGN.md "QP canon" for the definition of the returned point.
 #pragma once
 #include "dwbc_wave.h"
@@ -35,37 +37,13 @@ struct QpResult {
 
 #define DWBC_QP_INF 1.0e300
 
-// one Greville step: given uniform normal n[12], compute per-lane r (lane a<q) and uniform ru[], zu[]
-#define DWBC_QP_PROJECT(q_)                                                                 \
-    LANES {                                                                                  \
-        double s_ = 0.0;                                                                     \
-        _Pragma("unroll") for (int i = 0; i < kQpN; i++) s_ += LV(Np)[i] * n[i];             \
-        LV(r) = (lane < (q_)) ? s_ : 0.0;                                                    \
-    }                                                                                        \
-    _Pragma("unroll") for (int a = 0; a < kQpN; a++) ru[a] = BCAST(r, a);                    \
-    LANES {                                                                                  \
-        double s_ = pick12(n, lane);                                                         \
-        _Pragma("unroll") for (int a = 0; a < kQpN; a++) s_ -= LV(Nr)[a] * ru[a];            \
-        LV(z) = (lane < nv) ? s_ : 0.0;                                                      \
-    }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < kQpN; i++) zu[i] = BCAST(z, i);
-
-// append the current normal as column q_ of N and update N^+ (Greville)
-#define DWBC_QP_COMMIT(q_)                                                                   \
-    {                                                                                        \
-        double zn2_ = 0.0;                                                                   \
-        _Pragma("unroll") for (int i = 0; i < kQpN; i++) zn2_ += zu[i] * zu[i];              \
-        const double inv_ = 1.0 / zn2_;                                                      \
-        LANES {                                                                              \
-            const double ra_ = LV(r) * inv_;                                                 \
-            const bool newrow_ = (lane == (q_));                                             \
-            _Pragma("unroll") for (int i = 0; i < kQpN; i++) {                               \
-                const double upd_ = LV(Np)[i] - ra_ * zu[i];                                 \
-                LV(Np)[i] = newrow_ ? zu[i] * inv_ : ((lane < (q_)) ? upd_ : 0.0);           \
-            }                                                                                \
-            setidx12(LV(Nr), (q_), pick12(n, lane));                                         \
-        }                                                                                    \
-    }
+// uniform 12-array element with a uniform dynamic index
+DWBC_WDEV double upick12(const double *a, int idx) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < kQpN; i++) v = (i == idx) ? a[i] : v;
+    return v;
+}
 
 template <int DUMMY>
 DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS 12x12 */) {
@@ -81,9 +59,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     PL(int, actf);     // bit0: hi side in the working set, bit1: lo side
     PL(double, val);
     PL(int, key);
-    double xu[kQpN], n[kQpN], ru[kQpN], zu[kQpN];
+    double xu[kQpN], n[kQpN], ru[kQpN], zu[kQpN], gp[kQpN];
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) xu[i] = 0.0;
+    for (int i = 0; i < kQpN; i++) { xu[i] = 0.0; n[i] = 0.0; gp[i] = 0.0; }
     LANES {
         double s = 0.0;
 #pragma unroll
@@ -96,48 +74,77 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LV(akey) = 0;
         LV(actf) = 0;
     }
-    int q = 0, it = 0, status = 1;
+    // ---- Goldfarb-Idnani.  mode 0: look for the most violated row; 1: primal/dual step for row (p, side);
+    //      2: re-adding working-set member `ra` after a drop (N, N^+ are rebuilt column by column)
+    int q = 0, it = 0, status = 1, mode = 0, ra = 0, p = 0, side = 0, kmin = 0;
+    double up = 0.0, bp = 0.0, gnp = 1.0, worst = 0.0;
     for (;;) {
-        // most violated row not in the working set (normalised slack)
-        LANES {
-            double d = 0.0;
+        if (mode == 0) {
+            LANES {
+                double d = 0.0;
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) d += LV(R.g)[j] * xu[j];
-            double sh = (LV(actf) & 1) ? DWBC_QP_INF : (LV(R.hi) - d) * LV(rgn);
-            double sl = ((LV(actf) & 2) || LV(R.lo) >= DWBC_QP_INF) ? DWBC_QP_INF : (LV(R.lo) + d) * LV(rgn);
-            if (LV(R.hi) >= DWBC_QP_INF) sh = DWBC_QP_INF;
-            const bool lo_side = sl < sh;
-            LV(val) = lo_side ? sl : sh;
-            LV(key) = (lane << 1) | (lo_side ? 1 : 0);
+                for (int j = 0; j < kQpN; j++) d += LV(R.g)[j] * xu[j];
+                const double sh = ((LV(actf) & 1) || LV(R.hi) >= DWBC_QP_INF) ? DWBC_QP_INF : (LV(R.hi) - d) * LV(rgn);
+                const double sl = ((LV(actf) & 2) || LV(R.lo) >= DWBC_QP_INF) ? DWBC_QP_INF : (LV(R.lo) + d) * LV(rgn);
+                const bool lo_side = sl < sh;
+                LV(val) = lo_side ? sl : sh;
+                LV(key) = (lane << 1) | (lo_side ? 1 : 0);
+            }
+            WAVE_ARGMIN(val, key, worst, kmin);
+            if (!(worst < -kQpTol)) break;
+            p = kmin >> 1;
+            side = kmin & 1;
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
+            bp = side ? BCAST(R.lo, p) : BCAST(R.hi, p);
+            gnp = 1.0 / BCAST(rgn, p);
+            up = 0.0;
+            mode = 1;
         }
-        double worst;
-        int kmin;
-        WAVE_ARGMIN(val, key, worst, kmin);
-        if (!(worst < -kQpTol)) break;
-        const int p = kmin >> 1, side = kmin & 1;
-        double gp[kQpN];
+        // normal of the row being processed (GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g)
+        if (mode == 2) {
+            const int ka = BCASTI(akey, ra);
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
-        const double bp = side ? BCAST(R.lo, p) : BCAST(R.hi, p);
-        const double gnp = 1.0 / BCAST(rgn, p);
-        // GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g
+            for (int j = 0; j < kQpN; j++) {
+                const double gj = BCASTA(R.g, j, ka >> 1);
+                n[j] = (ka & 1) ? gj : -gj;
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) n[j] = side ? gp[j] : -gp[j];
-        double up = 0.0;
-        bool done_inner = false;
-        while (!done_inner) {
+            for (int j = 0; j < kQpN; j++) n[j] = side ? gp[j] : -gp[j];
+        }
+        const int qe = (mode == 2) ? ra : q;  // columns currently in N
+        // Greville projection: r = N^+ n (lane a), z = n - N r (lane i), both also broadcast
+        LANES {
+            double s_ = 0.0;
+#pragma unroll
+            for (int i = 0; i < kQpN; i++) s_ += LV(Np)[i] * n[i];
+            LV(r) = (lane < qe) ? s_ : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < kQpN; a++) ru[a] = BCAST(r, a);
+        LANES {
+            double s_ = pick12(n, lane);
+#pragma unroll
+            for (int a = 0; a < kQpN; a++) s_ -= LV(Nr)[a] * ru[a];
+            LV(z) = (lane < nv) ? s_ : 0.0;
+        }
+        double zn2 = 0.0, zg = 0.0;
+#pragma unroll
+        for (int i = 0; i < kQpN; i++) {
+            zu[i] = BCAST(z, i);
+            zn2 += zu[i] * zu[i];
+            zg += zu[i] * n[i];
+        }
+        bool commit = (mode == 2);
+        if (mode == 1) {
             if (++it > max_iter) { status = 0; break; }
-            DWBC_QP_PROJECT(q);
-            double zn2 = 0.0, zg = 0.0, rmax = 1.0;
-#pragma unroll
-            for (int i = 0; i < kQpN; i++) { zn2 += zu[i] * zu[i]; zg += zu[i] * n[i]; }
+            double rmax = 1.0;
 #pragma unroll
             for (int a = 0; a < kQpN; a++) rmax = fabs(ru[a]) > rmax ? fabs(ru[a]) : rmax;
-            // dual ratio test (per lane, then broadcast)
             LANES {
                 const bool ok = (lane < q) && (LV(r) > 1e-13 * rmax);
                 LV(val) = ok ? LV(u) / LV(r) : DWBC_QP_INF;
-                LV(key) = lane;
             }
             double t1 = DWBC_QP_INF;
             int l = -1;
@@ -162,15 +169,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             LANES { LV(u) -= tstep * LV(r); }
             up += tstep;
             if (full) {
-                DWBC_QP_COMMIT(q);
-                LANES {
-                    if (lane == q) { LV(u) = up; LV(akey) = kmin; }
-                    if (lane == p) LV(actf) |= (side ? 2 : 1);
-                }
-                q++;
-                done_inner = true;
+                commit = true;
             } else {
-                // drop working-set member l, compact, rebuild N and N^+ from the remaining members
+                // drop working-set member l, compact (u, akey), restart N / N^+ from empty
                 const int kl = BCASTI(akey, l);
                 PL(double, un);
                 PL(int, kn);
@@ -187,29 +188,40 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                     for (int j = 0; j < kQpN; j++) { LV(Np)[j] = 0.0; LV(Nr)[j] = 0.0; }
                 }
                 q--;
-                double nsave[kQpN];
-#pragma unroll
-                for (int j = 0; j < kQpN; j++) nsave[j] = n[j];
-                for (int a = 0; a < q; a++) {
-                    const int ka = BCASTI(akey, a);
-#pragma unroll
-                    for (int j = 0; j < kQpN; j++) {
-                        const double gj = BCASTA(R.g, j, ka >> 1);
-                        n[j] = (ka & 1) ? gj : -gj;
-                    }
-                    DWBC_QP_PROJECT(a);
-                    DWBC_QP_COMMIT(a);
-                }
-#pragma unroll
-                for (int j = 0; j < kQpN; j++) n[j] = nsave[j];
+                ra = 0;
+                mode = (q > 0) ? 2 : 1;
             }
         }
-        if (!status) break;
+        if (commit) {
+            // append n as column qe of N and update N^+ (Greville)
+            const double inv_ = 1.0 / zn2;
+            LANES {
+                const double ra_ = LV(r) * inv_;
+                const bool newrow_ = (lane == qe);
+#pragma unroll
+                for (int i = 0; i < kQpN; i++) {
+                    const double upd_ = LV(Np)[i] - ra_ * zu[i];
+                    LV(Np)[i] = newrow_ ? zu[i] * inv_ : ((lane < qe) ? upd_ : 0.0);
+                }
+                setidx12(LV(Nr), qe, pick12(n, lane));
+            }
+            if (mode == 2) {
+                ra++;
+                if (ra == q) mode = 1;
+            } else {
+                LANES {
+                    if (lane == q) { LV(u) = up; LV(akey) = kmin; }
+                    if (lane == p) LV(actf) |= (side ? 2 : 1);
+                }
+                q++;
+                mode = 0;
+            }
+        }
     }
     out.iters = it;
     out.nact = q;
     out.status = status;
-    out.viol = 0.0;
+    out.viol = worst >= DWBC_QP_INF ? 0.0 : worst;
 #pragma unroll
     for (int a = 0; a < kQpN; a++) {
         const int ka = BCASTI(akey, a);
@@ -217,11 +229,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         const int idh = BCASTI(R.id_hi, ow), idl = BCASTI(R.id_lo, ow);
         out.act[a] = a < q ? ((ka & 1) ? idl : idh) : -1;
     }
-    if (!status) {
 #pragma unroll
-        for (int i = 0; i < kQpN; i++) out.x[i] = 0.0;
-        return;
-    }
+    for (int i = 0; i < kQpN; i++) out.x[i] = 0.0;
+    if (!status || q == 0) return;  // x = 0: failure (caller zeroes the correction) or no active constraint
     // ---- final point from the working set alone: lexicographic least-norm point (contact block weighted) if it is
     //      feasible, else the Tikhonov point (DESIGN.md "QP canon").  Column a of the weighted normal matrix lives in
     //      lane a; column-pivoted Householder QR, rows = variables with the contact block first.
@@ -234,6 +244,8 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         PL(double, bb);
         PL(int, done);
         PL(double, w);
+        PL(double, beta);
+        PL(int, ord);
         LANES {
             const int ka = LV(akey);
             const int ow = (lane < q) ? (ka >> 1) : lane;
@@ -246,93 +258,92 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
             for (int i = 0; i < kQpN; i++) {
                 const int var = (i < k) ? (t + i) : (i - k);
-                const double gv = pick12(grow, var);
+                const double gv = upick12(grow, var);
                 LV(c)[i] = (lane < q && i < nv) ? sg * gv * ((i < k) ? wsc : 1.0) : 0.0;
             }
             LV(bb) = (lane < q) ? ((ka & 1) ? bl : bh) : 0.0;
             LV(done) = (lane < q) ? 0 : 1;
             LV(w) = 0.0;
+            LV(beta) = 0.0;
+            LV(ord) = 0;
         }
-        double beta[kQpN], yu[kQpN];
-        int order[kQpN];
+        double yu[kQpN];
 #pragma unroll
-        for (int s = 0; s < kQpN; s++) {
-            beta[s] = 0.0;
-            yu[s] = 0.0;
-            order[s] = 0;
-            if (s < q) {
-                LANES {
-                    double c2 = 0.0;
+        for (int i = 0; i < kQpN; i++) yu[i] = 0.0;
+        for (int s = 0; s < q; s++) {
+            LANES {
+                double c2 = 0.0;
 #pragma unroll
-                    for (int i = s; i < kQpN; i++) c2 += LV(c)[i] * LV(c)[i];
-                    LV(val) = LV(done) ? DWBC_QP_INF : -c2;
-                    LV(key) = lane;
-                }
-                double bn;
-                int jp;
-                WAVE_ARGMIN(val, key, bn, jp);
-                order[s] = jp;
-                double v[kQpN];
-                double nrm = 0.0;
+                for (int i = 0; i < kQpN; i++) c2 += (i >= s) ? LV(c)[i] * LV(c)[i] : 0.0;
+                LV(val) = LV(done) ? DWBC_QP_INF : -c2;
+                LV(key) = lane;
+            }
+            double bn;
+            int jp;
+            WAVE_ARGMIN(val, key, bn, jp);
+            double v[kQpN];
+            double nrm = 0.0, a0 = 0.0;
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) {
-                    v[i] = (i >= s) ? BCASTA(c, i, jp) : 0.0;
-                    nrm += v[i] * v[i];
-                }
-                nrm = sqrt(nrm);
-                const double a0 = v[s];
-                const double alpha = a0 > 0 ? -nrm : nrm;
-                v[s] = a0 - alpha;
-                double vn2 = 0.0;
+            for (int i = 0; i < kQpN; i++) {
+                const double ci = BCASTA(c, i, jp);
+                v[i] = (i >= s) ? ci : 0.0;
+                a0 = (i == s) ? ci : a0;
+                nrm += v[i] * v[i];
+            }
+            nrm = sqrt(nrm);
+            const double alpha = a0 > 0 ? -nrm : nrm;
+            double vn2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) vn2 += v[i] * v[i];
-                const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
-                beta[s] = bt;
-                LANES {
-                    if (lane < kQpN) V[s * kQpN + lane] = pick12(v, lane);
-                    if (lane == jp) {
-                        LV(done) = 1;
-                        LV(c)[s] = alpha;
-                    } else if (!LV(done)) {
-                        double d = 0.0;
+            for (int i = 0; i < kQpN; i++) {
+                v[i] = (i == s) ? a0 - alpha : v[i];
+                vn2 += v[i] * v[i];
+            }
+            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
+            LANES {
+                if (lane == s) { LV(beta) = bt; LV(ord) = jp; }
+                if (lane < kQpN) V[s * kQpN + lane] = pick12(v, lane);
+                if (lane == jp) {
+                    LV(done) = 1;
+                    setidx12(LV(c), s, alpha);
+                } else if (!LV(done)) {
+                    double d = 0.0;
 #pragma unroll
-                        for (int i = s; i < kQpN; i++) d += v[i] * LV(c)[i];
-                        d *= bt;
+                    for (int i = 0; i < kQpN; i++) d += v[i] * LV(c)[i];
+                    d *= bt;
 #pragma unroll
-                        for (int i = s; i < kQpN; i++) LV(c)[i] -= d * v[i];
-                    }
+                    for (int i = 0; i < kQpN; i++) LV(c)[i] -= d * v[i];
                 }
             }
         }
-        // R^T y = b in pivot order: column of R for pivot s is lane order[s]'s c[0..s]
+        // R^T y = b in pivot order: column of R for pivot s is lane ord[s]'s c[0..s]
+        for (int s = 0; s < q; s++) {
+            const int os = BCASTI(ord, s);
+            LANES {
+                double sacc = LV(bb), cs = 1.0;
 #pragma unroll
-        for (int s = 0; s < kQpN; s++) {
-            if (s < q) {
-                LANES {
-                    double sacc = LV(bb);
-#pragma unroll
-                    for (int cidx = 0; cidx < s; cidx++) sacc -= LV(c)[cidx] * yu[cidx];
-                    LV(val) = sacc / LV(c)[s];
+                for (int ci = 0; ci < kQpN; ci++) {
+                    sacc -= (ci < s) ? LV(c)[ci] * yu[ci] : 0.0;
+                    cs = (ci == s) ? LV(c)[ci] : cs;
                 }
-                yu[s] = BCAST(val, order[s]);
+                LV(val) = sacc / cs;
             }
+            const double ys = BCAST(val, os);
+#pragma unroll
+            for (int i = 0; i < kQpN; i++) yu[i] = (i == s) ? ys : yu[i];
         }
         LANES { LV(w) = (lane < q) ? pick12(yu, lane) : 0.0; }
         WSYNC();
-#pragma unroll
-        for (int s = kQpN - 1; s >= 0; s--) {
-            if (s < q) {
-                PL(double, vs);
-                LANES {
-                    LV(vs) = (lane < kQpN) ? V[s * kQpN + lane] : 0.0;
-                    LV(val) = LV(vs) * LV(w);
-                }
-                double d = 0.0;
-#pragma unroll
-                for (int i = 0; i < kQpN; i++) d += BCAST(val, i);
-                d *= beta[s];
-                LANES { LV(w) -= d * LV(vs); }
+        for (int s = q - 1; s >= 0; s--) {
+            PL(double, vs);
+            LANES {
+                LV(vs) = (lane < kQpN) ? V[s * kQpN + lane] : 0.0;
+                LV(val) = LV(vs) * LV(w);
             }
+            double d = 0.0;
+#pragma unroll
+            for (int i = 0; i < kQpN; i++) d += BCAST(val, i);
+            d *= BCAST(beta, s);
+            LANES { LV(w) -= d * LV(vs); }
         }
         WSYNC();
         // x[j]: task variable j sits at position k + j, contact variable j at position j
