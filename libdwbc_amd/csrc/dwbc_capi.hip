@@ -3,12 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/dwbc_batch.h"
-#include "dwbc_cycle.h"
+#include "dwbc_cycle2.h"
 #include "dwbc_model.h"
 #include "dwbc_setup.h"
 
@@ -25,6 +26,18 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const Ba
     Thr th{(int)threadIdx.x};
     int *iL = reinterpret_cast<int *>(lds + Lds<N, NB>::total);
     cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
+}
+
+// register-resident version (dwbc_cycle2.h): the default
+template <int N, int NB, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
+    static_assert(NT == 64, "one wavefront per instance");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB>::total);
+    cycle_instance_v2<N, NB, NT>(th, su, io, inst, lds, iL);
 }
 
 namespace {
@@ -47,7 +60,11 @@ struct KernelEntry {
     int lds_bytes;
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
+// index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 const KernelEntry kKernels[] = {
+    {39, 34, dwbc_cycle_kernel_v2<39, 34, kNT>, Lds2<39, 34>::total_bytes},
+};
+const KernelEntry kKernelsV1[] = {
     {39, 34, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes},
 };
 }  // namespace
@@ -146,8 +163,15 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return nullptr; }
     const KernelEntry *ke = nullptr;
-    for (const auto &k : kKernels)
-        if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
+    const char *kv = getenv("DWBC_KERNEL");
+    const bool use_v1 = kv && std::string(kv) == "v1";
+    if (use_v1) {
+        for (const auto &k : kKernelsV1)
+            if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
+    } else {
+        for (const auto &k : kKernels)
+            if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
+    }
     if (!ke) {
         g_err = "no kernel instantiated for a model with " + std::to_string(m->m.ndof) + " dof / " + std::to_string(m->m.nb) + " bodies";
         return nullptr;

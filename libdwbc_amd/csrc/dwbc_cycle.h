@@ -139,7 +139,7 @@ struct Thr {
 };
 
 template <int NT>
-DWBC_DEVN void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -149,7 +149,7 @@ DWBC_DEVN void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, cons
 }
 // C = A * B^T   (A m x k, B n x k)
 template <int NT>
-DWBC_DEVN void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -159,7 +159,7 @@ DWBC_DEVN void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, cons
 }
 // C = A^T * B   (A k x m, B k x n)
 template <int NT>
-DWBC_DEVN void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
@@ -168,7 +168,7 @@ DWBC_DEVN void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, cons
     }
 }
 template <int NT>
-DWBC_DEVN void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
+DWBC_DEV void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
     for (int i = th.tid; i < m; i += NT) {
         double s = 0.0;
         for (int j = 0; j < n; j++) s += A[i * lda + j] * x[j];
@@ -348,10 +348,8 @@ DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, con
 // (CalcPointJacobian6D + row swap: reference src/link.cpp:98-119, src/contact_constraint.cpp:59-61)
 // ----------------------------------------------------------------------------------------------
 template <int N, int NB, int NT>
-DWBC_DEVN void point_jacobian(Thr th, const double *L, const int *topo, int nb, int link, const double *P, double *J, int ld,
-                             int row0, int nrows, int rsel) {
-    using S = Lds<N, NB>;
-    const double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw;
+DWBC_DEVN void point_jacobian(Thr th, const double *Rw, const double *pw, const double *aw, const int *topo, int nb, int link,
+                             const double *P, double *J, int ld, int row0, int nrows, int rsel) {
     // rsel: 0 -> rows 0..5, 1 -> linear rows only (0..2), 2 -> angular rows only (3..5)
     for (int j = th.tid; j < N; j += NT) {
         double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
@@ -396,7 +394,7 @@ template <int N, int NB>
 DWBC_DEVN void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
                                 int t1, const double *P2, int ld2, int t2, double s2, const double *W1, int ldw1,
                                 const double *W2, int ldw2, const double *fv, const double *base, int tvars, int max_iter,
-                                QpResult &res) {
+                                QpResult &res, double *Vlds, double *xlds) {
     using S = Lds<N, NB>;
     constexpr int M = S::M;
     DWBC_LANE_DECL;
@@ -443,9 +441,9 @@ DWBC_DEVN void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone
             LV(R.id_hi) = nlim + rr;
         }
     }
-    qp_solve_wave<0>(R, nv, tvars, max_iter, res, L + S::qp_V);
+    qp_solve_wave<0>(R, nv, tvars, max_iter, res, Vlds);
     LANES {
-        if (lane < kQpN) L[S::qp_x + lane] = pick12(res.x, lane);
+        if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }
     DWBC_SYNC();
 }
@@ -644,7 +642,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     }
     DWBC_SYNC();
     for (int a = 0; a < nc; a++)
-        point_jacobian<N, NB, NT>(th, L, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, L + S::JC, N, 6 * a, 6, 0);
+        point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, L + S::JC, N, 6 * a, 6, 0);
     DWBC_SYNC();
     {
         double *Ai = L + S::bufA, *JC = L + S::JC, *Y = L + S::c_Y, *Lam = L + S::Lam, *JbT = L + S::JbT, *AiNc = L + S::bufN;
@@ -798,9 +796,9 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 const double *R = L + S::Rw + link * 9;
                 double P[3];
                 for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
-                if (mode <= TASK_LINK_6D_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 6, 0); row += 6; }
-                else if (mode <= TASK_LINK_POSITION_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 3, 1); row += 3; }
-                else { point_jacobian<N, NB, NT>(th, L, topo, nb, link, P, Jt, N, row, 3, 2); row += 3; }
+                if (mode <= TASK_LINK_6D_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, 6, 0); row += 6; }
+                else if (mode <= TASK_LINK_POSITION_CUSTOM_FRAME) { point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, 3, 1); row += 3; }
+                else { point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, 3, 2); row += 3; }
             }
             DWBC_SYNC();
             // --- CalculateJKT (wbd.cpp:207-213)
@@ -898,7 +896,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             DWBC_STAMP(7 + 3 * lv);  // level lv: QP inputs assembled
             QpResult qres;
             qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, kQpLd,
-                                     L + S::FNl, k, fv, base, t, su.qp_max_iter_task, qres);
+                                     L + S::FNl, k, fv, base, t, su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x);
             const int ok = qres.status;
             const double viol = qres.viol;
             if (diag && th.tid == 0) {
@@ -950,7 +948,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         DWBC_SYNC();
         QpResult qres;
         qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], L + S::NwJw, k, k, L + S::NwJw, k, 0, 1.0, L + S::FNl, k,
-                                 L + S::FNl, k, fv, base, k, su.qp_max_iter_contact, qres);
+                                 L + S::FNl, k, fv, base, k, su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
         const int ok = qres.status;
         const double viol = qres.viol;
         if (diag && th.tid == 0) {

@@ -1,0 +1,769 @@
+// dwbc_cycle2.h -- fused OSF/HQP control cycle, register-resident version (one wavefront = one robot instance).
+//
+// Same arithmetic as cycle_instance() in dwbc_cycle.h (kept as the readable NT-generic reference kernel), but the
+// three big symmetric matrices never live in LDS: lane j holds column j of A -> A^-1 -> A^-1 N_c (39 doubles) and later
+// column j of W^+ (33 doubles) in registers.  Every large product is then "own column . uniform operand": one FMA per
+// term, operands fetched with broadcast LDS reads (no bank conflicts, no index arithmetic), and the inverses are
+// symmetric sweeps whose pivot column is published through 39 doubles of LDS.  LDS holds only the thin matrices
+// (J_C, J̄_c^T, task blocks, QP inputs): ~47 KB per instance => 3 instances per CU (v1: 78 KB => 2).
+//
+// Reference functions restated: see the table at the top of dwbc_cycle.h.
+#pragma once
+#include "dwbc_cycle.h"
+
+namespace dwbc {
+
+template <int N, int NB>
+struct Lds2 {
+    static constexpr int M = N - 6;
+    static constexpr int C = 6 * kMaxActiveContacts;
+    static constexpr int K = C - 6;
+    static constexpr int T = kMaxTaskDof;
+    static constexpr int LV_ = kMaxLevels;
+    // ---- persistent
+    static constexpr int q = 0;                        // N+1
+    static constexpr int G = q + N + 1;
+    static constexpr int tg = G + N;
+    static constexpr int tt = tg + M;
+    static constexpr int tc = tt + M;
+    static constexpr int PC = tc + M;
+    static constexpr int Rc = PC + C;
+    static constexpr int Pc = Rc + kMaxActiveContacts * 9;
+    static constexpr int JbT = Pc + kMaxActiveContacts * 3;   // C x N
+    static constexpr int NwJw = JbT + C * N;                   // M x K
+    static constexpr int FNl = NwJw + M * K;                   // C x K
+    static constexpr int U = FNl + C * K;                      // levels x (M x T)
+    static constexpr int Xl = U + LV_ * M * T;                 // (levels-1) x (M x T)
+    static constexpr int T1r = Xl + (LV_ - 1) * M * T;         // (levels-1) x (T x M)
+    static constexpr int Rw = T1r + (LV_ - 1) * T * M;
+    static constexpr int pw = Rw + NB * 9;
+    static constexpr int aw = pw + NB * 3;
+    static constexpr int tmp = aw + NB * 3;
+    // ---- kinematics scratch
+    static constexpr int k_Rl = tmp;
+    static constexpr int k_Iw = k_Rl + NB * 9;
+    static constexpr int k_Ic = k_Iw + NB * 10;
+    static constexpr int k_S = k_Ic + NB * 10;
+    static constexpr int k_F = k_S + N * 6;
+    static constexpr int k_col = k_F + N * 6;                  // pivot column of the sweep
+    static constexpr int k_end = k_col + N;
+    // ---- contact / task-space scratch
+    static constexpr int c_JC = tmp;
+    static constexpr int c_Y = c_JC + C * N;
+    static constexpr int c_Lam = c_Y + C * N;
+    static constexpr int c_s1 = c_Lam + C * C;                 // C x 2C
+    static constexpr int c_s2 = c_s1 + C * 2 * C;              // C x C
+    static constexpr int c_Vb = c_s2 + C * C;                  // M x K
+    static constexpr int c_VG = c_Vb + M * K;                  // M x K
+    static constexpr int c_vec = c_VG + M * K;                 // N
+    static constexpr int c_col = c_vec + N;                    // N
+    static constexpr int c_Jt = c_col + N;                     // T x N
+    static constexpr int c_T1 = c_Jt + T * N;                  // T x N
+    static constexpr int c_Lt = c_T1 + T * N;                  // levels x T x T
+    static constexpr int c_Q = c_Lt + LV_ * T * T;             // T x M
+    static constexpr int c_QW = c_Q + T * M;                   // T x M
+    static constexpr int c_Pi = c_QW + T * M;                  // T x T
+    static constexpr int c_Z = c_Pi + T * T;                   // T x T
+    static constexpr int c_end = c_Z + T * T;
+    // ---- QP scratch (after the task-space phase)
+    static constexpr int t_base = tmp;
+    static constexpr int t_F = t_base + M;                     // C x kQpLd
+    static constexpr int t_fv = t_F + C * kQpLd;
+    static constexpr int t_s1 = t_fv + C;                      // C x (T+1)
+    static constexpr int qp_V = t_s1 + C * (T + 1);
+    static constexpr int qp_x = qp_V + kQpLd * kQpLd;
+    static constexpr int t_end = qp_x + kQpLd;
+    static constexpr int max2(int a, int b) { return a > b ? a : b; }
+    static constexpr int total = max2(max2(k_end, c_end), t_end);
+    static constexpr int total_bytes = total * 8 + 64;
+};
+
+// symmetric Gauss-Jordan sweep on a column-per-lane register matrix: on exit s / dg hold the inverse (see
+// spd_inverse_wave in dwbc_cycle.h for the derivation of the single-FMA update).  Returns 0 on a non-positive pivot.
+template <int NN>
+DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), double *colbuf) {
+    DWBC_LANE_DECL;
+    int ok = 1;
+    for (int k = 0; k < NN; k++) {
+        double d = BCAST(dg, k);
+        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        const double rp = 1.0 / d;
+        DWBC_SYNC();
+        LANES {
+            if (lane == k) {
+#pragma unroll
+                for (int i = 0; i < NN; i++) colbuf[i] = LV(s)[i];
+            }
+        }
+        DWBC_SYNC();
+        LANES {
+            if (lane == k) colbuf[k] = d - 1.0;
+        }
+        DWBC_SYNC();
+        LANES {
+            const double cj = colbuf[lane < NN ? lane : 0];
+            const double h = (lane == k) ? (1.0 - rp) : cj * rp;
+#pragma unroll
+            for (int i = 0; i < NN; i++) LV(s)[i] -= colbuf[i] * h;
+            LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
+        }
+    }
+    LANES {
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        LV(dg) = -LV(dg);
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
+template <int N, int NB, int NT>
+DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, double *L, int *iL) {
+    using S = Lds2<N, NB>;
+    constexpr int M = S::M, C = S::C, T = S::T;
+    DWBC_LANE_DECL;
+    (void)iL;
+    const int nb = su.nb;
+    const double *body = io.body;
+    const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
+    const double *qin = io.q + (size_t)inst * (N + 1);
+    const DumpLayout dl = DumpLayout::make(N);
+    double *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
+    int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
+    DWBC_STAMP_INIT();
+
+    PLA(double, s, N);  // column `lane` of A -> A^-1 -> A^-1 N_c
+    PL(double, dg);     // its diagonal element
+
+    // ================= stage 0: kinematics and CRBA (src/dwbc.cpp:279-371) =================
+    for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
+    for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = 0.0;
+    DWBC_SYNC();
+    {
+        double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw, *Rl = L + S::k_Rl;
+        const double *q = L + S::q;
+        for (int i = th.tid; i < nb; i += NT) {
+            const double *bd = body + i * kBodyStride;
+            if (i == 0) {
+                const double x = q[3], y = q[4], z = q[5], w = q[N];
+                double *R = Rw;
+                R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+                R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
+                R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
+                pw[0] = q[0]; pw[1] = q[1]; pw[2] = q[2];
+            } else {
+                const double ax = bd[BF_AXIS], ay = bd[BF_AXIS + 1], az = bd[BF_AXIS + 2];
+                double sn, cs;
+                sincos(q[6 + i - 1], &sn, &cs);
+                const double c1 = 1.0 - cs;
+                double Rj[9];
+                Rj[0] = cs + ax * ax * c1; Rj[1] = ax * ay * c1 - az * sn; Rj[2] = ax * az * c1 + ay * sn;
+                Rj[3] = ay * ax * c1 + az * sn; Rj[4] = cs + ay * ay * c1; Rj[5] = ay * az * c1 - ax * sn;
+                Rj[6] = az * ax * c1 - ay * sn; Rj[7] = az * ay * c1 + ax * sn; Rj[8] = cs + az * az * c1;
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < 3; b++)
+                        Rl[i * 9 + a * 3 + b] = bd[BF_RT + a * 3] * Rj[b] + bd[BF_RT + a * 3 + 1] * Rj[3 + b] + bd[BF_RT + a * 3 + 2] * Rj[6 + b];
+            }
+        }
+        for (int d = 1; d <= su.maxdepth; d++) {
+            DWBC_SYNC();
+            for (int i = th.tid; i < nb; i += NT) {
+                if (topo[nb + i] != d) continue;
+                const int par = topo[i];
+                const double *bd = body + i * kBodyStride;
+                const double *Rp = Rw + par * 9;
+                for (int a = 0; a < 3; a++) {
+                    for (int b = 0; b < 3; b++)
+                        Rw[i * 9 + a * 3 + b] = Rp[a * 3] * Rl[i * 9 + b] + Rp[a * 3 + 1] * Rl[i * 9 + 3 + b] + Rp[a * 3 + 2] * Rl[i * 9 + 6 + b];
+                    pw[i * 3 + a] = pw[par * 3 + a] + Rp[a * 3] * bd[BF_PT] + Rp[a * 3 + 1] * bd[BF_PT + 1] + Rp[a * 3 + 2] * bd[BF_PT + 2];
+                }
+            }
+        }
+        DWBC_SYNC();
+        double *Iw = L + S::k_Iw;
+        for (int i = th.tid; i < nb; i += NT) {
+            const double *bd = body + i * kBodyStride;
+            const double *R = Rw + i * 9;
+            for (int a = 0; a < 3; a++) aw[i * 3 + a] = R[a * 3] * bd[BF_AXIS] + R[a * 3 + 1] * bd[BF_AXIS + 1] + R[a * 3 + 2] * bd[BF_AXIS + 2];
+            const double m = bd[BF_MASS];
+            double r[3];
+            for (int a = 0; a < 3; a++)
+                r[a] = pw[i * 3 + a] + R[a * 3] * bd[BF_COM] + R[a * 3 + 1] * bd[BF_COM + 1] + R[a * 3 + 2] * bd[BF_COM + 2] - pw[a];
+            const double Ic[9] = {bd[BF_ICOM], bd[BF_ICOM + 1], bd[BF_ICOM + 2], bd[BF_ICOM + 1], bd[BF_ICOM + 3],
+                                  bd[BF_ICOM + 4], bd[BF_ICOM + 2], bd[BF_ICOM + 4], bd[BF_ICOM + 5]};
+            double Tm[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Tm[a * 3 + b] = R[a * 3] * Ic[b] + R[a * 3 + 1] * Ic[3 + b] + R[a * 3 + 2] * Ic[6 + b];
+            const double rr2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            double *o = Iw + i * 10;
+            o[0] = m;
+            o[1] = m * r[0]; o[2] = m * r[1]; o[3] = m * r[2];
+            int c = 4;
+            for (int a = 0; a < 3; a++)
+                for (int b = a; b < 3; b++) {
+                    double v = Tm[a * 3] * R[b * 3] + Tm[a * 3 + 1] * R[b * 3 + 1] + Tm[a * 3 + 2] * R[b * 3 + 2];
+                    v += m * ((a == b ? rr2 : 0.0) - r[a] * r[b]);
+                    o[c++] = v;
+                }
+        }
+        DWBC_SYNC();
+        double *Icm = L + S::k_Ic;
+        for (int idx = th.tid; idx < nb * 10; idx += NT) {
+            const int i = idx / 10, c = idx - i * 10;
+            const int e = i + topo[2 * nb + i];
+            double acc = 0.0;
+            for (int j = i; j < e; j++) acc += Iw[j * 10 + c];
+            Icm[idx] = acc;
+        }
+        double *Sm = L + S::k_S, *Fm = L + S::k_F;
+        for (int j = th.tid; j < N; j += NT) {
+            double w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+            if (j < 3) {
+                v[j] = 1.0;
+            } else if (j < 6) {
+                for (int a = 0; a < 3; a++) w[a] = Rw[a * 3 + (j - 3)];
+            } else {
+                const int b = j - 5;
+                for (int a = 0; a < 3; a++) w[a] = aw[b * 3 + a];
+                const double d0 = pw[b * 3] - pw[0], d1 = pw[b * 3 + 1] - pw[1], d2 = pw[b * 3 + 2] - pw[2];
+                v[0] = d1 * w[2] - d2 * w[1];
+                v[1] = d2 * w[0] - d0 * w[2];
+                v[2] = d0 * w[1] - d1 * w[0];
+            }
+            for (int a = 0; a < 3; a++) { Sm[j * 6 + a] = w[a]; Sm[j * 6 + 3 + a] = v[a]; }
+        }
+        DWBC_SYNC();
+        for (int j = th.tid; j < N; j += NT) {
+            const int b = j < 6 ? 0 : j - 5;
+            const double *I = Icm + b * 10;
+            const double *sv = Sm + j * 6;
+            const double m = I[0], h0 = I[1], h1 = I[2], h2 = I[3];
+            const double w0 = sv[0], w1 = sv[1], w2 = sv[2], v0 = sv[3], v1 = sv[4], v2 = sv[5];
+            Fm[j * 6 + 0] = I[4] * w0 + I[5] * w1 + I[6] * w2 + (h1 * v2 - h2 * v1);
+            Fm[j * 6 + 1] = I[5] * w0 + I[7] * w1 + I[8] * w2 + (h2 * v0 - h0 * v2);
+            Fm[j * 6 + 2] = I[6] * w0 + I[8] * w1 + I[9] * w2 + (h0 * v1 - h1 * v0);
+            Fm[j * 6 + 3] = m * v0 + (w1 * h2 - w2 * h1);
+            Fm[j * 6 + 4] = m * v1 + (w2 * h0 - w0 * h2);
+            Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
+        }
+        DWBC_SYNC();
+        // A[k][j] straight into lane j's registers: S_k . F_j when dof k is on the path root..j, S_j . F_k when j is on
+        // the path root..k, else 0 (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm).  DFS pre-order makes "on the path"
+        // a range test on body indices.
+        LANES {
+            const int j = lane < N ? lane : 0;
+            const int bj = j < 6 ? 0 : j - 5;
+            const int ej = bj + topo[2 * nb + bj];
+            double fj[6], sj[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { fj[a] = Fm[j * 6 + a]; sj[a] = Sm[j * 6 + a]; }
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const int bk = k < 6 ? 0 : k - 5;
+                const int ek = bk + topo[2 * nb + bk];
+                const bool k_on_j = (k < 6) ? true : (j >= 6 && bk <= bj && bj < ek);
+                const bool j_on_k = (j < 6) ? true : (k >= 6 && bj <= bk && bk < ej);
+                double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) { d1 += Sm[k * 6 + a] * fj[a]; d2 += sj[a] * Fm[k * 6 + a]; }
+                LV(s)[k] = (lane < N) ? (k_on_j ? d1 : (j_on_k ? d2 : 0.0)) : 0.0;
+            }
+            double dd = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) dd += sj[a] * fj[a];
+            LV(dg) = (lane < N) ? dd : 1.0;
+            if (lane < N) L[S::G + lane] = kGrav * LV(s)[2];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
+        }
+        if (dump) {
+            LANES {
+                if (lane < N) {
+#pragma unroll
+                    for (int i = 0; i < N; i++) dump[dl.A + i * N + lane] = LV(s)[i];
+                }
+            }
+            for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
+            for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
+        }
+    }
+    DWBC_STAMP(0);  // kinematics + CRBA done
+    int st_contact = 1;
+    // A_inv (dwbc.cpp:307)
+    if (!sweep_inverse_regs<N>(s, dg, L + S::k_col)) st_contact = 0;
+    if (dump) {
+        LANES {
+            if (lane < N) {
+#pragma unroll
+                for (int i = 0; i < N; i++) dump[dl.A_inv + i * N + lane] = LV(s)[i];
+            }
+        }
+        for (int j = th.tid; j < N; j += NT) dump[dl.G + j] = L[S::G + j];
+    }
+    DWBC_STAMP(1);  // A_inv done
+
+    // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
+    const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
+    int act_c[kMaxActiveContacts] = {0, 0};
+    int nc = 0;
+    for (int i = 0; i < su.n_contacts; i++)
+        if (fl[i] && nc < kMaxActiveContacts) act_c[nc++] = i;
+    const int cd = 6 * nc, k = cd > 6 ? cd - 6 : 0;
+    DWBC_SYNC();
+    for (int a = 0; a < nc; a++) {
+        const int ci = act_c[a], link = su.c_link[ci];
+        const double *R = L + S::Rw + link * 9;
+        for (int r = th.tid; r < 12; r += NT) {
+            if (r < 9) L[S::Rc + a * 9 + r] = R[r];
+            else {
+                const int x = r - 9;
+                L[S::Pc + a * 3 + x] = L[S::pw + link * 3 + x] + R[x * 3] * su.c_point[ci][0] + R[x * 3 + 1] * su.c_point[ci][1] + R[x * 3 + 2] * su.c_point[ci][2];
+            }
+        }
+    }
+    DWBC_SYNC();
+    double *JC = L + S::c_JC, *Y = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
+    for (int idx = th.tid; idx < C * N; idx += NT) { JC[idx] = 0.0; Y[idx] = 0.0; JbT[idx] = 0.0; }
+    DWBC_SYNC();
+    for (int a = 0; a < nc; a++)
+        point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JC, N, 6 * a, 6, 0);
+    DWBC_SYNC();
+    // Y = J_C A^-1: column `lane` of Y is J_C times lane's column of A^-1 (outer loop rolled: code size)
+    for (int p = 0; p < cd; p++) {
+        LANES {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += JC[p * N + i] * LV(s)[i];
+            if (lane < N) Y[p * N + lane] = acc;
+        }
+    }
+    DWBC_SYNC();
+    mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);  // J A^-1 J^T
+    if (cd > 0) {
+        const double cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);  // Lambda_c (wbd.cpp:115)
+        if (!(cond > 1e-14)) st_contact = 0;
+    }
+    DWBC_SYNC();
+    {
+        PLA(double, yc, C);
+        LANES {
+#pragma unroll
+            for (int p2 = 0; p2 < C; p2++) LV(yc)[p2] = Y[p2 * N + (lane < N ? lane : 0)];
+        }
+        for (int p = 0; p < cd; p++) {  // J̄^T = Lambda J A^-1 (wbd.cpp:116)
+            LANES {
+                double acc = 0.0;
+#pragma unroll
+                for (int p2 = 0; p2 < C; p2++) acc += ((p2 < cd) ? Lam[p * cd + p2] : 0.0) * LV(yc)[p2];
+                if (lane < N) JbT[p * N + lane] = acc;
+            }
+        }
+    }
+    DWBC_SYNC();
+    // A^-1 N_c = A^-1 - Y^T J̄^T   (wbd.cpp:117-118 without materialising N_c), one rank-1 update per contact row
+    for (int p = 0; p < cd; p++) {
+        LANES {
+            const double jbp = JbT[p * N + (lane < N ? lane : 0)];
+            LV(dg) -= Y[p * N + (lane < N ? lane : 0)] * jbp;
+#pragma unroll
+            for (int i = 0; i < N; i++) LV(s)[i] -= Y[p * N + i] * jbp;
+        }
+    }
+    DWBC_SYNC();
+    if (dump) {
+        for (int idx = th.tid; idx < cd * N; idx += NT) { dump[dl.J_C + idx] = JC[idx]; dump[dl.J_C_INV_T + idx] = JbT[idx]; }
+        for (int idx = th.tid; idx < cd * cd; idx += NT) dump[dl.Lambda_c + idx] = Lam[idx];
+        LANES {
+            if (lane < N) {
+#pragma unroll
+                for (int i = 0; i < N; i++) dump[dl.A_inv_N_C + i * N + lane] = LV(s)[i];
+            }
+        }
+    }
+    // gravity pre-vector (A^-1 N_c G) and P_C = J̄^T G  (wbd.cpp:186-192)
+    LANES {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += LV(s)[i] * L[S::G + i];
+        if (lane < N) L[S::c_vec + lane] = acc;
+    }
+    mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
+    DWBC_STAMP(2);  // J_C, Lambda_c, J̄, A^-1 N_c done
+    // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
+    for (int lv = 0; lv < su.n_levels; lv++) {
+        const int t = su.t_dof[lv];
+        double *Jt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < T * N; idx += NT) Jt[idx] = 0.0;
+        DWBC_SYNC();
+        int row = 0;
+        for (int li = 0; li < su.t_nlinks[lv]; li++) {
+            const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
+            double pl[3] = {0, 0, 0};
+            if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
+                for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
+            else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
+                for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
+            const double *R = L + S::Rw + link * 9;
+            double P[3];
+            for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+            const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
+            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, rsel == 0 ? 6 : 3, rsel);
+            row += rsel == 0 ? 6 : 3;
+        }
+        DWBC_SYNC();
+        for (int r = 0; r < T; r++) {
+            LANES {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
+                if (lane < N) T1[r * N + lane] = acc;
+                if (lv < kMaxLevels - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
+            }
+        }
+        DWBC_SYNC();
+        mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
+        gj_inverse<NT>(th, L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
+        if (lv == kMaxLevels - 1)
+            for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
+        if (dump) {
+            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jt[idx];
+            for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
+        }
+    }
+    DWBC_SYNC();
+    // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
+    double *Vb = L + S::c_Vb, *VG = L + S::c_VG;
+    if (k > 0) {
+        const double *Pc = L + S::Pc;
+        for (int idx = th.tid; idx < M * k; idx += NT) {
+            const int r = idx / k, a = idx - r * k;
+            const int ci = 1 + a / 6, e = a % 6;
+            double f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+            if (e < 3) f2[e] = 1.0; else m2[e - 3] = 1.0;
+            const double d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
+            const double m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
+            const double m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
+            const double m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
+            const double *J0 = JC, *J1 = JC + 6 * ci * N;
+            const int col = 6 + r;
+            double acc = -f2[0] * J0[0 * N + col] - f2[1] * J0[1 * N + col] - f2[2] * J0[2 * N + col];
+            acc += m1x * J0[3 * N + col] + m1y * J0[4 * N + col] + m1z * J0[5 * N + col];
+            acc += f2[0] * J1[0 * N + col] + f2[1] * J1[1 * N + col] + f2[2] * J1[2 * N + col];
+            acc += m2[0] * J1[3 * N + col] + m2[1] * J1[4 * N + col] + m2[2] * J1[5 * N + col];
+            Vb[idx] = acc;
+        }
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < k * k; idx += NT) {
+            const int i = idx / k, j = idx - i * k;
+            double acc = 0.0;
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
+            L[S::c_s2 + idx] = acc;
+        }
+        const double cond = gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+        if (!(cond > 1e-13)) st_contact = 0;
+        mm_nn<NT>(th, L + S::NwJw, k, Vb, k, L + S::c_s2, k, M, k, k);  // NwJw = Vb (J̄[0:k,6:] Vb)^-1 (wbd.cpp:128)
+        DWBC_SYNC();
+        mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
+        gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+        mm_nn<NT>(th, VG, k, Vb, k, L + S::c_s2, k, M, k, k);             // P = VG Vb^T
+        DWBC_SYNC();
+        // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
+        for (int idx = th.tid; idx < cd * k; idx += NT) {
+            const int i = idx / k, j = idx - i * k;
+            double acc = 0.0;
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
+            L[S::c_s1 + idx] = acc;
+        }
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < cd * k; idx += NT) {
+            const int i = idx / k, j = idx - i * k;
+            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+            const double *R = L + S::Rc + a * 9;
+            const double *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
+            L[S::FNl + idx] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[k] + R[2 * 3 + x] * src[2 * k];
+        }
+        DWBC_SYNC();
+    }
+    DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
+    // ---- W^+ = (W + alpha P)^-1 - P / alpha, column c of W held by lane c (moved down from lane 6 + c)
+    PLA(double, w, M);
+    PL(double, dw);
+    LANES {
+        const int src = lane < M ? lane + 6 : lane;
+#pragma unroll
+        for (int i = 0; i < M; i++) LV(w)[i] = SHFLA(s, 6 + i, src);
+        LV(dw) = SHFL(dg, src);
+    }
+    LANES {
+        if (lane < M) L[S::c_col + lane] = LV(dw);
+    }
+    DWBC_SYNC();
+    double alpha = 0.0;
+    for (int i = 0; i < M; i++) alpha += L[S::c_col + i];
+    alpha /= M;
+    const double ialpha = alpha != 0.0 ? 1.0 / alpha : 0.0;
+    DWBC_SYNC();
+    PLA(double, vbr, 6);  // row `lane` of Vb
+    LANES {
+#pragma unroll
+        for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * k + a] : 0.0;
+        if (k > 0) {
+            double dp = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double pij = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
+                LV(w)[i] += alpha * pij;
+                dp = (i == lane) ? pij : dp;
+            }
+            LV(dw) += alpha * dp;
+        }
+        if (lane >= M) {
+#pragma unroll
+            for (int i = 0; i < M; i++) LV(w)[i] = 0.0;
+            LV(dw) = 1.0;
+        }
+    }
+    if (!sweep_inverse_regs<M>(w, dw, L + S::c_col)) st_contact = 0;
+    LANES {
+        if (k > 0) {
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double pij = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
+                LV(w)[i] -= ialpha * pij;
+            }
+        }
+        // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
+        if (lane < M) L[S::tg + lane] = acc;
+    }
+    if (dump) {
+        LANES {
+            if (lane < M) {
+#pragma unroll
+                for (int i = 0; i < M; i++) dump[dl.W_inv + i * M + lane] = LV(w)[i];
+            }
+        }
+        for (int idx = th.tid; idx < M * k; idx += NT) dump[dl.NwJw + idx] = L[S::NwJw + idx];
+        for (int i = th.tid; i < cd; i += NT) dump[dl.P_C + i] = L[S::PC + i];
+    }
+    DWBC_SYNC();
+    DWBC_STAMP(4);  // W^+ and gravity compensation done
+
+    // ================= stage 3a: task-space dynamics for every level (wbd.cpp:207-261) =================
+    for (int lv = 0; lv < su.n_levels; lv++) {
+        const int t = su.t_dof[lv];
+        const double *Lt = L + S::c_Lt + lv * T * T;
+        const double *T1rl = (lv < kMaxLevels - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
+        double *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < T * M; idx += NT) {  // Q = Lambda T1[:,6:]  (zero padded to T rows)
+            const int i = idx / M, j = idx - i * M;
+            double acc = 0.0;
+            if (i < t)
+                for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * M + j];
+            Q[idx] = acc;
+        }
+        DWBC_SYNC();
+        for (int r = 0; r < T; r++) {
+            LANES {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) acc += Q[r * M + i] * LV(w)[i];
+                if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
+            }
+        }
+        DWBC_SYNC();
+        mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
+        const double cond = gj_inverse<NT>(th, L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
+        DWBC_SYNC();
+        // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
+        double *Ul = L + S::U + lv * M * T;
+        double *Xs = (lv < kMaxLevels - 1) ? L + S::Xl + lv * M * T : Ul;
+        LANES {
+            double jk[T], qw[T];
+#pragma unroll
+            for (int r = 0; r < T; r++) qw[r] = QW[r * M + (lane < M ? lane : 0)];
+#pragma unroll
+            for (int r2 = 0; r2 < T; r2++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : 0.0;
+                jk[r2] = acc;
+                if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
+            }
+#pragma unroll
+            for (int r3 = 0; r3 < T; r3++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : 0.0;
+                if (lane < M) {
+                    Xs[lane * T + r3] = acc;
+                    Ul[lane * T + r3] = acc;
+                }
+            }
+        }
+        DWBC_SYNC();
+        for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
+            const int tp = su.t_dof[pl];
+            const double *Xp = L + S::Xl + pl * M * T, *Yp = L + S::T1r + pl * T * M;
+            for (int idx = th.tid; idx < tp * t; idx += NT) {
+                const int i = idx / t, j = idx - i * t;
+                double acc = 0.0;
+                for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
+                L[S::c_Z + idx] = acc;
+            }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < M * t; idx += NT) {
+                const int i = idx / t, j = idx - i * t;
+                double acc = Ul[i * T + j];
+                for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * L[S::c_Z + p * t + j];
+                Ul[i * T + j] = acc;
+            }
+            DWBC_SYNC();
+        }
+        (void)cond;
+        DWBC_STAMP(6 + 3 * lv);
+    }
+    DWBC_SYNC();
+
+    // ================= stage 3b: the QP cascade (dwbc.cpp:818-873, 941-1127) =================
+    const int nlim = su.has_tau_lim ? 2 * M : 0;
+    const int ncone = 10 * nc;
+    int st_task = 1, fail_level = -1;
+    const double *fs_in = io.fstar + (size_t)inst * su.fstar_total;
+    double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
+    for (int lv = 0; lv < su.n_levels && st_task; lv++) {
+        const int t = su.t_dof[lv];
+        const double *Ul = L + S::U + lv * M * T;
+        const double *fs = fs_in + su.fstar_off[lv];
+        DWBC_SYNC();
+        for (int i = th.tid; i < M; i += NT) {
+            double acc = L[S::tg + i] + L[S::tt + i];
+            for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j];
+            base[i] = acc;
+        }
+        DWBC_SYNC();
+        // contact wrench map in the contact frame: F = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
+        for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
+            const int i = idx / (t + 1), j = idx - i * (t + 1);
+            double acc = 0.0;
+            if (j < t) { for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Ul[c * T + j]; }
+            else { for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c]; acc -= L[S::PC + i]; }
+            L[S::t_s1 + i * (T + 1) + j] = acc;
+        }
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
+            const int i = idx / (t + 1), j = idx - i * (t + 1);
+            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+            const double *R = L + S::Rc + a * 9;
+            const double *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
+            const double v = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[T + 1] + R[2 * 3 + x] * src[2 * (T + 1)];
+            if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
+        }
+        DWBC_SYNC();
+        DWBC_STAMP(7 + 3 * lv);
+        QpResult qres;
+        qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], Ul, T, t, L + S::NwJw, k, k, kQpScaleGI, F, kQpLd,
+                                 L + S::FNl, k, fv, base, t, su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x);
+        if (diag && th.tid == 0) {
+            diag[DG_QP_ITER + lv] = qres.iters;
+            diag[DG_QP_NACT + lv] = qres.nact;
+            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = qres.act[a];
+        }
+        if (dump && th.tid == 0) dump[dl.qp_viol + lv] = qres.viol;
+        DWBC_STAMP(8 + 3 * lv);
+        if (!qres.status) { st_task = 0; fail_level = lv; break; }  // cascade aborts (dwbc.cpp:836,1119)
+        const double *x = L + S::qp_x;
+        for (int i = th.tid; i < M; i += NT) {
+            double acc = 0.0;
+            for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
+            L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
+            double c = 0.0;
+            for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
+            L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+        }
+        if (dump) {
+            for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + lv * T + j] = x[j];
+            for (int j = th.tid; j < k; j += NT) dump[dl.contact_qp + lv * (C - 6) + j] = x[t + j];
+        }
+        DWBC_SYNC();
+    }
+    DWBC_STAMP(14);
+
+    // ================= stage 4: contact redistribution (dwbc.cpp:1372-1568) =================
+    int st_redis = 1;
+    if (k > 0) {
+        DWBC_SYNC();
+        for (int i = th.tid; i < M; i += NT) base[i] = L[S::tg + i] + L[S::tt + i] + L[S::tc + i];
+        DWBC_SYNC();
+        for (int i = th.tid; i < cd; i += NT) {
+            double acc = -L[S::PC + i];
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c];
+            L[S::t_s1 + i] = acc;
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < cd; i += NT) {
+            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+            const double *R = L + S::Rc + a * 9;
+            const double *src = L + S::t_s1 + 6 * a + 3 * h;
+            fv[i] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[1] + R[2 * 3 + x] * src[2];
+        }
+        DWBC_SYNC();
+        QpResult qres;
+        qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], L + S::NwJw, k, k, L + S::NwJw, k, 0, 1.0, L + S::FNl, k,
+                                 L + S::FNl, k, fv, base, k, su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
+        if (diag && th.tid == 0) {
+            diag[DG_QP_ITER + kMaxLevels] = qres.iters;
+            diag[DG_QP_NACT + kMaxLevels] = qres.nact;
+            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = qres.act[a];
+        }
+        if (dump && th.tid == 0) dump[dl.qp_viol + kMaxLevels] = qres.viol;
+        const double *x = L + S::qp_x;
+        if (qres.status) {
+            for (int i = th.tid; i < M; i += NT) {
+                double c = 0.0;
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
+                L[S::tc + i] += c;
+            }
+            if (dump)
+                for (int j = th.tid; j < k; j += NT) dump[dl.cf_redis + j] = x[j];
+        } else {
+            st_redis = 0;
+            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;
+        }
+    } else {
+        for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1562-1567
+    }
+    DWBC_SYNC();
+    DWBC_STAMP(15);
+
+    // ================= outputs =================
+    double *tau = io.tau + (size_t)inst * 3 * M;
+    for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
+    double *wr = io.wrench + (size_t)inst * 12;
+    for (int i = th.tid; i < 12; i += NT) {
+        double acc = 0.0;
+        if (i < cd) {
+            acc = -L[S::PC + i];
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);
+        }
+        wr[i] = acc;  // getContactForce(tau_total), wbd.cpp:268-271
+    }
+    if (th.tid == 0) {
+        io.status[inst] = (st_contact && st_task && st_redis) ? 1 : 0;
+        if (diag) {
+            diag[DG_ST_CONTACT] = st_contact;
+            diag[DG_ST_TASK] = st_task;
+            diag[DG_ST_REDIS] = st_redis;
+            diag[DG_FAIL_LEVEL] = fail_level;
+        }
+    }
+}
+
+}  // namespace dwbc

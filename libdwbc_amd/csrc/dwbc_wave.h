@@ -21,6 +21,8 @@
 #define SHFLA(x, j, src) ((x)[(src)][(j)])         /* inside LANES: x[j] of lane `src` (src may differ per lane) */
 #define SHFL(x, src) ((x)[(src)])
 #define DWBC_WDEV inline
+#define PLA_REF(type, name, n) type (&name)[64][n]
+#define PL_REF(type, name) type (&name)[64]
 #else
 #define PL(type, x) type x
 #define PLA(type, x, n) type x[n]
@@ -33,6 +35,8 @@
 #define SHFLA(x, j, src) __shfl((x)[(j)], (src), 64)
 #define SHFL(x, src) __shfl((x), (src), 64)
 #define DWBC_WDEV __device__ __forceinline__
+#define PLA_REF(type, name, n) type (&name)[n]
+#define PL_REF(type, name) type &name
 #endif
 
 namespace dwbc {

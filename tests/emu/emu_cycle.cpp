@@ -4,11 +4,12 @@
 // product's URDF reader and Setup builder, which this also covers.  It is never linked into libdwbc_hip.so and
 // is not a fallback: the product has no CPU path.
 #define DWBC_HOST_EMU 1
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "../../libdwbc_amd/csrc/dwbc_cycle.h"
+#include "../../libdwbc_amd/csrc/dwbc_cycle2.h"
 #include "../../libdwbc_amd/csrc/dwbc_model.h"
 #include "../../libdwbc_amd/csrc/dwbc_setup.h"
 
@@ -69,6 +70,8 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
 int emu_diag_count() { return DG_COUNT; }
 int emu_lds_bytes() { return Lds<39, 34>::total_bytes; }
 
+int emu_lds_bytes_v2() { return Lds2<39, 34>::total_bytes; }
+
 int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
             int *status, int *diag, double *dump) {
     if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
@@ -84,11 +87,14 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.dump = dump;
     io.body = c->body.data();
     io.topo = c->topo.data();
-    std::vector<double> lds(Lds<39, 34>::total + 64);
+    std::vector<double> lds(Lds<39, 34>::total + Lds2<39, 34>::total + 64);
     std::vector<int> ilds(64);
+    const char *kv = getenv("DWBC_KERNEL");
+    const bool v1 = kv && std::string(kv) == "v1";
     for (int b = 0; b < B; b++) {
         Thr th{0};
-        cycle_instance<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        if (v1) cycle_instance<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        else cycle_instance_v2<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
     }
     return 1;
 }
