@@ -46,7 +46,8 @@ struct Lds2 {
     static constexpr int k_S = k_Ic + NB * 10;
     static constexpr int k_F = k_S + N * 6;
     static constexpr int k_col = k_F + N * 6;                  // pivot column of the sweep
-    static constexpr int k_end = k_col + N;
+    static constexpr int k_A = k_col + N;                      // A staged once (N x N) before it moves to registers
+    static constexpr int k_end = k_A + N * N;
     // ---- contact / task-space scratch
     static constexpr int c_JC = tmp;
     static constexpr int c_Y = c_JC + C * N;
@@ -247,32 +248,34 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
         }
         DWBC_SYNC();
-        // A[k][j] straight into lane j's registers: S_k . F_j when dof k is on the path root..j, S_j . F_k when j is on
-        // the path root..k, else 0 (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm).  DFS pre-order makes "on the path"
-        // a range test on body indices.
-        LANES {
-            const int j = lane < N ? lane : 0;
-            const int bj = j < 6 ? 0 : j - 5;
-            const int ej = bj + topo[2 * nb + bj];
-            double fj[6], sj[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) { fj[a] = Fm[j * 6 + a]; sj[a] = Sm[j * 6 + a]; }
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const int bk = k < 6 ? 0 : k - 5;
-                const int ek = bk + topo[2 * nb + bk];
-                const bool k_on_j = (k < 6) ? true : (j >= 6 && bk <= bj && bj < ek);
-                const bool j_on_k = (j < 6) ? true : (k >= 6 && bj <= bk && bk < ej);
-                double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; a++) { d1 += Sm[k * 6 + a] * fj[a]; d2 += sj[a] * Fm[k * 6 + a]; }
-                LV(s)[k] = (lane < N) ? (k_on_j ? d1 : (j_on_k ? d2 : 0.0)) : 0.0;
+        // A[j][k] = S_k . F_j for k on the path from j to the root (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm), staged
+        // through LDS once and then loaded column-per-lane into registers
+        double *A = L + S::k_A;
+        for (int idx = th.tid; idx < N * N; idx += NT) A[idx] = 0.0;
+        DWBC_SYNC();
+        for (int j = th.tid; j < N; j += NT) {
+            const double *f = Fm + j * 6;
+            int kk = j;
+            for (;;) {
+                const double *sv = Sm + kk * 6;
+                const double v = sv[0] * f[0] + sv[1] * f[1] + sv[2] * f[2] + sv[3] * f[3] + sv[4] * f[4] + sv[5] * f[5];
+                A[j * N + kk] = v;
+                A[kk * N + j] = v;
+                if (kk == 0) break;
+                if (kk < 6) kk = kk - 1;
+                else {
+                    const int pb = topo[kk - 5];
+                    kk = pb == 0 ? 5 : pb + 5;
+                }
             }
-            double dd = 0.0;
+        }
+        DWBC_SYNC();
+        LANES {
+            const int col = lane < N ? lane : 0;
 #pragma unroll
-            for (int a = 0; a < 6; a++) dd += sj[a] * fj[a];
-            LV(dg) = (lane < N) ? dd : 1.0;
-            if (lane < N) L[S::G + lane] = kGrav * LV(s)[2];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
+            for (int i = 0; i < N; i++) LV(s)[i] = (lane < N) ? A[i * N + col] : 0.0;
+            LV(dg) = (lane < N) ? A[col * N + col] : 1.0;
+            if (lane < N) L[S::G + lane] = kGrav * A[2 * N + col];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
         }
         if (dump) {
             LANES {
