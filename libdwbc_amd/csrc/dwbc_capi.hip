@@ -29,15 +29,15 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const Ba
 }
 
 // register-resident version (dwbc_cycle2.h): the default
-template <int N, int NB, int NT>
+template <int N, int NB, int NLV, int NT>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
     static_assert(NT == 64, "one wavefront per instance");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
     if (inst >= io.B) return;
     Thr th{(int)threadIdx.x};
-    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB>::total);
-    cycle_instance_v2<N, NB, NT>(th, su, io, inst, lds, iL);
+    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);
+    cycle_instance_v2<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
 }
 
 namespace {
@@ -55,17 +55,20 @@ int fail(const std::string &s) {
 constexpr int kNT = 64;
 
 struct KernelEntry {
-    int n, nb;
+    int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
     void (*fn)(const Setup, const BatchIO);
     int lds_bytes;
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
 // index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 const KernelEntry kKernels[] = {
-    {39, 34, dwbc_cycle_kernel_v2<39, 34, kNT>, Lds2<39, 34>::total_bytes},
+    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes},
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes},
+    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes},
+    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes},
 };
 const KernelEntry kKernelsV1[] = {
-    {39, 34, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes},
+    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes},
 };
 }  // namespace
 
@@ -163,15 +166,8 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return nullptr; }
     const KernelEntry *ke = nullptr;
-    const char *kv = getenv("DWBC_KERNEL");
-    const bool use_v1 = kv && std::string(kv) == "v1";
-    if (use_v1) {
-        for (const auto &k : kKernelsV1)
-            if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
-    } else {
-        for (const auto &k : kKernels)
-            if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
-    }
+    for (const auto &k : kKernels)
+        if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
     if (!ke) {
         g_err = "no kernel instantiated for a model with " + std::to_string(m->m.ndof) + " dof / " + std::to_string(m->m.nb) + " bodies";
         return nullptr;
@@ -345,7 +341,25 @@ static int upload_inputs(dwbc_batch *b) {
     return 1;
 }
 
+static const KernelEntry *pick_kernel(const dwbc_batch *b) {
+    const char *kv = getenv("DWBC_KERNEL");
+    if (kv && std::string(kv) == "v1") {
+        for (const auto &k : kKernelsV1)
+            if (k.n == b->n && k.nb == b->su.nb) return &k;
+        return nullptr;
+    }
+    for (const auto &k : kKernels)
+        if (k.n == b->n && k.nb == b->su.nb && k.nlv == b->su.n_levels) return &k;
+    return nullptr;
+}
+
 static int launch(dwbc_batch *b) {
+    const KernelEntry *ke = pick_kernel(b);
+    if (!ke) return fail("no kernel for this model / number of task levels");
+    if (ke != b->kern) {
+        b->kern = ke;
+        b->attr_set = false;
+    }
     BatchIO io{};
     io.B = b->B;
     io.q = b->d_q;
@@ -494,8 +508,9 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
+    const KernelEntry *ke = pick_kernel(b);
     if (threads) *threads = kNT;
-    if (lds) *lds = b->kern->lds_bytes;
+    if (lds) *lds = ke ? ke->lds_bytes : 0;
     return 1;
 }
 

@@ -13,13 +13,13 @@
 
 namespace dwbc {
 
-template <int N, int NB>
+template <int N, int NB, int NLV>
 struct Lds2 {
     static constexpr int M = N - 6;
     static constexpr int C = 6 * kMaxActiveContacts;
     static constexpr int K = C - 6;
     static constexpr int T = kMaxTaskDof;
-    static constexpr int LV_ = kMaxLevels;
+    static constexpr int max2(int a, int b) { return a > b ? a : b; }
     // ---- persistent
     static constexpr int q = 0;                        // N+1
     static constexpr int G = q + N + 1;
@@ -29,43 +29,50 @@ struct Lds2 {
     static constexpr int PC = tc + M;
     static constexpr int Rc = PC + C;
     static constexpr int Pc = Rc + kMaxActiveContacts * 9;
-    static constexpr int JbT = Pc + kMaxActiveContacts * 3;   // C x N
+    static constexpr int JbT = Pc + kMaxActiveContacts * 3;   // C x N            (written from stage 1 on)
     static constexpr int NwJw = JbT + C * N;                   // M x K
     static constexpr int FNl = NwJw + M * K;                   // C x K
     static constexpr int U = FNl + C * K;                      // levels x (M x T)
-    static constexpr int Xl = U + LV_ * M * T;                 // (levels-1) x (M x T)
-    static constexpr int T1r = Xl + (LV_ - 1) * M * T;         // (levels-1) x (T x M)
-    static constexpr int Rw = T1r + (LV_ - 1) * T * M;
+    static constexpr int Xl = U + NLV * M * T;                 // (levels-1) x (M x T)
+    static constexpr int T1r = Xl + (NLV - 1) * M * T;         // (levels-1) x (T x M)
+    static constexpr int Rw = T1r + (NLV - 1) * T * M;
     static constexpr int pw = Rw + NB * 9;
     static constexpr int aw = pw + NB * 3;
     static constexpr int tmp = aw + NB * 3;
-    // ---- kinematics scratch
+    // ---- kinematics scratch.  The staged N x N mass matrix overlays JbT..T1r (not written before stage 1) if it fits.
     static constexpr int k_Rl = tmp;
     static constexpr int k_Iw = k_Rl + NB * 9;
     static constexpr int k_Ic = k_Iw + NB * 10;
     static constexpr int k_S = k_Ic + NB * 10;
     static constexpr int k_F = k_S + N * 6;
     static constexpr int k_col = k_F + N * 6;                  // pivot column of the sweep
-    static constexpr int k_A = k_col + N;                      // A staged once (N x N) before it moves to registers
-    static constexpr int k_end = k_A + N * N;
+    static constexpr bool a_overlay = (Rw - JbT) >= N * N;
+    static constexpr int k_A = a_overlay ? JbT : k_col + N;
+    static constexpr int k_end = a_overlay ? k_col + N : k_col + N + N * N;
     // ---- contact / task-space scratch
-    static constexpr int c_JC = tmp;
+    static constexpr int c_Vb = tmp;                           // M x K
+    static constexpr int c_VG = c_Vb + M * K;                  // M x K
+    static constexpr int c_vec = c_VG + M * K;                 // N
+    static constexpr int c_col = c_vec + N;                    // N
+    static constexpr int c_Lt = c_col + N;                     // levels x T x T
+    static constexpr int c_ov = c_Lt + NLV * T * T;            // two overlaid groups:
+    //   (1) contact algebra
+    static constexpr int c_JC = c_ov;
     static constexpr int c_Y = c_JC + C * N;
     static constexpr int c_Lam = c_Y + C * N;
     static constexpr int c_s1 = c_Lam + C * C;                 // C x 2C
     static constexpr int c_s2 = c_s1 + C * 2 * C;              // C x C
-    static constexpr int c_Vb = c_s2 + C * C;                  // M x K
-    static constexpr int c_VG = c_Vb + M * K;                  // M x K
-    static constexpr int c_vec = c_VG + M * K;                 // N
-    static constexpr int c_col = c_vec + N;                    // N
-    static constexpr int c_Jt = c_col + N;                     // T x N
+    static constexpr int c_end1 = c_s2 + C * C;
+    //   (2) task-space dynamics (after NwJw / projector are done; keeps c_s1/c_s2 for its small inverses)
+    static constexpr int c_Jt = c_ov;                          // T x N
     static constexpr int c_T1 = c_Jt + T * N;                  // T x N
-    static constexpr int c_Lt = c_T1 + T * N;                  // levels x T x T
-    static constexpr int c_Q = c_Lt + LV_ * T * T;             // T x M
+    static constexpr int c_Q = c_T1 + T * N;                   // T x M
     static constexpr int c_QW = c_Q + T * M;                   // T x M
     static constexpr int c_Pi = c_QW + T * M;                  // T x T
     static constexpr int c_Z = c_Pi + T * T;                   // T x T
-    static constexpr int c_end = c_Z + T * T;
+    static constexpr int c_end2 = c_Z + T * T;
+    static_assert(c_end2 <= c_s1, "task-space scratch must not reach the small-inverse scratch it shares");
+    static constexpr int c_end = max2(c_end1, c_end2);
     // ---- QP scratch (after the task-space phase)
     static constexpr int t_base = tmp;
     static constexpr int t_F = t_base + M;                     // C x kQpLd
@@ -74,7 +81,6 @@ struct Lds2 {
     static constexpr int qp_V = t_s1 + C * (T + 1);
     static constexpr int qp_x = qp_V + kQpLd * kQpLd;
     static constexpr int t_end = qp_x + kQpLd;
-    static constexpr int max2(int a, int b) { return a > b ? a : b; }
     static constexpr int total = max2(max2(k_end, c_end), t_end);
     static constexpr int total_bytes = total * 8 + 64;
 };
@@ -88,17 +94,15 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
     for (int k = 0; k < NN; k++) {
         double d = BCAST(dg, k);
         if (!(d > 0.0)) { ok = 0; d = 1.0; }
-        const double rp = 1.0 / d;
-        DWBC_SYNC();
+        const double rp = fast_rcp(d);
+        // lane k publishes its column; its own slot k gets c_k - 1 (LDS ops of one wave execute in order, so the second
+        // store to colbuf[k] needs no barrier; reads of the previous step were consumed by the FMAs that precede these stores)
         LANES {
             if (lane == k) {
 #pragma unroll
                 for (int i = 0; i < NN; i++) colbuf[i] = LV(s)[i];
+                colbuf[k] = d - 1.0;
             }
-        }
-        DWBC_SYNC();
-        LANES {
-            if (lane == k) colbuf[k] = d - 1.0;
         }
         DWBC_SYNC();
         LANES {
@@ -108,6 +112,7 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
             for (int i = 0; i < NN; i++) LV(s)[i] -= colbuf[i] * h;
             LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
         }
+        DWBC_SYNC();
     }
     LANES {
 #pragma unroll
@@ -118,9 +123,9 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
     return ok;
 }
 
-template <int N, int NB, int NT>
+template <int N, int NB, int NLV, int NT>
 DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, double *L, int *iL) {
-    using S = Lds2<N, NB>;
+    using S = Lds2<N, NB, NLV>;
     constexpr int M = S::M, C = S::C, T = S::T;
     DWBC_LANE_DECL;
     (void)iL;
@@ -324,7 +329,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     DWBC_SYNC();
     double *JC = L + S::c_JC, *Y = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
-    for (int idx = th.tid; idx < C * N; idx += NT) { JC[idx] = 0.0; Y[idx] = 0.0; JbT[idx] = 0.0; }
+    for (int idx = th.tid; idx < C * N; idx += NT) { JC[idx] = 0.0; Y[idx] = 0.0; JbT[idx] = 0.0; }  // (the staged A is dead)
     DWBC_SYNC();
     for (int a = 0; a < nc; a++)
         point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JC, N, 6 * a, 6, 0);
@@ -390,50 +395,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
     DWBC_STAMP(2);  // J_C, Lambda_c, J̄, A^-1 N_c done
-    // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
-    for (int lv = 0; lv < su.n_levels; lv++) {
-        const int t = su.t_dof[lv];
-        double *Jt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;
-        DWBC_SYNC();
-        for (int idx = th.tid; idx < T * N; idx += NT) Jt[idx] = 0.0;
-        DWBC_SYNC();
-        int row = 0;
-        for (int li = 0; li < su.t_nlinks[lv]; li++) {
-            const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
-            double pl[3] = {0, 0, 0};
-            if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
-                for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
-            else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
-                for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
-            const double *R = L + S::Rw + link * 9;
-            double P[3];
-            for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
-            const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
-            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, rsel == 0 ? 6 : 3, rsel);
-            row += rsel == 0 ? 6 : 3;
-        }
-        DWBC_SYNC();
-        for (int r = 0; r < T; r++) {
-            LANES {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
-                if (lane < N) T1[r * N + lane] = acc;
-                if (lv < kMaxLevels - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
-            }
-        }
-        DWBC_SYNC();
-        mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
-        gj_inverse<NT>(th, L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
-        // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
-        if (lv == kMaxLevels - 1)
-            for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
-        if (dump) {
-            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jt[idx];
-            for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
-        }
-    }
-    DWBC_SYNC();
     // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
     double *Vb = L + S::c_Vb, *VG = L + S::c_VG;
     if (k > 0) {
@@ -487,6 +448,50 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
     }
+    // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
+    for (int lv = 0; lv < su.n_levels; lv++) {
+        const int t = su.t_dof[lv];
+        double *Jt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;
+        DWBC_SYNC();
+        for (int idx = th.tid; idx < T * N; idx += NT) Jt[idx] = 0.0;
+        DWBC_SYNC();
+        int row = 0;
+        for (int li = 0; li < su.t_nlinks[lv]; li++) {
+            const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
+            double pl[3] = {0, 0, 0};
+            if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
+                for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
+            else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
+                for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
+            const double *R = L + S::Rw + link * 9;
+            double P[3];
+            for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+            const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
+            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, rsel == 0 ? 6 : 3, rsel);
+            row += rsel == 0 ? 6 : 3;
+        }
+        DWBC_SYNC();
+        for (int r = 0; r < T; r++) {
+            LANES {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
+                if (lane < N) T1[r * N + lane] = acc;
+                if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
+            }
+        }
+        DWBC_SYNC();
+        mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
+        gj_inverse<NT>(th, L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
+        if (lv == NLV - 1)
+            for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
+        if (dump) {
+            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jt[idx];
+            for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
+        }
+    }
+    DWBC_SYNC();
     DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
     // ---- W^+ = (W + alpha P)^-1 - P / alpha, column c of W held by lane c (moved down from lane 6 + c)
     PLA(double, w, M);
@@ -562,7 +567,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
         const double *Lt = L + S::c_Lt + lv * T * T;
-        const double *T1rl = (lv < kMaxLevels - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
+        const double *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
         double *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
         DWBC_SYNC();
         for (int idx = th.tid; idx < T * M; idx += NT) {  // Q = Lambda T1[:,6:]  (zero padded to T rows)
@@ -587,7 +592,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
         double *Ul = L + S::U + lv * M * T;
-        double *Xs = (lv < kMaxLevels - 1) ? L + S::Xl + lv * M * T : Ul;
+        double *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;
         LANES {
             double jk[T], qw[T];
 #pragma unroll

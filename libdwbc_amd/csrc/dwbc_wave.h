@@ -54,6 +54,20 @@ __device__ __forceinline__ int readlane_i32(int v, int srclane) { return __built
 #define BCASTI(x, src) ((x)[(src)])
 #endif
 
+// reciprocal without the IEEE division fix-up sequence: hardware estimate + two Newton steps (rel. error ~1e-16 for
+// normal, non-huge arguments -- the pivots and norms it is used on)
+DWBC_WDEV double fast_rcp(double d) {
+#ifdef DWBC_HOST_EMU
+    return 1.0 / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+#endif
+}
+
 // element `lane` of a uniform 12-array (avoids dynamic register indexing on the device)
 DWBC_WDEV double pick12(const double *a, int lane) {
     double v = 0.0;
