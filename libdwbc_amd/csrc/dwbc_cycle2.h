@@ -123,6 +123,33 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
     return ok;
 }
 
+// inverse of a small SPD matrix (n <= 12) held in LDS: column per lane in registers + the sweep above.  Used for
+// Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
+// where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
+// pivot is not positive (rank deficient block => status 0, where the reference would return a pseudo-inverse).
+DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, int ldo, double *colbuf) {
+    DWBC_LANE_DECL;
+    PLA(double, s, 12);
+    PL(double, dg);
+    DWBC_SYNC();
+    LANES {
+        const int col = lane < n ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] : 0.0;
+        LV(dg) = (lane < n) ? Ain[col * lda + col] : 1.0;
+    }
+    const int ok = sweep_inverse_regs<12>(s, dg, colbuf);
+    LANES {
+        if (lane < n) {
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                if (i < n) Out[i * ldo + lane] = LV(s)[i];
+        }
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
 template <int N, int NB, int NLV, int NT>
 DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, double *L, int *iL) {
     using S = Lds2<N, NB, NLV>;
@@ -346,8 +373,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_SYNC();
     mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);  // J A^-1 J^T
     if (cd > 0) {
-        const double cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);  // Lambda_c (wbd.cpp:115)
-        if (!(cond > 1e-14)) st_contact = 0;
+        if (!spd_inverse_small(L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
     }
     DWBC_SYNC();
     {
@@ -428,7 +454,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         mm_nn<NT>(th, L + S::NwJw, k, Vb, k, L + S::c_s2, k, M, k, k);  // NwJw = Vb (J̄[0:k,6:] Vb)^-1 (wbd.cpp:128)
         DWBC_SYNC();
         mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
-        gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+        spd_inverse_small(L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
         mm_nn<NT>(th, VG, k, Vb, k, L + S::c_s2, k, M, k, k);             // P = VG Vb^T
         DWBC_SYNC();
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
@@ -482,7 +508,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
-        gj_inverse<NT>(th, L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
         if (lv == NLV - 1)
             for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
@@ -564,6 +590,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(4);  // W^+ and gravity compensation done
 
     // ================= stage 3a: task-space dynamics for every level (wbd.cpp:207-261) =================
+    int rankbad = 0;
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
         const double *Lt = L + S::c_Lt + lv * T * T;
@@ -588,7 +615,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
-        const double cond = gj_inverse<NT>(th, L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
+        const int cond = spd_inverse_small(L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
         DWBC_SYNC();
         // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
         double *Ul = L + S::U + lv * M * T;
@@ -635,7 +662,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
         }
-        (void)cond;
+        if (!cond) rankbad |= (1 << lv);
         DWBC_STAMP(6 + 3 * lv);
     }
     DWBC_SYNC();
@@ -650,6 +677,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const int t = su.t_dof[lv];
         const double *Ul = L + S::U + lv * M * T;
         const double *fs = fs_in + su.fstar_off[lv];
+        if (rankbad & (1 << lv)) { st_task = 0; fail_level = lv; break; }  // rank-deficient task block (reference: pseudo-inverse)
         DWBC_SYNC();
         for (int i = th.tid; i < M; i += NT) {
             double acc = L[S::tg + i] + L[S::tt + i];
