@@ -123,35 +123,6 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
     return ok;
 }
 
-// The same sweep for the big matrices, with no LDS at all: the pivot column is broadcast with v_readlane (lane select
-// = the uniform pivot index) and each lane's own element of the pivot ROW -- S[k][lane] = S[lane][k] by symmetry -- is
-// a uniform dynamic index into its own column (s_set_gpr_idx on the device).
-template <int NN>
-DWBC_WDEV int sweep_inverse_col(PCOL_REF(s, NN), PL_REF(double, dg)) {
-    DWBC_LANE_DECL;
-    int ok = 1;
-    for (int k = 0; k < NN; k++) {
-        double d = BCAST(dg, k);
-        if (!(d > 0.0)) { ok = 0; d = 1.0; }
-        const double rp = fast_rcp(d);
-        COL_SNAPSHOT(s, k, NN);
-        LANES {
-            const double cj = CDYN(s, k);
-            const double h = (lane == k) ? (1.0 - rp) : cj * rp;
-#pragma unroll
-            for (int i = 0; i < NN; i++) CS(s, i, CG(s, i) - CSNAP(s, i, k) * h);
-            CADD_DYN(s, k, h);  // the "- delta_ik" of the multiplier: S[k][j] -= (c_k - 1) h
-            LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
-        }
-    }
-    LANES {
-#pragma unroll
-        for (int i = 0; i < NN; i++) CS(s, i, (i == lane) ? -LV(dg) : -CG(s, i));
-        LV(dg) = -LV(dg);
-    }
-    return ok;
-}
-
 // inverse of a small SPD matrix (n <= 12) held in LDS: column per lane in registers + the sweep above.  Used for
 // Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
 // where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
@@ -194,7 +165,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
     DWBC_STAMP_INIT();
 
-    PCOL(s, N);         // column `lane` of A -> A^-1 -> A^-1 N_c
+    PLA(double, s, N);  // column `lane` of A -> A^-1 -> A^-1 N_c
     PL(double, dg);     // its diagonal element
 
     // ================= stage 0: kinematics and CRBA (src/dwbc.cpp:279-371) =================
@@ -334,7 +305,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         LANES {
             const int col = lane < N ? lane : 0;
 #pragma unroll
-            for (int i = 0; i < N; i++) CS(s, i, (lane < N) ? A[i * N + col] : 0.0);
+            for (int i = 0; i < N; i++) LV(s)[i] = (lane < N) ? A[i * N + col] : 0.0;
             LV(dg) = (lane < N) ? A[col * N + col] : 1.0;
             if (lane < N) L[S::G + lane] = kGrav * A[2 * N + col];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
         }
@@ -342,7 +313,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 if (lane < N) {
 #pragma unroll
-                    for (int i = 0; i < N; i++) dump[dl.A + i * N + lane] = CG(s, i);
+                    for (int i = 0; i < N; i++) dump[dl.A + i * N + lane] = LV(s)[i];
                 }
             }
             for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
@@ -352,12 +323,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(0);  // kinematics + CRBA done
     int st_contact = 1;
     // A_inv (dwbc.cpp:307)
-    if (!sweep_inverse_col<N>(s, dg)) st_contact = 0;
+    if (!sweep_inverse_regs<N>(s, dg, L + S::k_col)) st_contact = 0;
     if (dump) {
         LANES {
             if (lane < N) {
 #pragma unroll
-                for (int i = 0; i < N; i++) dump[dl.A_inv + i * N + lane] = CG(s, i);
+                for (int i = 0; i < N; i++) dump[dl.A_inv + i * N + lane] = LV(s)[i];
             }
         }
         for (int j = th.tid; j < N; j += NT) dump[dl.G + j] = L[S::G + j];
@@ -395,7 +366,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         LANES {
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; i++) acc += JC[p * N + i] * CG(s, i);
+            for (int i = 0; i < N; i++) acc += JC[p * N + i] * LV(s)[i];
             if (lane < N) Y[p * N + lane] = acc;
         }
     }
@@ -427,7 +398,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const double jbp = JbT[p * N + (lane < N ? lane : 0)];
             LV(dg) -= Y[p * N + (lane < N ? lane : 0)] * jbp;
 #pragma unroll
-            for (int i = 0; i < N; i++) CS(s, i, CG(s, i) - Y[p * N + i] * jbp);
+            for (int i = 0; i < N; i++) LV(s)[i] -= Y[p * N + i] * jbp;
         }
     }
     DWBC_SYNC();
@@ -437,7 +408,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         LANES {
             if (lane < N) {
 #pragma unroll
-                for (int i = 0; i < N; i++) dump[dl.A_inv_N_C + i * N + lane] = CG(s, i);
+                for (int i = 0; i < N; i++) dump[dl.A_inv_N_C + i * N + lane] = LV(s)[i];
             }
         }
     }
@@ -445,7 +416,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     LANES {
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; i++) acc += CG(s, i) * L[S::G + i];
+        for (int i = 0; i < N; i++) acc += LV(s)[i] * L[S::G + i];
         if (lane < N) L[S::c_vec + lane] = acc;
     }
     mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
@@ -530,7 +501,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * CG(s, i);
+                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
                 if (lane < N) T1[r * N + lane] = acc;
                 if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
             }
@@ -549,12 +520,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_SYNC();
     DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
     // ---- W^+ = (W + alpha P)^-1 - P / alpha, column c of W held by lane c (moved down from lane 6 + c)
-    PCOL(w, M);
+    PLA(double, w, M);
     PL(double, dw);
     LANES {
         const int src = lane < M ? lane + 6 : lane;
 #pragma unroll
-        for (int i = 0; i < M; i++) CS(w, i, CSHFL(s, 6 + i, src));
+        for (int i = 0; i < M; i++) LV(w)[i] = SHFLA(s, 6 + i, src);
         LV(dw) = SHFL(dg, src);
     }
     LANES {
@@ -577,18 +548,18 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 double pij = 0.0;
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
-                CS(w, i, CG(w, i) + alpha * pij);
+                LV(w)[i] += alpha * pij;
                 dp = (i == lane) ? pij : dp;
             }
             LV(dw) += alpha * dp;
         }
         if (lane >= M) {
 #pragma unroll
-            for (int i = 0; i < M; i++) CS(w, i, 0.0);
+            for (int i = 0; i < M; i++) LV(w)[i] = 0.0;
             LV(dw) = 1.0;
         }
     }
-    if (!sweep_inverse_col<M>(w, dw)) st_contact = 0;
+    if (!sweep_inverse_regs<M>(w, dw, L + S::c_col)) st_contact = 0;
     LANES {
         if (k > 0) {
 #pragma unroll
@@ -596,20 +567,20 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 double pij = 0.0;
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
-                CS(w, i, CG(w, i) - ialpha * pij);
+                LV(w)[i] -= ialpha * pij;
             }
         }
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; i++) acc += CG(w, i) * L[S::c_vec + 6 + i];
+        for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
         if (lane < M) L[S::tg + lane] = acc;
     }
     if (dump) {
         LANES {
             if (lane < M) {
 #pragma unroll
-                for (int i = 0; i < M; i++) dump[dl.W_inv + i * M + lane] = CG(w, i);
+                for (int i = 0; i < M; i++) dump[dl.W_inv + i * M + lane] = LV(w)[i];
             }
         }
         for (int idx = th.tid; idx < M * k; idx += NT) dump[dl.NwJw + idx] = L[S::NwJw + idx];
@@ -638,7 +609,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < M; i++) acc += Q[r * M + i] * CG(w, i);
+                for (int i = 0; i < M; i++) acc += Q[r * M + i] * LV(w)[i];
                 if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
             }
         }

@@ -21,16 +21,6 @@
 #define SHFLA(x, j, src) ((x)[(src)][(j)])         /* inside LANES: x[j] of lane `src` (src may differ per lane) */
 #define SHFL(x, src) ((x)[(src)])
 #define DWBC_WDEV inline
-/* 48-slot per-lane column (the big symmetric matrices): plain array in the emulation */
-#define PCOL(x, NN) double x[64][48]
-#define PCOL_REF(x, NN) double (&x)[64][48]
-#define CG(x, i) ((x)[lane][(i)])
-#define CS(x, i, v) ((x)[lane][(i)] = (v))
-#define CDYN(x, k) ((x)[lane][(k)])
-#define CADD_DYN(x, k, v) ((x)[lane][(k)] += (v))
-#define CSHFL(x, i, src) ((x)[(src)][(i)])
-#define COL_SNAPSHOT(x, k, n) double snap_[48]; for (int i_ = 0; i_ < (n); i_++) snap_[i_] = (x)[(k)][i_]
-#define CSNAP(x, i, k) (snap_[(i)])
 #define PLA_REF(type, name, n) type (&name)[64][n]
 #define PL_REF(type, name) type (&name)[64]
 #else
@@ -45,17 +35,6 @@
 #define SHFLA(x, j, src) __shfl((x)[(j)], (src), 64)
 #define SHFL(x, src) __shfl((x), (src), 64)
 #define DWBC_WDEV __device__ __forceinline__
-/* per-lane column of 33..48 doubles in LLVM vectors (16 + 16 + tail): static indices fold to plain registers after unrolling, a
- * uniform dynamic index becomes s_set_gpr_idx (no scratch, no select chain) */
-#define PCOL(x, NN) dwbc::ColT<NN> x
-#define PCOL_REF(x, NN) dwbc::ColT<NN> &x
-#define CG(x, i) dwbc::colget((x), (i))
-#define CS(x, i, v) dwbc::colset((x), (i), (v))
-#define CDYN(x, k) dwbc::coldyn((x), (k))
-#define CADD_DYN(x, k, v) dwbc::coladd_dyn((x), (k), (v))
-#define CSHFL(x, i, src) __shfl(dwbc::colget((x), (i)), (src), 64)
-#define COL_SNAPSHOT(x, k, n) ((void)0)
-#define CSNAP(x, i, k) dwbc::readlane_f64(dwbc::colget((x), (i)), (k))
 #define PLA_REF(type, name, n) type (&name)[n]
 #define PL_REF(type, name) type &name
 #endif
@@ -63,43 +42,6 @@
 namespace dwbc {
 
 #ifndef DWBC_HOST_EMU
-typedef double d16 __attribute__((ext_vector_type(16)));
-typedef double d8 __attribute__((ext_vector_type(8)));
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-template <int R> struct TailVec { typedef d16 type; static constexpr int mask = 15; };
-template <> struct TailVec<8> { typedef d8 type; static constexpr int mask = 7; };
-template <> struct TailVec<4> { typedef d4 type; static constexpr int mask = 3; };
-template <> struct TailVec<2> { typedef d2 type; static constexpr int mask = 1; };
-constexpr int tail_slots(int r) { return r <= 2 ? 2 : (r <= 4 ? 4 : (r <= 8 ? 8 : 16)); }
-// NN (33..48) doubles per lane: two 16-double vectors + a tail vector of 2/4/8/16
-template <int NN>
-struct ColT {
-    typedef TailVec<tail_slots(NN - 32)> Tail;
-    d16 a, b;
-    typename Tail::type c;
-};
-template <int NN>
-__device__ __forceinline__ double colget(const ColT<NN> &x, int i) {
-    return i < 16 ? x.a[i & 15] : (i < 32 ? x.b[i & 15] : x.c[i & ColT<NN>::Tail::mask]);
-}
-template <int NN>
-__device__ __forceinline__ void colset(ColT<NN> &x, int i, double v) {
-    if (i < 16) x.a[i & 15] = v;
-    else if (i < 32) x.b[i & 15] = v;
-    else x.c[i & ColT<NN>::Tail::mask] = v;
-}
-template <int NN>
-__device__ __forceinline__ double coldyn(const ColT<NN> &x, int k) {  // k uniform
-    const double va = x.a[k & 15], vb = x.b[k & 15], vc = x.c[k & ColT<NN>::Tail::mask];
-    return k < 16 ? va : (k < 32 ? vb : vc);
-}
-template <int NN>
-__device__ __forceinline__ void coladd_dyn(ColT<NN> &x, int k, double v) {  // k uniform
-    if (k < 16) x.a[k & 15] += v;
-    else if (k < 32) x.b[k & 15] += v;
-    else x.c[k & ColT<NN>::Tail::mask] += v;
-}
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srclane);
