@@ -391,7 +391,7 @@ DWBC_DEVN void point_jacobian(Thr th, const double *Rw, const double *pw, const 
 // W1/W2/fv are the contact wrench maps already rotated into the contact frames (A_rot applied).
 // ----------------------------------------------------------------------------------------------
 template <int N, int NB>
-DWBC_DEVN void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
+DWBC_DEV void qp_rows_and_solve(const Setup &su, double *L, int nlim, int ncone, int ci0, int ci1, const double *P1, int ld1,
                                 int t1, const double *P2, int ld2, int t2, double s2, const double *W1, int ldw1,
                                 const double *W2, int ldw2, const double *fv, const double *base, int tvars, int max_iter,
                                 QpResult &res, double *Vlds, double *xlds) {

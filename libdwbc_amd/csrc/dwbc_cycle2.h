@@ -667,21 +667,27 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     DWBC_SYNC();
 
-    // ================= stage 3b: the QP cascade (dwbc.cpp:818-873, 941-1127) =================
+    // ================= stage 3b + 4: the QP cascade (dwbc.cpp:818-873, 941-1127) followed by the contact
+    // redistribution QP (dwbc.cpp:1372-1568).  One loop, ONE inlined copy of the solver: pass qi < n_levels is task
+    // level qi, the last pass is the redistribution. =================
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
-    int st_task = 1, fail_level = -1;
+    int st_task = 1, fail_level = -1, st_redis = 1;
     const double *fs_in = io.fstar + (size_t)inst * su.fstar_total;
     double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
-    for (int lv = 0; lv < su.n_levels && st_task; lv++) {
-        const int t = su.t_dof[lv];
-        const double *Ul = L + S::U + lv * M * T;
-        const double *fs = fs_in + su.fstar_off[lv];
-        if (rankbad & (1 << lv)) { st_task = 0; fail_level = lv; break; }  // rank-deficient task block (reference: pseudo-inverse)
+    for (int qi = 0; qi <= su.n_levels; qi++) {
+        const bool is_task = qi < su.n_levels;
+        if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
+        if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
+        const int t = is_task ? su.t_dof[qi] : 0;
+        const double *Ul = L + S::U + (is_task ? qi : 0) * M * T;
+        const double *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
+        if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
         DWBC_SYNC();
         for (int i = th.tid; i < M; i += NT) {
             double acc = L[S::tg + i] + L[S::tt + i];
-            for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j];
+            if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
+            else acc += L[S::tc + i];
             base[i] = acc;
         }
         DWBC_SYNC();
@@ -703,77 +709,56 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
         }
         DWBC_SYNC();
-        DWBC_STAMP(7 + 3 * lv);
+        if (is_task) DWBC_STAMP(7 + 3 * qi);
         QpResult qres;
-        qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], Ul, T, t, L + S::NwJw, k, k, kQpScaleGI, F, kQpLd,
-                                 L + S::FNl, k, fv, base, t, su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x);
+        {
+            // task level: x = [f*_qp (t) ; contact_qp (k)], rows [U | s NwJw];  redistribution: x = c (k), rows [NwJw]
+            const double *P1 = is_task ? Ul : L + S::NwJw;
+            const int ld1 = is_task ? T : k, n1 = is_task ? t : k, n2 = is_task ? k : 0;
+            const double *W1 = is_task ? F : L + S::FNl;
+            const int ldw1 = is_task ? kQpLd : k;
+            qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], P1, ld1, n1, L + S::NwJw, k, n2,
+                                     is_task ? kQpScaleGI : 1.0, W1, ldw1, L + S::FNl, k, fv, base, n1,
+                                     is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
+        }
+        const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
-            diag[DG_QP_ITER + lv] = qres.iters;
-            diag[DG_QP_NACT + lv] = qres.nact;
-            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + lv * kQpLd + a] = qres.act[a];
+            diag[DG_QP_ITER + slot] = qres.iters;
+            diag[DG_QP_NACT + slot] = qres.nact;
+            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + slot * kQpLd + a] = qres.act[a];
         }
-        if (dump && th.tid == 0) dump[dl.qp_viol + lv] = qres.viol;
-        DWBC_STAMP(8 + 3 * lv);
-        if (!qres.status) { st_task = 0; fail_level = lv; break; }  // cascade aborts (dwbc.cpp:836,1119)
+        if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
+        if (is_task) DWBC_STAMP(8 + 3 * qi);
         const double *x = L + S::qp_x;
-        for (int i = th.tid; i < M; i += NT) {
-            double acc = 0.0;
-            for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
-            L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
-            double c = 0.0;
-            for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
-            L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
-        }
-        if (dump) {
-            for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + lv * T + j] = x[j];
-            for (int j = th.tid; j < k; j += NT) dump[dl.contact_qp + lv * (C - 6) + j] = x[t + j];
-        }
-        DWBC_SYNC();
-    }
-    DWBC_STAMP(14);
-
-    // ================= stage 4: contact redistribution (dwbc.cpp:1372-1568) =================
-    int st_redis = 1;
-    if (k > 0) {
-        DWBC_SYNC();
-        for (int i = th.tid; i < M; i += NT) base[i] = L[S::tg + i] + L[S::tt + i] + L[S::tc + i];
-        DWBC_SYNC();
-        for (int i = th.tid; i < cd; i += NT) {
-            double acc = -L[S::PC + i];
-            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c];
-            L[S::t_s1 + i] = acc;
-        }
-        DWBC_SYNC();
-        for (int i = th.tid; i < cd; i += NT) {
-            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
-            const double *R = L + S::Rc + a * 9;
-            const double *src = L + S::t_s1 + 6 * a + 3 * h;
-            fv[i] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[1] + R[2 * 3 + x] * src[2];
-        }
-        DWBC_SYNC();
-        QpResult qres;
-        qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], L + S::NwJw, k, k, L + S::NwJw, k, 0, 1.0, L + S::FNl, k,
-                                 L + S::FNl, k, fv, base, k, su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
-        if (diag && th.tid == 0) {
-            diag[DG_QP_ITER + kMaxLevels] = qres.iters;
-            diag[DG_QP_NACT + kMaxLevels] = qres.nact;
-            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = qres.act[a];
-        }
-        if (dump && th.tid == 0) dump[dl.qp_viol + kMaxLevels] = qres.viol;
-        const double *x = L + S::qp_x;
-        if (qres.status) {
+        if (is_task) {
+            if (!qres.status) { st_task = 0; fail_level = qi; continue; }  // cascade aborts (dwbc.cpp:836,1119)
+            for (int i = th.tid; i < M; i += NT) {
+                double acc = 0.0;
+                for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
+                L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
+                double c = 0.0;
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
+                L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+            }
+            if (dump) {
+                for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + qi * T + j] = x[j];
+                for (int j = th.tid; j < k; j += NT) dump[dl.contact_qp + qi * (C - 6) + j] = x[t + j];
+            }
+        } else if (qres.status) {
             for (int i = th.tid; i < M; i += NT) {
                 double c = 0.0;
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
-                L[S::tc + i] += c;
+                L[S::tc + i] += c;    // torque_contact_ += NwJw c   (dwbc.cpp:1549)
             }
             if (dump)
                 for (int j = th.tid; j < k; j += NT) dump[dl.cf_redis + j] = x[j];
         } else {
             st_redis = 0;
-            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;
+            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1553-1559
         }
-    } else {
+        DWBC_SYNC();
+    }
+    if (k == 0) {
         for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1562-1567
     }
     DWBC_SYNC();

@@ -59,9 +59,11 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     PL(int, actf);     // bit0: hi side in the working set, bit1: lo side
     PL(double, val);
     PL(int, key);
-    double xu[kQpN], n[kQpN], ru[kQpN], zu[kQpN], gp[kQpN];
+    double xu[kQpN], n[kQpN], ru[kQpN], zu[kQpN];
+    double *nbuf = V, *rbuf = V + 16, *zbuf = V + 32;  // LDS broadcast buffers (V is only needed by the final solve)
+    PL(double, nl);    // lane i < nv: component i of the current normal
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) { xu[i] = 0.0; n[i] = 0.0; gp[i] = 0.0; }
+    for (int i = 0; i < kQpN; i++) { xu[i] = 0.0; n[i] = 0.0; }
     LANES {
         double s = 0.0;
 #pragma unroll
@@ -71,11 +73,14 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LV(u) = 0.0;
         LV(r) = 0.0;
         LV(z) = 0.0;
+        LV(nl) = 0.0;
         LV(akey) = 0;
         LV(actf) = 0;
     }
     // ---- Goldfarb-Idnani.  mode 0: look for the most violated row; 1: primal/dual step for row (p, side);
-    //      2: re-adding working-set member `ra` after a drop (N, N^+ are rebuilt column by column)
+    //      2: re-adding working-set member `ra` after a drop (N, N^+ are rebuilt column by column).
+    //      Vectors that every lane needs (normal n, r = N^+ n, z = n - N r) are broadcast through 12-double LDS
+    //      buffers: one store per lane + uniform reads, instead of 24 v_readlane and a 12-way select chain each.
     int q = 0, it = 0, status = 1, mode = 0, ra = 0, p = 0, side = 0, kmin = 0;
     double up = 0.0, bp = 0.0, gnp = 1.0, worst = 0.0;
     for (;;) {
@@ -94,45 +99,55 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             if (!(worst < -kQpTol)) break;
             p = kmin >> 1;
             side = kmin & 1;
-#pragma unroll
-            for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
-            bp = side ? BCAST(R.lo, p) : BCAST(R.hi, p);
-            gnp = 1.0 / BCAST(rgn, p);
             up = 0.0;
             mode = 1;
         }
-        // normal of the row being processed (GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g)
+        // normal of the row being processed (GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g),
+        // published by its owner lane
+        int pe = p, se = side;
         if (mode == 2) {
             const int ka = BCASTI(akey, ra);
-#pragma unroll
-            for (int j = 0; j < kQpN; j++) {
-                const double gj = BCASTA(R.g, j, ka >> 1);
-                n[j] = (ka & 1) ? gj : -gj;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kQpN; j++) n[j] = side ? gp[j] : -gp[j];
+            pe = ka >> 1;
+            se = ka & 1;
         }
-        const int qe = (mode == 2) ? ra : q;  // columns currently in N
-        // Greville projection: r = N^+ n (lane a), z = n - N r (lane i), both also broadcast
+        WSYNC();
         LANES {
+            if (lane == pe) {
+#pragma unroll
+                for (int j = 0; j < kQpN; j++) nbuf[j] = se ? LV(R.g)[j] : -LV(R.g)[j];
+                nbuf[12] = se ? LV(R.lo) : LV(R.hi);
+                nbuf[13] = LV(rgn);
+            }
+        }
+        WSYNC();
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) n[j] = nbuf[j];
+        if (mode == 1) { bp = nbuf[12]; gnp = 1.0 / nbuf[13]; }
+        const int qe = (mode == 2) ? ra : q;  // columns currently in N
+        // Greville projection: r = N^+ n (lane a), z = n - N r (lane i)
+        LANES {
+            LV(nl) = nbuf[lane < kQpN ? lane : 0];
             double s_ = 0.0;
 #pragma unroll
             for (int i = 0; i < kQpN; i++) s_ += LV(Np)[i] * n[i];
             LV(r) = (lane < qe) ? s_ : 0.0;
+            if (lane < kQpN) rbuf[lane] = LV(r);
         }
+        WSYNC();
 #pragma unroll
-        for (int a = 0; a < kQpN; a++) ru[a] = BCAST(r, a);
+        for (int a = 0; a < kQpN; a++) ru[a] = rbuf[a];
         LANES {
-            double s_ = pick12(n, lane);
+            double s_ = LV(nl);
 #pragma unroll
             for (int a = 0; a < kQpN; a++) s_ -= LV(Nr)[a] * ru[a];
             LV(z) = (lane < nv) ? s_ : 0.0;
+            if (lane < kQpN) zbuf[lane] = LV(z);
         }
+        WSYNC();
         double zn2 = 0.0, zg = 0.0;
 #pragma unroll
         for (int i = 0; i < kQpN; i++) {
-            zu[i] = BCAST(z, i);
+            zu[i] = zbuf[i];
             zn2 += zu[i] * zu[i];
             zg += zu[i] * n[i];
         }
@@ -144,21 +159,18 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             for (int a = 0; a < kQpN; a++) rmax = fabs(ru[a]) > rmax ? fabs(ru[a]) : rmax;
             LANES {
                 const bool ok = (lane < q) && (LV(r) > 1e-13 * rmax);
-                LV(val) = ok ? LV(u) / LV(r) : DWBC_QP_INF;
+                LV(val) = ok ? LV(u) * fast_rcp(LV(r)) : DWBC_QP_INF;
+                LV(key) = lane;
             }
-            double t1 = DWBC_QP_INF;
-            int l = -1;
-#pragma unroll
-            for (int a = 0; a < kQpN; a++) {
-                const double ta = BCAST(val, a);
-                if (ta < t1) { t1 = ta; l = a; }
-            }
+            double t1;
+            int l;
+            WAVE_ARGMIN(val, key, t1, l);
             double gx = 0.0;
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) gx += gp[j] * xu[j];
-            const double sp = side ? (bp + gx) : (bp - gx);  // slack of the violated side (negative)
+            for (int j = 0; j < kQpN; j++) gx += n[j] * xu[j];
+            const double sp = bp + gx;  // slack of the violated side (negative): hi - g.x or lo + g.x
             const bool zok = sqrt(zn2) > 1e-10 * gnp && q < nv;
-            const double t2 = zok ? -sp / zg : DWBC_QP_INF;
+            const double t2 = zok ? -sp * fast_rcp(zg) : DWBC_QP_INF;
             const double tstep = t1 < t2 ? t1 : t2;
             if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
             const bool full = zok && t2 <= t1;
@@ -194,16 +206,29 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         }
         if (commit) {
             // append n as column qe of N and update N^+ (Greville)
-            const double inv_ = 1.0 / zn2;
+            const double inv_ = fast_rcp(zn2);
             LANES {
                 const double ra_ = LV(r) * inv_;
-                const bool newrow_ = (lane == qe);
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) {
-                    const double upd_ = LV(Np)[i] - ra_ * zu[i];
-                    LV(Np)[i] = newrow_ ? zu[i] * inv_ : ((lane < qe) ? upd_ : 0.0);
+                for (int i = 0; i < kQpN; i++) LV(Np)[i] -= ra_ * zu[i];  // lanes >= qe hold zeros and r = 0
+                if (lane == qe) {
+#pragma unroll
+                    for (int i = 0; i < kQpN; i++) LV(Np)[i] = zu[i] * inv_;
                 }
-                setidx12(LV(Nr), qe, pick12(n, lane));
+                switch (qe) {  // uniform
+                    case 0: LV(Nr)[0] = LV(nl); break;
+                    case 1: LV(Nr)[1] = LV(nl); break;
+                    case 2: LV(Nr)[2] = LV(nl); break;
+                    case 3: LV(Nr)[3] = LV(nl); break;
+                    case 4: LV(Nr)[4] = LV(nl); break;
+                    case 5: LV(Nr)[5] = LV(nl); break;
+                    case 6: LV(Nr)[6] = LV(nl); break;
+                    case 7: LV(Nr)[7] = LV(nl); break;
+                    case 8: LV(Nr)[8] = LV(nl); break;
+                    case 9: LV(Nr)[9] = LV(nl); break;
+                    case 10: LV(Nr)[10] = LV(nl); break;
+                    default: LV(Nr)[11] = LV(nl); break;
+                }
             }
             if (mode == 2) {
                 ra++;
