@@ -123,6 +123,62 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
     return ok;
 }
 
+// The sweep without LDS.  The pivot column is broadcast with v_readlane (lane select = the uniform pivot index k).  Each
+// lane's own element of the pivot ROW, S[k][lane] = S[lane][k], would be a dynamic register index; the pivot loop is
+// therefore unrolled by 8 with k = 8*kb + kr: kr is static, and the element is picked from the five candidates
+// s[kr], s[8+kr], ... by the uniform kb.  The "- delta_ik" of the multiplier is absorbed by storing the diagonal
+// shifted by one (s[j][j] = S[j][j] - 1), so that readlane(s[k], k) is already c_k - 1; the true diagonal lives in dg.
+template <int NN>
+DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg)) {
+    DWBC_LANE_DECL;
+    static_assert(NN <= 40, "five candidate registers per kr");
+    int ok = 1;
+    LANES {
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - 1.0 : LV(s)[i];
+    }
+    for (int kb = 0; kb < 5; kb++) {
+#pragma unroll
+        for (int kr = 0; kr < 8; kr++) {
+            const int k = 8 * kb + kr;
+            if (k < NN) {
+                double d = BCAST(dg, k);
+                if (!(d > 0.0)) { ok = 0; d = 1.0; }
+                const double rp = fast_rcp(d);
+#ifdef DWBC_HOST_EMU
+                double snap_[NN];
+                for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[k][i_];
+#endif
+                LANES {
+                    // own element k = 8*kb + kr: static candidates, uniform selector
+                    double cj = LV(s)[kr];
+                    if (8 + kr < NN) cj = (kb == 1) ? LV(s)[(8 + kr) < NN ? 8 + kr : 0] : cj;
+                    if (16 + kr < NN) cj = (kb == 2) ? LV(s)[(16 + kr) < NN ? 16 + kr : 0] : cj;
+                    if (24 + kr < NN) cj = (kb == 3) ? LV(s)[(24 + kr) < NN ? 24 + kr : 0] : cj;
+                    if (32 + kr < NN) cj = (kb == 4) ? LV(s)[(32 + kr) < NN ? 32 + kr : 0] : cj;
+                    const double h = (lane == k) ? (1.0 - rp) : cj * rp;
+#pragma unroll
+                    for (int i = 0; i < NN; i++) {
+#ifdef DWBC_HOST_EMU
+                        const double ci = snap_[i];
+#else
+                        const double ci = readlane_f64(LV(s)[i], k);
+#endif
+                        LV(s)[i] -= ci * h;
+                    }
+                    LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
+                }
+            }
+        }
+    }
+    LANES {
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        LV(dg) = -LV(dg);
+    }
+    return ok;
+}
+
 // inverse of a small SPD matrix (n <= 12) held in LDS: column per lane in registers + the sweep above.  Used for
 // Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
 // where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
@@ -323,7 +379,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(0);  // kinematics + CRBA done
     int st_contact = 1;
     // A_inv (dwbc.cpp:307)
-    if (!sweep_inverse_regs<N>(s, dg, L + S::k_col)) st_contact = 0;
+    if (!sweep_inverse_rl<N>(s, dg)) st_contact = 0;
     if (dump) {
         LANES {
             if (lane < N) {
@@ -559,7 +615,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LV(dw) = 1.0;
         }
     }
-    if (!sweep_inverse_regs<M>(w, dw, L + S::c_col)) st_contact = 0;
+    if (!sweep_inverse_rl<M>(w, dw)) st_contact = 0;
     LANES {
         if (k > 0) {
 #pragma unroll
