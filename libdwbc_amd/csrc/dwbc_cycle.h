@@ -143,6 +143,7 @@ DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
+        _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[i * lda + p] * B[p * ldb + j];
         Cm[i * ldc + j] = s;
     }
@@ -153,6 +154,7 @@ DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
+        _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[i * lda + p] * B[j * ldb + p];
         Cm[i * ldc + j] = s;
     }
@@ -163,6 +165,7 @@ DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const
     for (int idx = th.tid; idx < m * n; idx += NT) {
         int i = idx / n, j = idx - i * n;
         double s = 0.0;
+        _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[p * lda + i] * B[p * ldb + j];
         Cm[i * ldc + j] = s;
     }
@@ -171,6 +174,7 @@ template <int NT>
 DWBC_DEV void mv_n(Thr th, double *y, const double *A, int lda, const double *x, int m, int n) {
     for (int i = th.tid; i < m; i += NT) {
         double s = 0.0;
+        _Pragma("unroll 8")
         for (int j = 0; j < n; j++) s += A[i * lda + j] * x[j];
         y[i] = s;
     }
@@ -659,6 +663,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         for (int idx = th.tid; idx < N * N; idx += NT) {
             const int i = idx / N, j = idx - i * N;
             double s = Ai[idx];
+            _Pragma("unroll 8")
             for (int p = 0; p < cd; p++) s -= Y[p * N + i] * JbT[p * N + j];
             AiNc[idx] = s;
         }
@@ -698,6 +703,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < k * k; idx += NT) {
                 const int i = idx / k, j = idx - i * k;
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * Vb[c * k + j];
                 L[S::c_s2 + idx] = s;
             }
@@ -749,6 +755,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < cd * k; idx += NT) {
                 const int i = idx / k, j = idx - i * k;
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
                 L[S::c_s1 + idx] = s;
             }
@@ -809,6 +816,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < t * M; idx += NT) {             // Q = (Lambda J A^-1 N_c)[:,6:]
                 const int i = idx / M, j = idx - i * M;
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int p = 0; p < t; p++) s += Lt[i * t + p] * T1[p * N + 6 + j];
                 Q[idx] = s;
             }
@@ -821,6 +829,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < M * t; idx += NT) {             // J_kt = W^+ Q^T pinv(.)
                 const int i = idx / t, j = idx - i * t;
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int p = 0; p < t; p++) s += QW[p * M + i] * L[S::t_s3 + p * t + j];
                 Jkt[idx] = s;
             }
@@ -830,6 +839,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             for (int idx = th.tid; idx < M * t; idx += NT) {
                 const int i = idx / t, j = idx - i * t;
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int p = 0; p < t; p++) s += Jkt[i * t + p] * Lt[p * t + j];
                 X[i * T + j] = s;
                 U[i * T + j] = s;
@@ -853,6 +863,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 for (int idx = th.tid; idx < tp * t; idx += NT) {       // Z = Yp U  (tp x t)
                     const int i = idx / t, j = idx - i * t;
                     double s = 0.0;
+                    _Pragma("unroll 8")
                     for (int c = 0; c < M; c++) s += Yp[i * M + c] * U[c * T + j];
                     L[S::t_s2 + idx] = s;
                 }
@@ -860,6 +871,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
                 for (int idx = th.tid; idx < M * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double s = U[i * T + j];
+                    _Pragma("unroll 8")
                     for (int p = 0; p < tp; p++) s -= Xp[i * T + p] * L[S::t_s2 + p * t + j];
                     U[i * T + j] = s;
                 }
@@ -871,6 +883,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
             for (int i = th.tid; i < M; i += NT) {
                 double s = L[S::tg + i] + L[S::tt + i];
+                _Pragma("unroll 8")
                 for (int j = 0; j < t; j++) s += U[i * T + j] * fs[j];
                 base[i] = s;
             }
@@ -911,9 +924,11 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp) ; torque_contact_ = NwJw contact_qp_ (dwbc.cpp:839-851)
             for (int i = th.tid; i < M; i += NT) {
                 double s = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < t; j++) s += U[i * T + j] * (fs[j] + x[j]);
                 L[S::tt + i] += s;
                 double c = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
                 L[S::tc + i] = c;
             }
@@ -935,6 +950,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         DWBC_SYNC();
         for (int i = th.tid; i < cd; i += NT) {
             double s = -L[S::PC + i];
+            _Pragma("unroll 8")
             for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * base[c];
             L[S::t_s1 + i] = s;
         }
@@ -961,6 +977,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         if (ok) {
             for (int i = th.tid; i < M; i += NT) {
                 double c = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
                 L[S::tc + i] += c;
             }
@@ -984,6 +1001,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         double s = 0.0;
         if (i < cd) {
             s = -L[S::PC + i];
+            _Pragma("unroll 8")
             for (int c = 0; c < M; c++) s += L[S::JbT + i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);
         }
         wr[i] = s;  // getContactForce(tau_total), wbd.cpp:268-271

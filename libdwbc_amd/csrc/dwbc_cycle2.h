@@ -422,6 +422,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         LANES {
             double acc = 0.0;
 #pragma unroll
+            _Pragma("unroll 8")
             for (int i = 0; i < N; i++) acc += JC[p * N + i] * LV(s)[i];
             if (lane < N) Y[p * N + lane] = acc;
         }
@@ -442,6 +443,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
+                _Pragma("unroll 8")
                 for (int p2 = 0; p2 < C; p2++) acc += ((p2 < cd) ? Lam[p * cd + p2] : 0.0) * LV(yc)[p2];
                 if (lane < N) JbT[p * N + lane] = acc;
             }
@@ -472,6 +474,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     LANES {
         double acc = 0.0;
 #pragma unroll
+        _Pragma("unroll 8")
         for (int i = 0; i < N; i++) acc += LV(s)[i] * L[S::G + i];
         if (lane < N) L[S::c_vec + lane] = acc;
     }
@@ -502,6 +505,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < k * k; idx += NT) {
             const int i = idx / k, j = idx - i * k;
             double acc = 0.0;
+            _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
             L[S::c_s2 + idx] = acc;
         }
@@ -517,6 +521,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < cd * k; idx += NT) {
             const int i = idx / k, j = idx - i * k;
             double acc = 0.0;
+            _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
             L[S::c_s1 + idx] = acc;
         }
@@ -557,6 +562,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
+                _Pragma("unroll 8")
                 for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
                 if (lane < N) T1[r * N + lane] = acc;
                 if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
@@ -629,6 +635,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         double acc = 0.0;
 #pragma unroll
+        _Pragma("unroll 8")
         for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
         if (lane < M) L[S::tg + lane] = acc;
     }
@@ -657,6 +664,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const int i = idx / M, j = idx - i * M;
             double acc = 0.0;
             if (i < t)
+                _Pragma("unroll 8")
                 for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * M + j];
             Q[idx] = acc;
         }
@@ -665,6 +673,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
+                _Pragma("unroll 8")
                 for (int i = 0; i < M; i++) acc += Q[r * M + i] * LV(w)[i];
                 if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
             }
@@ -684,6 +693,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int r2 = 0; r2 < T; r2++) {
                 double acc = 0.0;
 #pragma unroll
+                _Pragma("unroll 8")
                 for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : 0.0;
                 jk[r2] = acc;
                 if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
@@ -692,6 +702,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int r3 = 0; r3 < T; r3++) {
                 double acc = 0.0;
 #pragma unroll
+                _Pragma("unroll 8")
                 for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : 0.0;
                 if (lane < M) {
                     Xs[lane * T + r3] = acc;
@@ -706,6 +717,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int idx = th.tid; idx < tp * t; idx += NT) {
                 const int i = idx / t, j = idx - i * t;
                 double acc = 0.0;
+                _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
                 L[S::c_Z + idx] = acc;
             }
@@ -713,6 +725,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int idx = th.tid; idx < M * t; idx += NT) {
                 const int i = idx / t, j = idx - i * t;
                 double acc = Ul[i * T + j];
+                _Pragma("unroll 8")
                 for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * L[S::c_Z + p * t + j];
                 Ul[i * T + j] = acc;
             }
@@ -751,8 +764,14 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
             const int i = idx / (t + 1), j = idx - i * (t + 1);
             double acc = 0.0;
-            if (j < t) { for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Ul[c * T + j]; }
-            else { for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c]; acc -= L[S::PC + i]; }
+            if (j < t) {
+                _Pragma("unroll 8")
+                for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Ul[c * T + j];
+            } else {
+                _Pragma("unroll 8")
+                for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c];
+                acc -= L[S::PC + i];
+            }
             L[S::t_s1 + i * (T + 1) + j] = acc;
         }
         DWBC_SYNC();
@@ -790,9 +809,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }  // cascade aborts (dwbc.cpp:836,1119)
             for (int i = th.tid; i < M; i += NT) {
                 double acc = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
                 L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
                 double c = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
                 L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
             }
@@ -803,6 +824,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         } else if (qres.status) {
             for (int i = th.tid; i < M; i += NT) {
                 double c = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
                 L[S::tc + i] += c;    // torque_contact_ += NwJw c   (dwbc.cpp:1549)
             }
@@ -828,6 +850,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         double acc = 0.0;
         if (i < cd) {
             acc = -L[S::PC + i];
+            _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);
         }
         wr[i] = acc;  // getContactForce(tau_total), wbd.cpp:268-271
