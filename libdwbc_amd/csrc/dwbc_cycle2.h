@@ -422,7 +422,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         LANES {
             double acc = 0.0;
 #pragma unroll
-            _Pragma("unroll 8")
             for (int i = 0; i < N; i++) acc += JC[p * N + i] * LV(s)[i];
             if (lane < N) Y[p * N + lane] = acc;
         }
@@ -443,7 +442,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
-                _Pragma("unroll 8")
                 for (int p2 = 0; p2 < C; p2++) acc += ((p2 < cd) ? Lam[p * cd + p2] : 0.0) * LV(yc)[p2];
                 if (lane < N) JbT[p * N + lane] = acc;
             }
@@ -474,7 +472,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     LANES {
         double acc = 0.0;
 #pragma unroll
-        _Pragma("unroll 8")
         for (int i = 0; i < N; i++) acc += LV(s)[i] * L[S::G + i];
         if (lane < N) L[S::c_vec + lane] = acc;
     }
@@ -562,7 +559,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
-                _Pragma("unroll 8")
                 for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
                 if (lane < N) T1[r * N + lane] = acc;
                 if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
@@ -635,7 +631,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         double acc = 0.0;
 #pragma unroll
-        _Pragma("unroll 8")
         for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
         if (lane < M) L[S::tg + lane] = acc;
     }
@@ -673,7 +668,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LANES {
                 double acc = 0.0;
 #pragma unroll
-                _Pragma("unroll 8")
                 for (int i = 0; i < M; i++) acc += Q[r * M + i] * LV(w)[i];
                 if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
             }
@@ -693,7 +687,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int r2 = 0; r2 < T; r2++) {
                 double acc = 0.0;
 #pragma unroll
-                _Pragma("unroll 8")
                 for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : 0.0;
                 jk[r2] = acc;
                 if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
@@ -702,7 +695,6 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int r3 = 0; r3 < T; r3++) {
                 double acc = 0.0;
 #pragma unroll
-                _Pragma("unroll 8")
                 for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : 0.0;
                 if (lane < M) {
                     Xs[lane * T + r3] = acc;
