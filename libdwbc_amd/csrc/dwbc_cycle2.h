@@ -532,6 +532,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
     }
+    DWBC_STAMP(12);  // (diagnostic) NwJw / projector block done
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
@@ -566,6 +567,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
+        if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
         spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
         if (lv == NLV - 1)

@@ -33,4 +33,5 @@ for i, n in enumerate(names):
         continue
     print(f"{n:26s} {med[i]-prev:12.0f} {med[i]:12.0f}")
     prev = med[i]
+print("diag stamps 12,13 (cumulative):", med[12], med[13])
 print("qp iters median", np.median(d[:, 4:9], axis=0), "nact", np.median(d[:, 9:14], axis=0))
