@@ -1,0 +1,265 @@
+// dwbc_amd.hpp -- header-only C++ facade that gives libdwbc's RobotData names and call sequence back on top of the
+// C-ABI (include/dwbc_batch.h, libdwbc_hip.so).  One object = one robot (a batch of 1) so that an existing libdwbc
+// control loop (reference example/main.cpp:62-108, tests/dwbc_test.cpp:61-130) compiles against it with
+//     using DWBC::RobotData;     // from this header instead of the reference's dwbc.h
+// Differences that are deliberate and visible:
+//   * vectors / matrices are dwbc_amd::Vec / dwbc_amd::Mat (std::vector<double> based, row-major); when Eigen is
+//     available define DWBC_AMD_WITH_EIGEN before including to get Eigen::VectorXd / MatrixXd overloads and getters;
+//   * every Calc* call launches the fused kernel (CalcContactConstraint .. CalcContactRedistribute are one launch on the
+//     device) and refreshes all public fields, so the reference's call order yields the reference's values; a loop that
+//     only needs the final torque should call CalcAll() once per tick;
+//   * only what the device path implements: floating base, CONTACT_6D, link tasks (TASK_LINK_*), hqp = true.
+//
+// Reference API mirrored: include/dwbc.h:59-430 (method names, argument order, int 1/0 returns, std::cout messages).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "dwbc_batch.h"
+
+namespace dwbc_amd {
+typedef std::vector<double> Vec;
+struct Mat {  // row-major dense matrix
+    int rows = 0, cols = 0;
+    std::vector<double> d;
+    Mat() {}
+    Mat(int r, int c) : rows(r), cols(c), d((size_t)r * c, 0.0) {}
+    double &operator()(int i, int j) { return d[(size_t)i * cols + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * cols + j]; }
+};
+struct Vec3 {
+    double v[3];
+    Vec3(double x = 0, double y = 0, double z = 0) : v{x, y, z} {}
+    const double *data() const { return v; }
+};
+}  // namespace dwbc_amd
+
+namespace DWBC {
+
+using dwbc_amd::Mat;
+using dwbc_amd::Vec;
+using dwbc_amd::Vec3;
+
+enum CONTACT_TYPE { CONTACT_6D = 0, CONTACT_POINT = 1, CONTACT_LINK = 2, CONTACT_LINE = 3 };  // dwbc_contact_constraint.h:19-25
+enum TASK_LINK_MODE {                                                                          // dwbc_task.h:23-33
+    TASK_LINK_6D = 0, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME, TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME,
+    TASK_LINK_POSITION_CUSTOM_FRAME, TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME
+};
+
+struct TaskSpaceView {  // the fields of DWBC::TaskSpace callers read (include/dwbc_task.h:130-171)
+    int task_dof_ = 0;
+    Vec f_star_, f_star_qp_, contact_qp_;
+    Mat J_task_, Lambda_task_, J_kt_;
+    int qp_error = 0;
+};
+struct ContactView {  // include/dwbc_contact_constraint.h:27-80
+    int link_number_ = -1;
+    bool contact = false;
+    int contact_dof_ = 6;
+};
+
+class RobotData {
+  public:
+    unsigned int system_dof_ = 0, model_dof_ = 0, contact_dof_ = 0, contact_link_num_ = 0, link_num_ = 0;
+    bool is_floating_ = true;
+    double total_mass_ = 0.0;
+    Vec q_system_, q_dot_system_, q_ddot_system_;
+    Vec G_, torque_grav_, torque_task_, torque_contact_, torque_limit_;
+    Mat A_, A_inv_, J_C, Lambda_contact, J_C_INV_T, N_C, A_inv_N_C, W, W_inv, NwJw;
+    Vec P_C, cf_redis_qp_;
+    bool torque_limit_set_ = false;
+    std::vector<TaskSpaceView> ts_;
+    std::vector<ContactView> cc_;
+
+    RobotData() {}
+    ~RobotData() { release(); }
+    RobotData(const RobotData &) = delete;
+    RobotData &operator=(const RobotData &) = delete;
+
+    // ---- RobotData::LoadModelData (dwbc.h:237)
+    void LoadModelData(std::string urdf_path, bool floating, int verbose = 0, int device = 0) {
+        release();
+        model_ = dwbc_model_create_from_urdf(urdf_path.c_str(), floating ? 1 : 0);
+        if (!model_) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        batch_ = dwbc_batch_create(model_, 1, device, DWBC_F64);
+        if (!batch_) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        dwbc_batch_enable_dump(batch_, 1);
+        is_floating_ = floating;
+        system_dof_ = dwbc_model_system_dof(model_);
+        model_dof_ = system_dof_ - 6;
+        link_num_ = dwbc_model_num_links(model_);
+        total_mass_ = dwbc_model_total_mass(model_);
+        q_system_.assign(system_dof_ + 1, 0.0);
+        q_system_[system_dof_] = 1.0;
+        torque_grav_.assign(model_dof_, 0.0);
+        torque_task_.assign(model_dof_, 0.0);
+        torque_contact_.assign(model_dof_, 0.0);
+        if (verbose) std::cout << "System DOF : " << system_dof_ << "  Total Mass : " << total_mass_ << std::endl;
+    }
+    int getLinkID(std::string link_name) { return model_ ? dwbc_model_link_id(model_, link_name.c_str()) : -1; }
+
+    void SetTorqueLimit(const Vec &torque_limit) {  // dwbc.h:249
+        torque_limit_set_ = true;
+        torque_limit_ = torque_limit;
+        dwbc_batch_set_torque_limit(batch_, torque_limit.data());
+    }
+    void UpdateKinematics(const Vec &q_virtual, const Vec &q_dot_virtual, const Vec &q_ddot_virtual, bool = true) {  // dwbc.h:251
+        if (q_virtual.size() != system_dof_ + 1) { std::cout << "q size is not matched : qsize : " << system_dof_ + 1 << " input size : " << q_virtual.size() << std::endl; return; }
+        if (q_dot_virtual.size() != system_dof_) { std::cout << "q_dot size is not matched" << std::endl; return; }
+        if (q_ddot_virtual.size() != system_dof_) { std::cout << "q_ddot size is not matched" << std::endl; return; }
+        q_system_ = q_virtual; q_dot_system_ = q_dot_virtual; q_ddot_system_ = q_ddot_virtual;
+        dwbc_batch_set_state(batch_, q_system_.data(), q_dot_system_.data(), q_ddot_system_.data());
+        dirty_ = true;
+    }
+    // ---- contacts (dwbc.h:259-291)
+    void AddContactConstraint(int link_number, int contact_type, Vec3 contact_point, Vec3 /*contact_vector*/, double contact_x = 0, double contact_y = 0, bool verbose = false) {
+        for (auto &c : cc_) if (c.link_number_ == link_number) { std::cout << "Contact Constraint Already Exist for Link : " << link_number << std::endl; return; }
+        if (dwbc_batch_add_contact(batch_, link_number, contact_type, contact_point.data(), contact_x, contact_y, 0.2, 0.2) < 0) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        ContactView c; c.link_number_ = link_number; cc_.push_back(c);
+        flags_.push_back(0);
+        if (verbose) std::cout << "#" << (cc_.size() - 1) << " Contact Constraint Added : " << dwbc_model_link_name(model_, link_number) << std::endl;
+    }
+    void AddContactConstraint(const char *link_name, int contact_type, Vec3 p, Vec3 n, double cx = 0, double cy = 0, bool verbose = false) {
+        int id = getLinkID(link_name);
+        if (id < 0) { std::cout << "Link Name is Wrong : " << link_name << std::endl; return; }
+        AddContactConstraint(id, contact_type, p, n, cx, cy, verbose);
+    }
+    template <typename... Types>
+    void SetContact(Types... args) {  // dwbc.h:432-474
+        std::vector<bool> v{static_cast<bool>(args)...};
+        if (cc_.size() < v.size()) { std::cout << "Contact Constraint size mismatch ! input size : " << v.size() << " contact constraint size : " << cc_.size() << std::endl; return; }
+        contact_link_num_ = 0; contact_dof_ = 0;
+        for (size_t i = 0; i < cc_.size(); i++) {
+            bool on = i < v.size() ? v[i] : false;
+            cc_[i].contact = on; flags_[i] = on ? 1 : 0;
+            if (on) { contact_link_num_++; contact_dof_ += 6; }
+        }
+        dwbc_batch_set_contact(batch_, flags_.data());
+        dirty_ = true;
+    }
+    // ---- tasks (dwbc.h:318-333)
+    void AddTaskSpace(int heirarchy, int task_mode, int link_number, Vec3 task_point, bool verbose = false) {
+        if (!dwbc_batch_add_task(batch_, heirarchy, task_mode, link_number, task_point.data())) { std::cout << dwbc_last_error() << std::endl; return; }
+        if ((int)ts_.size() <= heirarchy) ts_.resize(heirarchy + 1);
+        ts_[heirarchy].task_dof_ = dwbc_batch_task_dof(batch_, heirarchy);
+        ts_[heirarchy].f_star_.assign(ts_[heirarchy].task_dof_, 0.0);
+        if (verbose) std::cout << "#" << heirarchy << " Task Space Added : " << dwbc_model_link_name(model_, link_number) << std::endl;
+    }
+    void AddTaskSpace(int heirarchy, int task_mode, const char *link_name, Vec3 task_point, bool verbose = false) {
+        int id = getLinkID(link_name);
+        if (id < 0) { std::cout << "Link Name is not Correct" << std::endl; return; }
+        AddTaskSpace(heirarchy, task_mode, id, task_point, verbose);
+    }
+    void SetTaskSpace(int heirarchy, const Vec &f_star) {  // dwbc.h:333
+        if (heirarchy >= (int)ts_.size()) { std::cout << "ERROR : task space size overflow" << std::endl; return; }
+        if ((int)f_star.size() != ts_[heirarchy].task_dof_) { std::cout << "ERROR : task dof not matching! heir : " << heirarchy << " fstar size : " << f_star.size() << " task_dof : " << ts_[heirarchy].task_dof_ << std::endl; return; }
+        ts_[heirarchy].f_star_ = f_star;
+        ts_[heirarchy].f_star_qp_.assign(f_star.size(), 0.0);
+        dwbc_batch_set_fstar(batch_, heirarchy, f_star.data());
+        dirty_ = true;
+    }
+    // ---- the cycle (dwbc.h:280, 246, 349, 298, 303)
+    int CalcContactConstraint() { return refresh() ? diag_[0] : 0; }
+    Vec CalcGravCompensation() { refresh(); return torque_grav_; }
+    int CalcTaskControlTorque(bool hqp = true, bool init = true, bool = true) {
+        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        if (!refresh(init)) return 0;
+        // torque_contact_ = NwJw * contact_qp_(last level) at this point of the reference sequence (dwbc.cpp:851)
+        const int k = contact_dof_ > 6 ? (int)contact_dof_ - 6 : 0;
+        torque_contact_.assign(model_dof_, 0.0);
+        if (k > 0 && !ts_.empty())
+            for (unsigned i = 0; i < model_dof_; i++)
+                for (int j = 0; j < k; j++) torque_contact_[i] += NwJw(i, j) * ts_.back().contact_qp_[j];
+        redistributed_ = false;
+        return diag_[1];
+    }
+    int CalcContactRedistribute(bool hqp = true, bool init = true) {
+        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        if (!refresh(init)) return 0;
+        torque_contact_ = tau_contact_final_;
+        redistributed_ = true;
+        return diag_[2];
+    }
+    int CalcAll(bool init = true) { int ok = refresh(init); torque_contact_ = tau_contact_final_; return ok && diag_[0] && diag_[1] && diag_[2]; }
+    Vec getContactForce(const Vec &command_torque) {  // wbd.cpp:268-271: J_C_INV_T[:,6:] tau - P_C
+        Vec f(contact_dof_, 0.0);
+        for (unsigned c = 0; c < contact_dof_; c++) {
+            double s = -P_C[c];
+            for (unsigned j = 0; j < model_dof_; j++) s += J_C_INV_T(c, 6 + j) * command_torque[j];
+            f[c] = s;
+        }
+        return f;
+    }
+
+  private:
+    dwbc_model *model_ = nullptr;
+    dwbc_batch *batch_ = nullptr;
+    std::vector<uint8_t> flags_;
+    bool dirty_ = true, redistributed_ = false;
+    int diag_[96] = {0};
+    Vec tau_contact_final_;
+
+    void release() {
+        if (batch_) dwbc_batch_destroy(batch_);
+        if (model_) dwbc_model_destroy(model_);
+        batch_ = nullptr; model_ = nullptr;
+    }
+    Mat fetch(int field, int r, int c, int src_cols = -1) {
+        size_t nb = dwbc_batch_field_bytes(batch_, field);
+        std::vector<double> buf(nb / 8);
+        Mat m(r, c);
+        if (!dwbc_batch_get(batch_, field, buf.data(), nb)) return m;
+        if (src_cols < 0) src_cols = c;
+        for (int i = 0; i < r; i++) for (int j = 0; j < c; j++) m(i, j) = buf[(size_t)i * src_cols + j];
+        return m;
+    }
+    int refresh(bool init = true) {
+        if (!batch_) return 0;
+        if (!dirty_) return 1;
+        if (!dwbc_batch_solve(batch_, DWBC_SOLVE_HQP | (init ? DWBC_SOLVE_INIT : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        const int n = system_dof_, m = model_dof_, cd = contact_dof_, k = cd > 6 ? cd - 6 : 0;
+        std::vector<double> tau(3 * m);
+        dwbc_batch_get(batch_, DWBC_TAU, tau.data(), tau.size() * 8);
+        torque_grav_.assign(tau.begin(), tau.begin() + m);
+        torque_task_.assign(tau.begin() + m, tau.begin() + 2 * m);
+        tau_contact_final_.assign(tau.begin() + 2 * m, tau.end());
+        dwbc_batch_get(batch_, DWBC_DIAG, diag_, sizeof(int) * 90);
+        A_ = fetch(DWBC_A, n, n); A_inv_ = fetch(DWBC_A_INV, n, n); A_inv_N_C = fetch(DWBC_A_INV_N_C, n, n);
+        J_C = fetch(DWBC_J_C, cd, n); J_C_INV_T = fetch(DWBC_J_C_INV_T, cd, n);
+        Lambda_contact = fetch(DWBC_LAMBDA_C, cd, cd, cd);
+        W_inv = fetch(DWBC_W_INV, m, m); NwJw = fetch(DWBC_NWJW, m, k, k > 0 ? k : 1);
+        Mat g = fetch(DWBC_G, 1, n), pc = fetch(DWBC_P_C, 1, cd, 12);
+        G_ = g.d; P_C = pc.d;
+        W = Mat(m, m);
+        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) W(i, j) = A_inv_N_C(6 + i, 6 + j);
+        N_C = Mat(n, n);  // N_C = I - J_C^T J_C_INV_T (wbd.cpp:117)
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int c = 0; c < cd; c++) s -= J_C(c, i) * J_C_INV_T(c, j);
+            N_C(i, j) = s;
+        }
+        Mat fq = fetch(DWBC_FSTAR_QP, 4, 6), cq = fetch(DWBC_CONTACT_QP, 4, 6), cr = fetch(DWBC_CF_REDIS, 1, 6);
+        cf_redis_qp_.assign(cr.d.begin(), cr.d.begin() + k);
+        std::vector<double> jt(dwbc_batch_field_bytes(batch_, DWBC_J_TASK) / 8), lt(dwbc_batch_field_bytes(batch_, DWBC_LAMBDA_TASK) / 8), jk(dwbc_batch_field_bytes(batch_, DWBC_J_KT) / 8);
+        dwbc_batch_get(batch_, DWBC_J_TASK, jt.data(), jt.size() * 8);
+        dwbc_batch_get(batch_, DWBC_LAMBDA_TASK, lt.data(), lt.size() * 8);
+        dwbc_batch_get(batch_, DWBC_J_KT, jk.data(), jk.size() * 8);
+        for (size_t l = 0; l < ts_.size(); l++) {
+            const int t = ts_[l].task_dof_;
+            ts_[l].f_star_qp_.assign(&fq.d[l * 6], &fq.d[l * 6] + t);
+            ts_[l].contact_qp_.assign(&cq.d[l * 6], &cq.d[l * 6] + k);
+            ts_[l].J_task_ = Mat(t, n); ts_[l].Lambda_task_ = Mat(t, t); ts_[l].J_kt_ = Mat(m, t);
+            for (int i = 0; i < t; i++) for (int j = 0; j < n; j++) ts_[l].J_task_(i, j) = jt[l * 6 * n + i * n + j];
+            for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) ts_[l].Lambda_task_(i, j) = lt[l * 36 + i * t + j];
+            for (int i = 0; i < m; i++) for (int j = 0; j < t; j++) ts_[l].J_kt_(i, j) = jk[l * m * 6 + i * t + j];
+            ts_[l].qp_error = (diag_[1] == 0 && diag_[3] == (int)l) ? 1 : 0;
+        }
+        dirty_ = false;
+        return 1;
+    }
+};
+
+}  // namespace DWBC

@@ -1,0 +1,67 @@
+// Mirror of reference tests/dwbc_test.cpp:29-131 (CASE 1 / CASE 2) written against the drop-in facade
+// include/dwbc_amd.hpp.  Prints torque_grav_, torque_task_, torque_contact_ (after CalcTaskControlTorque and after
+// CalcContactRedistribute) and a few matrices' checksums as JSON for tests/test_facade_cpp.py.
+#include <cstdio>
+#include <cstdlib>
+
+#include "dwbc_amd.hpp"
+
+using namespace DWBC;
+
+static void print_vec(const char *name, const Vec &v, bool last = false) {
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) printf("%s%.17g", i ? ", " : "", v[i]);
+    printf("]%s\n", last ? "" : ",");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: facade_case <urdf> <case 1|2>\n"); return 2; }
+    const int cs = atoi(argv[2]);
+    RobotData rd_;
+    rd_.LoadModelData(argv[1], true, false);
+    if (rd_.system_dof_ != 39) { fprintf(stderr, "model load failed\n"); return 3; }
+    Vec q(rd_.system_dof_ + 1, 0.0), qdot(rd_.system_dof_, 0.0), qddot(rd_.system_dof_, 0.0);
+    const double q1[40] = {0, 0, 0.92983, 0, 0, 0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0, 0, 0,
+                           0.3, 0.3, 1.5, -1.27, -1, 0, -1, 0, 0, 0, -0.3, -0.3, -1.5, 1.27, 1, 0, 1, 0, 1};
+    const double q2[40] = {0, 0, 0.92983, 0, 0, 0, 0.1, 0.0, -0.24, 0.5, -0.6, 0.0, 0.05, 0.0, -0.21, 0.7, -0.31, 0.0, 0, 0, 0,
+                           0.2, 0.5, 1.5, -1.27, -1.2, 0, -1, 0, 0, 0, -0.3, -0.3, -1.5, 1.27, 1.3, 0.1, 1.3, 0, 1};
+    for (int i = 0; i < 40; i++) q[i] = cs == 1 ? q1[i] : q2[i];
+    Vec fstar_1 = cs == 1 ? Vec{0.1, 4.0, 0.1, 0.1, -0.1, 0.1} : Vec{0.4, 2.0, 0.1, 0.3, -0.1, 0.1};
+    Vec fstar_2 = cs == 1 ? Vec{0.1, -0.1, 0.1} : Vec{0.1, 0.1, 0.1};
+
+    rd_.UpdateKinematics(q, qdot, qddot);
+    int left_foot_id = 6, right_foot_id = 12;
+    rd_.AddContactConstraint(left_foot_id, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.15, 0.075);
+    rd_.AddContactConstraint(right_foot_id, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.15, 0.075);
+    rd_.AddContactConstraint(23, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.04, 0.04);
+    rd_.AddContactConstraint(31, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.04, 0.04);
+    rd_.AddTaskSpace(0, TASK_LINK_6D, 0, Vec3());
+    rd_.AddTaskSpace(1, TASK_LINK_ROTATION, "upperbody_link", Vec3());
+    rd_.SetTorqueLimit(Vec(rd_.model_dof_, 300.0));
+    rd_.UpdateKinematics(q, qdot, qddot);
+    rd_.SetContact(true, true);
+    int ok_c = rd_.CalcContactConstraint();
+    rd_.SetTaskSpace(0, fstar_1);
+    rd_.SetTaskSpace(1, fstar_2);
+    Vec tg = rd_.CalcGravCompensation();
+    int ok_t = rd_.CalcTaskControlTorque(true);
+    Vec tc_before = rd_.torque_contact_;
+    int ok_r = rd_.CalcContactRedistribute(true);
+    Vec total(rd_.model_dof_);
+    for (unsigned i = 0; i < rd_.model_dof_; i++) total[i] = rd_.torque_grav_[i] + rd_.torque_task_[i] + rd_.torque_contact_[i];
+    Vec cf = rd_.getContactForce(total);
+    printf("{\n\"ok\": [%d, %d, %d],\n", ok_c, ok_t, ok_r);
+    printf("\"dims\": [%u, %u, %u, %u],\n", rd_.system_dof_, rd_.model_dof_, rd_.contact_dof_, rd_.contact_link_num_);
+    print_vec("torque_grav_", tg);
+    print_vec("torque_task_", rd_.torque_task_);
+    print_vec("torque_contact_before_redis", tc_before);
+    print_vec("torque_contact_", rd_.torque_contact_);
+    print_vec("contact_force", cf);
+    print_vec("A_inv_", rd_.A_inv_.d);
+    print_vec("N_C", rd_.N_C.d);
+    print_vec("W", rd_.W.d);
+    print_vec("NwJw", rd_.NwJw.d);
+    print_vec("contact_qp_last", rd_.ts_.back().contact_qp_, true);
+    printf("}\n");
+    return 0;
+}
