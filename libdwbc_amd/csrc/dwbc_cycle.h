@@ -124,7 +124,7 @@ struct Lds {
     static constexpr int t_F = t_base + M;            // C x kQpLd
     static constexpr int t_fv = t_F + C * kQpLd;      // C
     static constexpr int qp_V = t_fv + C;             // householder vectors of the final least-norm solve (12 x 12)
-    static constexpr int qp_x = qp_V + kQpLd * kQpLd; // QP solution (uniform copy for the torque updates)
+    static constexpr int qp_x = qp_V + kQpLd * kQpLd + 32; // QP solution (uniform copy for the torque updates)
     static constexpr int t_end = qp_x + kQpLd;
     static constexpr int max2(int a, int b) { return a > b ? a : b; }
     static constexpr int total = max2(max2(k_end, c_end), t_end);
@@ -138,10 +138,19 @@ struct Thr {
     int tid;
 };
 
+// idx / n for 0 <= idx < 2048, 1 <= n <= 64 with one multiply (a runtime integer division costs ~40 VALU instructions)
+struct FastDiv {
+    int n;
+    unsigned inv;
+    DWBC_DEV explicit FastDiv(int n_) : n(n_), inv((1u << 20) / (unsigned)(n_ > 0 ? n_ : 1) + 1u) {}
+    DWBC_DEV int div(int idx) const { return (int)(((unsigned)idx * inv) >> 20); }
+};
+
 template <int NT>
 DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    const FastDiv fd(n);
     for (int idx = th.tid; idx < m * n; idx += NT) {
-        int i = idx / n, j = idx - i * n;
+        int i = fd.div(idx), j = idx - i * n;
         double s = 0.0;
         _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[i * lda + p] * B[p * ldb + j];
@@ -151,8 +160,9 @@ DWBC_DEV void mm_nn(Thr th, double *Cm, int ldc, const double *A, int lda, const
 // C = A * B^T   (A m x k, B n x k)
 template <int NT>
 DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    const FastDiv fd(n);
     for (int idx = th.tid; idx < m * n; idx += NT) {
-        int i = idx / n, j = idx - i * n;
+        int i = fd.div(idx), j = idx - i * n;
         double s = 0.0;
         _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[i * lda + p] * B[j * ldb + p];
@@ -162,8 +172,9 @@ DWBC_DEV void mm_nt(Thr th, double *Cm, int ldc, const double *A, int lda, const
 // C = A^T * B   (A k x m, B k x n)
 template <int NT>
 DWBC_DEV void mm_tn(Thr th, double *Cm, int ldc, const double *A, int lda, const double *B, int ldb, int m, int k, int n) {
+    const FastDiv fd(n);
     for (int idx = th.tid; idx < m * n; idx += NT) {
-        int i = idx / n, j = idx - i * n;
+        int i = fd.div(idx), j = idx - i * n;
         double s = 0.0;
         _Pragma("unroll 8")
         for (int p = 0; p < k; p++) s += A[p * lda + i] * B[p * ldb + j];

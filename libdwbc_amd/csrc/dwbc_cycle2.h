@@ -79,7 +79,7 @@ struct Lds2 {
     static constexpr int t_fv = t_F + C * kQpLd;
     static constexpr int t_s1 = t_fv + C;                      // C x (T+1)
     static constexpr int qp_V = t_s1 + C * (T + 1);
-    static constexpr int qp_x = qp_V + kQpLd * kQpLd;
+    static constexpr int qp_x = qp_V + kQpLd * kQpLd + 32;
     static constexpr int t_end = qp_x + kQpLd;
     static constexpr int total = max2(max2(k_end, c_end), t_end);
     static constexpr int total_bytes = total * 8 + 64;
@@ -482,7 +482,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     if (k > 0) {
         const double *Pc = L + S::Pc;
         for (int idx = th.tid; idx < M * k; idx += NT) {
-            const int r = idx / k, a = idx - r * k;
+            const int r = idx / 6, a = idx - r * 6;  // k == 6 here
             const int ci = 1 + a / 6, e = a % 6;
             double f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
             if (e < 3) f2[e] = 1.0; else m2[e - 3] = 1.0;
@@ -500,7 +500,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         for (int idx = th.tid; idx < k * k; idx += NT) {
-            const int i = idx / k, j = idx - i * k;
+            const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             double acc = 0.0;
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
@@ -516,7 +516,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
         for (int idx = th.tid; idx < cd * k; idx += NT) {
-            const int i = idx / k, j = idx - i * k;
+            const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             double acc = 0.0;
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
@@ -524,7 +524,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         for (int idx = th.tid; idx < cd * k; idx += NT) {
-            const int i = idx / k, j = idx - i * k;
+            const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
             const double *R = L + S::Rc + a * 9;
             const double *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
@@ -654,6 +654,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
         const double *Lt = L + S::c_Lt + lv * T * T;
+        const FastDiv fdt(t);
         const double *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
         double *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
         DWBC_SYNC();
@@ -709,7 +710,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const int tp = su.t_dof[pl];
             const double *Xp = L + S::Xl + pl * M * T, *Yp = L + S::T1r + pl * T * M;
             for (int idx = th.tid; idx < tp * t; idx += NT) {
-                const int i = idx / t, j = idx - i * t;
+                const int i = fdt.div(idx), j = idx - i * t;
                 double acc = 0.0;
                 _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
@@ -717,7 +718,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             for (int idx = th.tid; idx < M * t; idx += NT) {
-                const int i = idx / t, j = idx - i * t;
+                const int i = fdt.div(idx), j = idx - i * t;
                 double acc = Ul[i * T + j];
                 _Pragma("unroll 8")
                 for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * L[S::c_Z + p * t + j];
@@ -743,6 +744,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
         if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
         const int t = is_task ? su.t_dof[qi] : 0;
+        const FastDiv fdt1(t + 1);
         const double *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const double *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
@@ -756,7 +758,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // contact wrench map in the contact frame: F = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-            const int i = idx / (t + 1), j = idx - i * (t + 1);
+            const int i = fdt1.div(idx), j = idx - i * (t + 1);
             double acc = 0.0;
             if (j < t) {
                 _Pragma("unroll 8")
@@ -770,7 +772,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-            const int i = idx / (t + 1), j = idx - i * (t + 1);
+            const int i = fdt1.div(idx), j = idx - i * (t + 1);
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
             const double *R = L + S::Rc + a * 9;
             const double *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;

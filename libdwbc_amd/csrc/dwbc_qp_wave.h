@@ -46,7 +46,7 @@ DWBC_WDEV double upick12(const double *a, int idx) {
 }
 
 template <int DUMMY>
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS 12x12 */) {
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS, 176 doubles */) {
     DWBC_LANE_DECL;
     const int k = nv - t;
     PLA(double, Np, kQpN);
@@ -55,6 +55,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     PL(double, z);
     PL(double, u);
     PL(double, rgn);   // 1 / |g|
+    PL(double, gno);   // |g|
     PL(int, akey);     // lane a < q: (owner lane << 1) | side of the a-th working-set member
     PL(int, actf);     // bit0: hi side in the working set, bit1: lo side
     PL(double, val);
@@ -69,7 +70,8 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
         for (int j = 0; j < kQpN; j++) { s += LV(R.g)[j] * LV(R.g)[j]; LV(Np)[j] = 0.0; LV(Nr)[j] = 0.0; }
         s = sqrt(s);
-        LV(rgn) = 1.0 / (s < 1e-300 ? 1e-300 : s);
+        LV(gno) = s < 1e-300 ? 1e-300 : s;
+        LV(rgn) = 1.0 / LV(gno);
         LV(u) = 0.0;
         LV(r) = 0.0;
         LV(z) = 0.0;
@@ -116,13 +118,13 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
                 for (int j = 0; j < kQpN; j++) nbuf[j] = se ? LV(R.g)[j] : -LV(R.g)[j];
                 nbuf[12] = se ? LV(R.lo) : LV(R.hi);
-                nbuf[13] = LV(rgn);
+                nbuf[13] = LV(gno);
             }
         }
         WSYNC();
 #pragma unroll
         for (int j = 0; j < kQpN; j++) n[j] = nbuf[j];
-        if (mode == 1) { bp = nbuf[12]; gnp = 1.0 / nbuf[13]; }
+        if (mode == 1) { bp = nbuf[12]; gnp = nbuf[13]; }
         const int qe = (mode == 2) ? ra : q;  // columns currently in N
         // Greville projection: r = N^+ n (lane a), z = n - N r (lane i)
         LANES {
@@ -169,7 +171,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
             for (int j = 0; j < kQpN; j++) gx += n[j] * xu[j];
             const double sp = bp + gx;  // slack of the violated side (negative): hi - g.x or lo + g.x
-            const bool zok = sqrt(zn2) > 1e-10 * gnp && q < nv;
+            const bool zok = zn2 > (1e-10 * gnp) * (1e-10 * gnp) && q < nv;
             const double t2 = zok ? -sp * fast_rcp(zg) : DWBC_QP_INF;
             const double tstep = t1 < t2 ? t1 : t2;
             if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
@@ -259,8 +261,14 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     if (!status || q == 0) return;  // x = 0: failure (caller zeroes the correction) or no active constraint
     // ---- final point from the working set alone: lexicographic least-norm point (contact block weighted) if it is
     //      feasible, else the Tikhonov point (DESIGN.md "QP canon").  Column a of the weighted normal matrix lives in
-    //      lane a; column-pivoted Householder QR, rows = variables with the contact block first.
+    //      lane a (registers indexed by VARIABLE); column-pivoted Householder QR whose elimination order visits the
+    //      contact variables first -- pos(j) = position of variable j -- which is the row sorting that keeps the 1e9
+    //      weight stable.  Pivot column, y and the reflector dot products travel through small LDS buffers.
     const bool lex = (k > 0 && t > 0);
+    int pos[kQpN];
+#pragma unroll
+    for (int j = 0; j < kQpN; j++) pos[j] = (j < nv) ? ((j >= t) ? (j - t) : (k + j)) : (100 + j);  // padding never pivots
+    double *cbuf = V + 144, *pbuf = V + 160;  // V[0..143]: reflectors; V is 176 doubles
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool weighted = lex && attempt == 0;
         const double wsc = weighted ? kQpScalePolish / kQpScaleGI : 1.0;
@@ -275,109 +283,114 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             const int ka = LV(akey);
             const int ow = (lane < q) ? (ka >> 1) : lane;
             const double sg = (ka & 1) ? -1.0 : 1.0;  // row as  (sg*g).x = b
-            double grow[kQpN];
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) grow[j] = SHFLA(R.g, j, ow);
-            const double bh = SHFL(R.hi, ow), bl = SHFL(R.lo, ow);
-            // variable order: contact block first (weighted), then the task block
-#pragma unroll
-            for (int i = 0; i < kQpN; i++) {
-                const int var = (i < k) ? (t + i) : (i - k);
-                const double gv = upick12(grow, var);
-                LV(c)[i] = (lane < q && i < nv) ? sg * gv * ((i < k) ? wsc : 1.0) : 0.0;
+            for (int j = 0; j < kQpN; j++) {
+                const double gj = SHFLA(R.g, j, ow);
+                LV(c)[j] = (lane < q && j < nv) ? sg * gj * ((j >= t) ? wsc : 1.0) : 0.0;
             }
+            const double bh = SHFL(R.hi, ow), bl = SHFL(R.lo, ow);
             LV(bb) = (lane < q) ? ((ka & 1) ? bl : bh) : 0.0;
             LV(done) = (lane < q) ? 0 : 1;
             LV(w) = 0.0;
             LV(beta) = 0.0;
             LV(ord) = 0;
         }
-        double yu[kQpN];
+        double yv[kQpN];
 #pragma unroll
-        for (int i = 0; i < kQpN; i++) yu[i] = 0.0;
+        for (int i = 0; i < kQpN; i++) yv[i] = 0.0;
         for (int s = 0; s < q; s++) {
             LANES {
                 double c2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) c2 += (i >= s) ? LV(c)[i] * LV(c)[i] : 0.0;
+                for (int j = 0; j < kQpN; j++) c2 += (pos[j] >= s) ? LV(c)[j] * LV(c)[j] : 0.0;
                 LV(val) = LV(done) ? DWBC_QP_INF : -c2;
                 LV(key) = lane;
             }
             double bn;
             int jp;
             WAVE_ARGMIN(val, key, bn, jp);
+            WSYNC();
+            LANES {
+                if (lane == jp) {
+#pragma unroll
+                    for (int j = 0; j < kQpN; j++) cbuf[j] = LV(c)[j];
+                }
+            }
+            WSYNC();
             double v[kQpN];
-            double nrm = 0.0, a0 = 0.0;
+            double nrm2 = 0.0, a0 = 0.0;
 #pragma unroll
-            for (int i = 0; i < kQpN; i++) {
-                const double ci = BCASTA(c, i, jp);
-                v[i] = (i >= s) ? ci : 0.0;
-                a0 = (i == s) ? ci : a0;
-                nrm += v[i] * v[i];
+            for (int j = 0; j < kQpN; j++) {
+                const double cj = cbuf[j];
+                v[j] = (pos[j] >= s) ? cj : 0.0;
+                a0 = (pos[j] == s) ? cj : a0;
+                nrm2 += v[j] * v[j];
             }
-            nrm = sqrt(nrm);
+            const double nrm = sqrt(nrm2);
             const double alpha = a0 > 0 ? -nrm : nrm;
-            double vn2 = 0.0;
+            const double vs0 = a0 - alpha;
+            const double vn2 = nrm2 - a0 * a0 + vs0 * vs0;
+            const double bt = vn2 > 0.0 ? 2.0 * fast_rcp(vn2) : 0.0;
 #pragma unroll
-            for (int i = 0; i < kQpN; i++) {
-                v[i] = (i == s) ? a0 - alpha : v[i];
-                vn2 += v[i] * v[i];
-            }
-            const double bt = vn2 > 0.0 ? 2.0 / vn2 : 0.0;
+            for (int j = 0; j < kQpN; j++) v[j] = (pos[j] == s) ? vs0 : v[j];
             LANES {
                 if (lane == s) { LV(beta) = bt; LV(ord) = jp; }
-                if (lane < kQpN) V[s * kQpN + lane] = pick12(v, lane);
                 if (lane == jp) {
                     LV(done) = 1;
-                    setidx12(LV(c), s, alpha);
+#pragma unroll
+                    for (int j = 0; j < kQpN; j++) {
+                        V[s * kQpN + j] = v[j];
+                        LV(c)[j] = (pos[j] == s) ? alpha : LV(c)[j];
+                    }
                 } else if (!LV(done)) {
                     double d = 0.0;
 #pragma unroll
-                    for (int i = 0; i < kQpN; i++) d += v[i] * LV(c)[i];
+                    for (int j = 0; j < kQpN; j++) d += v[j] * LV(c)[j];
                     d *= bt;
 #pragma unroll
-                    for (int i = 0; i < kQpN; i++) LV(c)[i] -= d * v[i];
+                    for (int j = 0; j < kQpN; j++) LV(c)[j] -= d * v[j];
                 }
             }
         }
-        // R^T y = b in pivot order: column of R for pivot s is lane ord[s]'s c[0..s]
+        // R^T y = b in pivot order: the column of R for pivot s is lane ord[s]'s c at positions 0..s
         for (int s = 0; s < q; s++) {
             const int os = BCASTI(ord, s);
             LANES {
                 double sacc = LV(bb), cs = 1.0;
 #pragma unroll
-                for (int ci = 0; ci < kQpN; ci++) {
-                    sacc -= (ci < s) ? LV(c)[ci] * yu[ci] : 0.0;
-                    cs = (ci == s) ? LV(c)[ci] : cs;
+                for (int j = 0; j < kQpN; j++) {
+                    sacc -= (pos[j] < s) ? LV(c)[j] * yv[j] : 0.0;
+                    cs = (pos[j] == s) ? LV(c)[j] : cs;
                 }
-                LV(val) = sacc / cs;
+                LV(val) = sacc * fast_rcp(cs);
             }
             const double ys = BCAST(val, os);
 #pragma unroll
-            for (int i = 0; i < kQpN; i++) yu[i] = (i == s) ? ys : yu[i];
+            for (int j = 0; j < kQpN; j++) yv[j] = (pos[j] == s) ? ys : yv[j];
         }
-        LANES { LV(w) = (lane < q) ? pick12(yu, lane) : 0.0; }
+        LANES { LV(w) = pick12(yv, lane); }  // x~ = Q [y; 0], variable `lane` in lane `lane`
         WSYNC();
         for (int s = q - 1; s >= 0; s--) {
             PL(double, vs);
             LANES {
                 LV(vs) = (lane < kQpN) ? V[s * kQpN + lane] : 0.0;
-                LV(val) = LV(vs) * LV(w);
+                if (lane < kQpN) pbuf[lane] = LV(vs) * LV(w);
             }
+            WSYNC();
             double d = 0.0;
 #pragma unroll
-            for (int i = 0; i < kQpN; i++) d += BCAST(val, i);
+            for (int i = 0; i < kQpN; i++) d += pbuf[i];
             d *= BCAST(beta, s);
             LANES { LV(w) -= d * LV(vs); }
+            WSYNC();
+        }
+        LANES {
+            if (lane < kQpN) pbuf[lane] = (lane < nv) ? LV(w) * ((lane >= t) ? cscale : 1.0) : 0.0;
         }
         WSYNC();
-        // x[j]: task variable j sits at position k + j, contact variable j at position j
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) {
-            const int pos = (j < t) ? (k + j) : (j - t);
-            const double wj = BCAST(w, (pos < kQpN && pos >= 0) ? pos : 0);
-            out.x[j] = (j < nv) ? ((j < t) ? wj : wj * cscale) : 0.0;
-        }
+        for (int j = 0; j < kQpN; j++) out.x[j] = pbuf[j];
+        WSYNC();
         // worst slack of the returned point, normalised by the unscaled row norm
         LANES {
             double d = 0.0, nr = 0.0;
