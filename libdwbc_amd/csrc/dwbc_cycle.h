@@ -33,7 +33,13 @@
         if (diag && th.tid == 0) diag[DG_TIME + (i)] = (int)(clock64() - t_start_);     \
     } while (0)
 #define DWBC_STAMP_INIT() const long long t_start_ = clock64()
+#define DWBC_FSTAMP(i)                                                                  \
+    do {                                                                                \
+        DWBC_SYNC();                                                                    \
+        if (dump && th.tid == 0) dump[dl.stamps + (i)] = (double)(clock64() - t_start_); \
+    } while (0)
 #else
+#define DWBC_FSTAMP(i) ((void)0)
 #define DWBC_STAMP(i) ((void)0)
 #define DWBC_STAMP_INIT() ((void)0)
 #endif

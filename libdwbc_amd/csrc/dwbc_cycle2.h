@@ -129,7 +129,7 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
 // s[kr], s[8+kr], ... by the uniform kb.  The "- delta_ik" of the multiplier is absorbed by storing the diagonal
 // shifted by one (s[j][j] = S[j][j] - 1), so that readlane(s[k], k) is already c_k - 1; the true diagonal lives in dg.
 template <int NN>
-DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg)) {
+DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg), int npiv = NN) {
     DWBC_LANE_DECL;
     static_assert(NN <= 40, "five candidate registers per kr");
     int ok = 1;
@@ -137,11 +137,11 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg)) {
 #pragma unroll
         for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - 1.0 : LV(s)[i];
     }
-    for (int kb = 0; kb < 5; kb++) {
+    for (int kb = 0; kb < (NN + 7) / 8; kb++) {
 #pragma unroll
         for (int kr = 0; kr < 8; kr++) {
             const int k = 8 * kb + kr;
-            if (k < NN) {
+            if (k < NN && k < npiv) {
                 double d = BCAST(dg, k);
                 if (!(d > 0.0)) { ok = 0; d = 1.0; }
                 const double rp = fast_rcp(d);
@@ -185,6 +185,7 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg)) {
 // pivot is not positive (rank deficient block => status 0, where the reference would return a pseudo-inverse).
 DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, int ldo, double *colbuf) {
     DWBC_LANE_DECL;
+    (void)colbuf;
     PLA(double, s, 12);
     PL(double, dg);
     DWBC_SYNC();
@@ -194,7 +195,8 @@ DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, 
         for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] : 0.0;
         LV(dg) = (lane < n) ? Ain[col * lda + col] : 1.0;
     }
-    const int ok = sweep_inverse_regs<12>(s, dg, colbuf);
+    const int ok = sweep_inverse_rl<12>(s, dg, n);
+    DWBC_SYNC();
     LANES {
         if (lane < n) {
 #pragma unroll
@@ -412,26 +414,31 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     DWBC_SYNC();
     double *JC = L + S::c_JC, *Y = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
+    DWBC_FSTAMP(0);
     for (int idx = th.tid; idx < C * N; idx += NT) { JC[idx] = 0.0; Y[idx] = 0.0; JbT[idx] = 0.0; }  // (the staged A is dead)
     DWBC_SYNC();
     for (int a = 0; a < nc; a++)
         point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JC, N, 6 * a, 6, 0);
     DWBC_SYNC();
+    DWBC_FSTAMP(1);  // J_C built
     // Y = J_C A^-1: column `lane` of Y is J_C times lane's column of A^-1 (outer loop rolled: code size)
     for (int p = 0; p < cd; p++) {
         LANES {
-            double acc = 0.0;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};  // four chains: a single accumulator serialises on the FMA latency
 #pragma unroll
-            for (int i = 0; i < N; i++) acc += JC[p * N + i] * LV(s)[i];
+            for (int i = 0; i < N; i++) a4[i & 3] += JC[p * N + i] * LV(s)[i];
+            const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
             if (lane < N) Y[p * N + lane] = acc;
         }
     }
     DWBC_SYNC();
+    DWBC_FSTAMP(2);  // Y
     mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);  // J A^-1 J^T
     if (cd > 0) {
         if (!spd_inverse_small(L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
     }
     DWBC_SYNC();
+    DWBC_FSTAMP(3);  // Lambda_c
     {
         PLA(double, yc, C);
         LANES {
@@ -448,6 +455,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
     }
     DWBC_SYNC();
+    DWBC_FSTAMP(4);  // JbT
     // A^-1 N_c = A^-1 - Y^T J̄^T   (wbd.cpp:117-118 without materialising N_c), one rank-1 update per contact row
     for (int p = 0; p < cd; p++) {
         LANES {
@@ -468,15 +476,18 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
         }
     }
+    DWBC_FSTAMP(5);  // AiNc
     // gravity pre-vector (A^-1 N_c G) and P_C = J̄^T G  (wbd.cpp:186-192)
     LANES {
-        double acc = 0.0;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < N; i++) acc += LV(s)[i] * L[S::G + i];
+        for (int i = 0; i < N; i++) a4[i & 3] += LV(s)[i] * L[S::G + i];
+        const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         if (lane < N) L[S::c_vec + lane] = acc;
     }
     mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
     DWBC_STAMP(2);  // J_C, Lambda_c, J̄, A^-1 N_c done
+    DWBC_FSTAMP(6);  // vec, PC
     // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
     double *Vb = L + S::c_Vb, *VG = L + S::c_VG;
     if (k > 0) {
@@ -499,6 +510,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             Vb[idx] = acc;
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(7);  // Vb
         for (int idx = th.tid; idx < k * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             double acc = 0.0;
@@ -506,14 +518,27 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
             L[S::c_s2 + idx] = acc;
         }
-        const double cond = gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
-        if (!(cond > 1e-13)) st_contact = 0;
-        mm_nn<NT>(th, L + S::NwJw, k, Vb, k, L + S::c_s2, k, M, k, k);  // NwJw = Vb (J̄[0:k,6:] Vb)^-1 (wbd.cpp:128)
-        DWBC_SYNC();
-        mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
-        spd_inverse_small(L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
-        mm_nn<NT>(th, VG, k, Vb, k, L + S::c_s2, k, M, k, k);             // P = VG Vb^T
-        DWBC_SYNC();
+        DWBC_FSTAMP(8);  // JV
+        // NwJw = Vb (J̄1 Vb)^-1 (wbd.cpp:128) written with SPD inverses only: with G = Vb^T Vb, VG = Vb G^-1 and
+        // JV = J̄[0:k,6:] Vb:  NwJw = VG JV^T (JV G^-1 JV^T)^-1  (same matrix: both satisfy J̄1 NwJw = I on span(Vb))
+        DWBC_FSTAMP(8);
+        {
+            double *JV = L + S::c_s2, *Gi = L + S::c_s2 + 36, *Bm = L + S::c_s2 + 72, *Sm6 = L + S::c_s2 + 108;  // 4 x (6x6) in C*C = 144
+            mm_tn<NT>(th, Gi, k, Vb, k, Vb, k, k, M, k);                      // G
+            DWBC_SYNC();
+            spd_inverse_small(Gi, k, k, Gi, k, L + S::c_s1);                   // G^-1
+            mm_nn<NT>(th, VG, k, Vb, k, Gi, k, M, k, k);                       // VG = Vb G^-1   (projector P = VG Vb^T)
+            mm_nn<NT>(th, Bm, k, JV, k, Gi, k, k, k, k);                       // B = JV G^-1
+            DWBC_SYNC();
+            mm_nt<NT>(th, Sm6, k, Bm, k, JV, k, k, k, k);                      // S = B JV^T  (SPD)
+            DWBC_SYNC();
+            if (!spd_inverse_small(Sm6, k, k, Sm6, k, L + S::c_s1)) st_contact = 0;
+            mm_nn<NT>(th, Bm, k, Sm6, k, JV, k, k, k, k);                      // X = S^-1 JV
+            DWBC_SYNC();
+            mm_nt<NT>(th, L + S::NwJw, k, VG, k, Bm, k, M, k, k);              // NwJw = VG X^T
+            DWBC_SYNC();
+        }
+        DWBC_FSTAMP(12);  // VG
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
         for (int idx = th.tid; idx < cd * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
@@ -533,6 +558,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
     }
     DWBC_STAMP(12);  // (diagnostic) NwJw / projector block done
+    DWBC_FSTAMP(13);  // FNl
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
@@ -558,17 +584,21 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int r = 0; r < T; r++) {
             LANES {
-                double acc = 0.0;
+                double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int i = 0; i < N; i++) acc += Jt[r * N + i] * LV(s)[i];
+                for (int i = 0; i < N; i++) a4[i & 3] += Jt[r * N + i] * LV(s)[i];
+                const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 if (lane < N) T1[r * N + lane] = acc;
                 if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
             }
         }
         DWBC_SYNC();
+        if (lv == 0) DWBC_FSTAMP(14);  // level 0: Jt + T1
         mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
         if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
+        if (lv == 0) DWBC_FSTAMP(15);  // level 0: J A J^T
         spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        if (lv == 0) DWBC_FSTAMP(16);  // level 0: Lambda_task
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
         if (lv == NLV - 1)
             for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
@@ -579,6 +609,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     DWBC_SYNC();
     DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
+    DWBC_FSTAMP(17);  // all task levels
     // ---- W^+ = (W + alpha P)^-1 - P / alpha, column c of W held by lane c (moved down from lane 6 + c)
     PLA(double, w, M);
     PL(double, dw);
@@ -619,7 +650,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LV(dw) = 1.0;
         }
     }
+    DWBC_FSTAMP(18);  // W + alpha P assembled
     if (!sweep_inverse_rl<M>(w, dw)) st_contact = 0;
+    DWBC_FSTAMP(19);  // W sweep
     LANES {
         if (k > 0) {
 #pragma unroll
@@ -649,6 +682,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_SYNC();
     DWBC_STAMP(4);  // W^+ and gravity compensation done
 
+    DWBC_FSTAMP(20);  // W^+ correction + gravity torque
     // ================= stage 3a: task-space dynamics for every level (wbd.cpp:207-261) =================
     int rankbad = 0;
     for (int lv = 0; lv < su.n_levels; lv++) {
@@ -669,16 +703,19 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int r = 0; r < T; r++) {
             LANES {
-                double acc = 0.0;
+                double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int i = 0; i < M; i++) acc += Q[r * M + i] * LV(w)[i];
+                for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
+                const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
             }
         }
         DWBC_SYNC();
+        if (lv == 0) DWBC_FSTAMP(21);  // level 0: Q, QW
         mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
         const int cond = spd_inverse_small(L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
         DWBC_SYNC();
+        if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
         // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
         double *Ul = L + S::U + lv * M * T;
         double *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;

@@ -62,7 +62,7 @@ enum DiagField {
 struct DumpLayout {
     int N, M;
     int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
-    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, total;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, stamps, total;
     __host__ __device__ static DumpLayout make(int n) {
         DumpLayout d;
         d.N = n;
@@ -91,6 +91,7 @@ struct DumpLayout {
         d.contact_qp = o; o += L * K;
         d.cf_redis = o; o += K;
         d.qp_viol = o; o += L + 1;
+        d.stamps = o; o += 32;  // fine-grained stage stamps (diagnostic build only)
         d.total = o;
         return d;
     }

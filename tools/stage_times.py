@@ -17,6 +17,7 @@ wbc.add_task(0, D.TASK_LINK_6D, 0)
 wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
 wbc.set_torque_limit(np.array(cases.TAU_LIM))
 q, fl, fs = cases.synth_batch(B, seed=20251226 + 2)
+wbc.enable_dump(True)
 wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
 for _ in range(3):
     wbc.solve()
@@ -35,3 +36,16 @@ for i, n in enumerate(names):
     prev = med[i]
 print("diag stamps 12,13 (cumulative):", med[12], med[13])
 print("qp iters median", np.median(d[:, 4:9], axis=0), "nact", np.median(d[:, 9:14], axis=0))
+
+import ctypes
+nb = wbc._L.dwbc_batch_field_bytes(wbc._h, 49)
+raw = np.zeros(nb // 8)
+wbc._L.dwbc_batch_get(wbc._h, 49, raw.ctypes.data, nb)
+raw = raw.reshape(B, -1)
+st = np.median(raw[:, -32:], axis=0)
+fn = ["start stage1", "J_C", "Y", "Lambda_c", "JbT", "AiNc", "vec,PC", "Vb", "JV", "gj6", "NwJw", "gram+inv", "VG", "FNl", "L0 Jt+T1", "L0 JAJ", "L0 Lambda_t", "all levels", "W+aP", "W sweep", "W corr+grav", "L0 Q,QW", "L0 QWQ inv"]
+prev = st[0]
+print("fine stamps (dump enabled, so absolute values include dump stores):")
+for i, n in enumerate(fn):
+    print(f"  {n:16s} {st[i]-prev:10.0f} {st[i]:10.0f}")
+    prev = st[i]
