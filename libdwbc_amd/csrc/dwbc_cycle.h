@@ -370,7 +370,8 @@ DWBC_DEV double cone_row(int r, double lx, double ly, double mu, double muz, con
 // ----------------------------------------------------------------------------------------------
 template <int N, int NB, int NT>
 DWBC_DEVN void point_jacobian(Thr th, const double *Rw, const double *pw, const double *aw, const int *topo, int nb, int link,
-                             const double *P, double *J, int ld, int row0, int nrows, int rsel) {
+                             const double *P, double *J, int ld, int row0, int nrows, int rsel, int cs = 1) {
+    // element (row, col) is stored at J[row * ld + col * cs]  (ld = N, cs = 1: row-major;  ld = 1, cs = rows: transposed)
     // rsel: 0 -> rows 0..5, 1 -> linear rows only (0..2), 2 -> angular rows only (3..5)
     for (int j = th.tid; j < N; j += NT) {
         double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
@@ -395,11 +396,11 @@ DWBC_DEVN void point_jacobian(Thr th, const double *Rw, const double *pw, const 
             }
         }
         if (rsel == 0) {
-            for (int a = 0; a < 3; a++) { J[(row0 + a) * ld + j] = lin[a]; J[(row0 + 3 + a) * ld + j] = ang[a]; }
+            for (int a = 0; a < 3; a++) { J[(row0 + a) * ld + j * cs] = lin[a]; J[(row0 + 3 + a) * ld + j * cs] = ang[a]; }
         } else if (rsel == 1) {
-            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j] = lin[a];
+            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j * cs] = lin[a];
         } else {
-            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j] = ang[a];
+            for (int a = 0; a < 3; a++) J[(row0 + a) * ld + j * cs] = ang[a];
         }
     }
     (void)nrows;

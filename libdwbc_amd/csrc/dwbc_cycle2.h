@@ -413,61 +413,75 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
     }
     DWBC_SYNC();
-    double *JC = L + S::c_JC, *Y = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
+    // J_C and Y = J_C A^-1 are kept TRANSPOSED in LDS (N x C): all C contact rows of one column are 96 contiguous bytes,
+    // so "own column . all rows" products fetch them with broadcast b128 reads and run C independent FMA chains
+    double *JCt = L + S::c_JC, *Yt = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
     DWBC_FSTAMP(0);
-    for (int idx = th.tid; idx < C * N; idx += NT) { JC[idx] = 0.0; Y[idx] = 0.0; JbT[idx] = 0.0; }  // (the staged A is dead)
+    for (int idx = th.tid; idx < C * N; idx += NT) { JCt[idx] = 0.0; Yt[idx] = 0.0; JbT[idx] = 0.0; }  // (the staged A is dead)
     DWBC_SYNC();
     for (int a = 0; a < nc; a++)
-        point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JC, N, 6 * a, 6, 0);
+        point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JCt, 1, 6 * a, 6, 0, C);
     DWBC_SYNC();
     DWBC_FSTAMP(1);  // J_C built
-    // Y = J_C A^-1: column `lane` of Y is J_C times lane's column of A^-1 (outer loop rolled: code size)
-    for (int p = 0; p < cd; p++) {
-        LANES {
-            double a4[4] = {0.0, 0.0, 0.0, 0.0};  // four chains: a single accumulator serialises on the FMA latency
+    // Y[:, lane] = J_C * (lane's column of A^-1)
+    LANES {
+        double yc[C];
 #pragma unroll
-            for (int i = 0; i < N; i++) a4[i & 3] += JC[p * N + i] * LV(s)[i];
-            const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-            if (lane < N) Y[p * N + lane] = acc;
+        for (int p = 0; p < C; p++) yc[p] = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double si = LV(s)[i];
+#pragma unroll
+            for (int p = 0; p < C; p++) yc[p] += JCt[i * C + p] * si;
+        }
+        if (lane < N) {
+#pragma unroll
+            for (int p = 0; p < C; p++) Yt[lane * C + p] = yc[p];
         }
     }
     DWBC_SYNC();
     DWBC_FSTAMP(2);  // Y
-    mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);  // J A^-1 J^T
+    for (int idx = th.tid; idx < cd * cd; idx += NT) {  // J A^-1 J^T = Y J_C^T
+        const int i = idx / cd, j = idx - i * cd;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < N; c++) a4[c & 3] += Yt[c * C + i] * JCt[c * C + j];
+        L[S::c_s2 + idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    }
     if (cd > 0) {
         if (!spd_inverse_small(L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
     }
     DWBC_SYNC();
     DWBC_FSTAMP(3);  // Lambda_c
-    {
-        PLA(double, yc, C);
-        LANES {
+    // J̄^T = Lambda J A^-1 (wbd.cpp:116), then A^-1 N_c = A^-1 - Y^T J̄^T (wbd.cpp:117-118, N_c never materialised)
+    LANES {
+        double yc[C], jb[C];
+        const int col = lane < N ? lane : 0;
 #pragma unroll
-            for (int p2 = 0; p2 < C; p2++) LV(yc)[p2] = Y[p2 * N + (lane < N ? lane : 0)];
+        for (int p = 0; p < C; p++) yc[p] = Yt[col * C + p];
+#pragma unroll
+        for (int p = 0; p < C; p++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < C; p2++) acc += ((p < cd && p2 < cd) ? Lam[p * cd + p2] : 0.0) * yc[p2];
+            jb[p] = acc;
+            if (lane < N) JbT[p * N + lane] = acc;
         }
-        for (int p = 0; p < cd; p++) {  // J̄^T = Lambda J A^-1 (wbd.cpp:116)
-            LANES {
-                double acc = 0.0;
+        double dsub = 0.0;
 #pragma unroll
-                for (int p2 = 0; p2 < C; p2++) acc += ((p2 < cd) ? Lam[p * cd + p2] : 0.0) * LV(yc)[p2];
-                if (lane < N) JbT[p * N + lane] = acc;
-            }
-        }
-    }
-    DWBC_SYNC();
-    DWBC_FSTAMP(4);  // JbT
-    // A^-1 N_c = A^-1 - Y^T J̄^T   (wbd.cpp:117-118 without materialising N_c), one rank-1 update per contact row
-    for (int p = 0; p < cd; p++) {
-        LANES {
-            const double jbp = JbT[p * N + (lane < N ? lane : 0)];
-            LV(dg) -= Y[p * N + (lane < N ? lane : 0)] * jbp;
+        for (int p = 0; p < C; p++) dsub += yc[p] * jb[p];
+        LV(dg) -= dsub;
 #pragma unroll
-            for (int i = 0; i < N; i++) LV(s)[i] -= Y[p * N + i] * jbp;
+        for (int i = 0; i < N; i++) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int p = 0; p < C; p += 2) { a0 += Yt[i * C + p] * jb[p]; a1 += Yt[i * C + p + 1] * jb[p + 1]; }
+            LV(s)[i] -= a0 + a1;
         }
     }
     DWBC_SYNC();
     if (dump) {
-        for (int idx = th.tid; idx < cd * N; idx += NT) { dump[dl.J_C + idx] = JC[idx]; dump[dl.J_C_INV_T + idx] = JbT[idx]; }
+        for (int idx = th.tid; idx < cd * N; idx += NT) { dump[dl.J_C + idx] = JCt[(idx % N) * C + idx / N]; dump[dl.J_C_INV_T + idx] = JbT[idx]; }
         for (int idx = th.tid; idx < cd * cd; idx += NT) dump[dl.Lambda_c + idx] = Lam[idx];
         LANES {
             if (lane < N) {
@@ -501,12 +515,13 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const double m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
             const double m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
             const double m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
-            const double *J0 = JC, *J1 = JC + 6 * ci * N;
             const int col = 6 + r;
-            double acc = -f2[0] * J0[0 * N + col] - f2[1] * J0[1 * N + col] - f2[2] * J0[2 * N + col];
-            acc += m1x * J0[3 * N + col] + m1y * J0[4 * N + col] + m1z * J0[5 * N + col];
-            acc += f2[0] * J1[0 * N + col] + f2[1] * J1[1 * N + col] + f2[2] * J1[2 * N + col];
-            acc += m2[0] * J1[3 * N + col] + m2[1] * J1[4 * N + col] + m2[2] * J1[5 * N + col];
+            const double *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
+            const int o1 = 6 * ci;
+            double acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
+            acc += m1x * Jc[3] + m1y * Jc[4] + m1z * Jc[5];
+            acc += f2[0] * Jc[o1 + 0] + f2[1] * Jc[o1 + 1] + f2[2] * Jc[o1 + 2];
+            acc += m2[0] * Jc[o1 + 3] + m2[1] * Jc[o1 + 4] + m2[2] * Jc[o1 + 5];
             Vb[idx] = acc;
         }
         DWBC_SYNC();
