@@ -851,6 +851,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + slot * kQpLd + a] = qres.act[a];
         }
         if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+        if (dump && th.tid == 0 && qi == 0)
+            for (int i_ = 0; i_ < 8; i_++) dump[dl.stamps + 23 + i_] = (double)qres.tm[i_];
+#endif
         if (is_task) DWBC_STAMP(8 + 3 * qi);
         const double *x = L + S::qp_x;
         if (is_task) {

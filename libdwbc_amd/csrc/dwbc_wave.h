@@ -92,6 +92,23 @@ DWBC_WDEV void setidx12(double *arr, int q, double v) {
         for (int l_ = 1; l_ < 64; l_++)                                                            \
             if ((val)[l_] < out_v || ((val)[l_] == out_v && (key)[l_] < out_k)) { out_v = (val)[l_]; out_k = (key)[l_]; } \
     } while (0)
+// lane of the smallest value after rounding to float (first such lane); the selection rules that use it (most violated
+// row, QR pivot column) tolerate a 1e-7 relative tie-break
+#define WAVE_ARGMIN_F32(val, out_lane)                                                             \
+    do {                                                                                           \
+        float m_ = (float)(val)[0];                                                                \
+        out_lane = 0;                                                                              \
+        for (int l_ = 1; l_ < 64; l_++)                                                            \
+            if ((float)(val)[l_] < m_) { m_ = (float)(val)[l_]; out_lane = l_; }                   \
+    } while (0)
+// exact arg-min over lanes 16..31 only
+#define WAVE_ARGMIN_ROW1(val, key, out_v, out_k)                                                   \
+    do {                                                                                           \
+        out_v = (val)[16];                                                                         \
+        out_k = (key)[16];                                                                         \
+        for (int l_ = 17; l_ < 32; l_++)                                                           \
+            if ((val)[l_] < out_v || ((val)[l_] == out_v && (key)[l_] < out_k)) { out_v = (val)[l_]; out_k = (key)[l_]; } \
+    } while (0)
 #else
 namespace dwbc {
 // min over the wave of a 64-bit unsigned key with DPP row shifts / row broadcasts (gfx9 family), result uniform
@@ -115,6 +132,45 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x)
     const int hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
+// same reduction restricted to DPP row 1 (lanes 16..31); the result is read from lane 31
+__device__ __forceinline__ unsigned long long row1_min_u64(unsigned long long x) {
+#define DWBC_DPP_STEP(ctrl)                                                                                \
+    {                                                                                                      \
+        const int lo_ = (int)(unsigned)(x & 0xffffffffull), hi_ = (int)(unsigned)(x >> 32);                \
+        const int olo_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, 0xf, 0xf, false);                     \
+        const int ohi_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, 0xf, 0xf, false);                     \
+        const unsigned long long o_ = ((unsigned long long)(unsigned)ohi_ << 32) | (unsigned)olo_;         \
+        x = o_ < x ? o_ : x;                                                                               \
+    }
+    DWBC_DPP_STEP(0x111)
+    DWBC_DPP_STEP(0x112)
+    DWBC_DPP_STEP(0x114)
+    DWBC_DPP_STEP(0x118)
+#undef DWBC_DPP_STEP
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(x & 0xffffffffull), 31);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 31);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// lane of the wave minimum of a value rounded to float: six single-register DPP steps and a ballot
+__device__ __forceinline__ int wave_argmin_f32(double v) {
+    const float f = (float)v;
+    float m = f;
+#define DWBC_DPP_STEP(ctrl, rmask)                                                                         \
+    {                                                                                                      \
+        const int o_ = __builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), ctrl, rmask, 0xf, false); \
+        m = fminf(m, __int_as_float(o_));                                                                  \
+    }
+    DWBC_DPP_STEP(0x111, 0xf)
+    DWBC_DPP_STEP(0x112, 0xf)
+    DWBC_DPP_STEP(0x114, 0xf)
+    DWBC_DPP_STEP(0x118, 0xf)
+    DWBC_DPP_STEP(0x142, 0xa)
+    DWBC_DPP_STEP(0x143, 0xc)
+#undef DWBC_DPP_STEP
+    const float mall = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    const unsigned long long b = __ballot(f == mall);
+    return b ? (int)__builtin_ctzll(b) : 0;
+}
 // order-preserving map double -> u64, low 7 bits replaced by the lane so that keys are unique
 __device__ __forceinline__ unsigned long long argmin_key(double v, int lane) {
     unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -126,6 +182,14 @@ __device__ __forceinline__ unsigned long long argmin_key(double v, int lane) {
 #define WAVE_ARGMIN(val, key, out_v, out_k)                                                        \
     do {                                                                                           \
         const unsigned long long m_ = dwbc::wave_min_u64(dwbc::argmin_key((val), lane));           \
+        const int wl_ = (int)(m_ & 127ull);                                                        \
+        out_v = dwbc::readlane_f64((val), wl_);                                                    \
+        out_k = dwbc::readlane_i32((key), wl_);                                                    \
+    } while (0)
+#define WAVE_ARGMIN_F32(val, out_lane) out_lane = dwbc::wave_argmin_f32(val)
+#define WAVE_ARGMIN_ROW1(val, key, out_v, out_k)                                                   \
+    do {                                                                                           \
+        const unsigned long long m_ = dwbc::row1_min_u64(dwbc::argmin_key((val), lane));           \
         const int wl_ = (int)(m_ & 127ull);                                                        \
         out_v = dwbc::readlane_f64((val), wl_);                                                    \
         out_k = dwbc::readlane_i32((key), wl_);                                                    \

@@ -49,3 +49,7 @@ print("fine stamps (dump enabled, so absolute values include dump stores):")
 for i, n in enumerate(fn):
     print(f"  {n:16s} {st[i]-prev:10.0f} {st[i]:10.0f}")
     prev = st[i]
+qn = ["post-loop", "slack+argmin", "publish n, r, z", "step/drop", "commit", "rows+QR", "R^T y", "reflect+feas"]
+print("level-0 QP solver sections (cycles, summed over iterations):")
+for i, n in enumerate(qn):
+    print(f"  {n:16s} {st[23 + i]:10.0f}")
