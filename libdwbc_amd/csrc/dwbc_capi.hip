@@ -28,16 +28,25 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const Ba
     cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
 }
 
-// register-resident version (dwbc_cycle2.h): the default
-template <int N, int NB, int NLV, int NT>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
-    static_assert(NT == 64, "one wavefront per instance");
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int inst = blockIdx.x;
-    if (inst >= io.B) return;
-    Thr th{(int)threadIdx.x};
-    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);
+// register-resident version (dwbc_cycle2.h): the default.  Two builds of the same body:
+//   _v2   amdgpu_waves_per_eu(2): VGPR + AGPR <= 256, so a fifth workgroup of a CU (the LDS map allows 5 at <= 31 KB) can
+//         share a SIMD -- the throughput build for batches larger than 4 instances per CU
+//   _v2w  no register cap (one wave per SIMD): ~7 % shorter single-instance latency -- used while B <= 4 x CUs
+#define DWBC_V2_BODY                                                                     \
+    static_assert(NT == 64, "one wavefront per instance");                               \
+    extern __shared__ __attribute__((aligned(16))) double lds[];                         \
+    const int inst = blockIdx.x;                                                         \
+    if (inst >= io.B) return;                                                            \
+    Thr th{(int)threadIdx.x};                                                            \
+    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
     cycle_instance_v2<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
+    DWBC_V2_BODY
+}
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
+    DWBC_V2_BODY
 }
 
 namespace {
@@ -58,17 +67,18 @@ struct KernelEntry {
     int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
     void (*fn)(const Setup, const BatchIO);
     int lds_bytes;
+    void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
 // index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 const KernelEntry kKernels[] = {
-    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes},
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes},
-    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes},
-    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes},
+    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT>},
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
+    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT>},
+    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT>},
 };
 const KernelEntry kKernelsV1[] = {
-    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes},
+    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
 };
 }  // namespace
 
@@ -94,6 +104,7 @@ struct dwbc_batch {
     std::vector<unsigned char> h_flags;
     bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
     bool attr_set = false;
+    int n_cu = 0;
     DumpLayout dl{};
 };
 
@@ -374,9 +385,15 @@ static int launch(dwbc_batch *b) {
     io.topo = b->d_topo;
     if (!b->attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
+        if (b->kern->fn_wide)
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn_wide), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, b->device));
+        b->n_cu = prop.multiProcessorCount;
         b->attr_set = true;
     }
-    hipLaunchKernelGGL(b->kern->fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
+    const bool wide = b->kern->fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
+    hipLaunchKernelGGL(wide ? b->kern->fn_wide : b->kern->fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
     HIP_OK(hipGetLastError());
     return 1;
 }

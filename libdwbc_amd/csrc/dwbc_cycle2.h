@@ -53,15 +53,15 @@ struct Lds2 {
     static constexpr int c_Vb = tmp;                           // M x K
     static constexpr int c_VG = c_Vb + M * K;                  // M x K
     static constexpr int c_vec = c_VG + M * K;                 // N
-    static constexpr int c_col = c_vec + N;                    // N
-    static constexpr int c_Lt = c_col + N;                     // levels x T x T
+    static constexpr int c_Lt = c_vec + N;                     // levels x T x T
     static constexpr int c_ov = c_Lt + NLV * T * T;            // two overlaid groups:
     //   (1) contact algebra
     static constexpr int c_JC = c_ov;
     static constexpr int c_Y = c_JC + C * N;
-    static constexpr int c_Lam = c_Y + C * N;
-    static constexpr int c_s1 = c_Lam + C * C;                 // C x 2C
-    static constexpr int c_s2 = c_s1 + C * 2 * C;              // C x C
+    static constexpr int c_s1 = c_Y + C * N;                   // C x K  (wrench-map scratch; later the diagonal of W)
+    static constexpr int c_col = c_s1;                         // M  (W stage only)
+    static constexpr int c_s2 = c_s1 + max2(C * K, M);         // C x C  (input of the small SPD inverses)
+    static constexpr int c_Lam = c_s2;                         // Lambda_c is inverted in place
     static constexpr int c_end1 = c_s2 + C * C;
     //   (2) task-space dynamics (after NwJw / projector are done; keeps c_s1/c_s2 for its small inverses)
     static constexpr int c_Jt = c_ov;                          // T x N
