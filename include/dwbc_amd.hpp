@@ -69,6 +69,8 @@ class RobotData {
     Vec q_system_, q_dot_system_, q_ddot_system_;
     Vec G_, torque_grav_, torque_task_, torque_contact_, torque_limit_;
     Mat A_, A_inv_, J_C, Lambda_contact, J_C_INV_T, N_C, A_inv_N_C, W, W_inv, NwJw;
+    Mat CMM_, J_com_, com_inertia_;  // include/dwbc.h:114, link_.back().jac_com_, link_.back().inertia
+    Vec3 com_pos;                    // include/dwbc.h:141
     Vec P_C, cf_redis_qp_;
     bool torque_limit_set_ = false;
     std::vector<TaskSpaceView> ts_;
@@ -233,6 +235,8 @@ class RobotData {
         W_inv = fetch(DWBC_W_INV, m, m); NwJw = fetch(DWBC_NWJW, m, k, k > 0 ? k : 1);
         Mat g = fetch(DWBC_G, 1, n), pc = fetch(DWBC_P_C, 1, cd, 12);
         G_ = g.d; P_C = pc.d;
+        CMM_ = fetch(DWBC_CMM, 6, n); J_com_ = fetch(DWBC_J_COM, 6, n); com_inertia_ = fetch(DWBC_COM_INERTIA, 3, 3);
+        { Mat cp = fetch(DWBC_COM, 1, 3); com_pos = Vec3(cp.d[0], cp.d[1], cp.d[2]); }
         W = Mat(m, m);
         for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) W(i, j) = A_inv_N_C(6 + i, 6 + j);
         N_C = Mat(n, n);  // N_C = I - J_C^T J_C_INV_T (wbd.cpp:117)

@@ -68,7 +68,11 @@ enum dwbc_field {
     DWBC_LAMBDA_TASK = 46,/* (4, 36)  ts_[l].Lambda_task_ (row stride t_l) */
     DWBC_J_KT = 47,       /* (4, m*6) ts_[l].J_kt_ (row stride t_l)        */
     DWBC_QP_VIOL = 48,    /* (5)      worst normalised slack of each QP's returned point */
-    DWBC_DUMP_RAW = 49    /* whole dump record */
+    DWBC_DUMP_RAW = 49,   /* whole dump record */
+    DWBC_CMM = 50,        /* (6, n)   CMM_                      (src/dwbc.cpp:336) */
+    DWBC_COM = 51,        /* (3)      com_pos                   (src/dwbc.cpp:322) */
+    DWBC_COM_INERTIA = 52,/* (3, 3)   link_.back().inertia      (src/dwbc.cpp:343) */
+    DWBC_J_COM = 53       /* (6, n)   link_.back().jac_com_     (src/dwbc.cpp:352) */
 };
 
 const char *dwbc_last_error(void);

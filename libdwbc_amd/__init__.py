@@ -9,4 +9,6 @@ from .batch import (  # noqa: F401
     Batch, DwbcError, Model,
 )
 
-__all__ = ["Batch", "Model", "DwbcError"]
+from .rl_bridge import RlWBCBridge  # noqa: F401,E402
+
+__all__ = ["Batch", "Model", "DwbcError", "RlWBCBridge"]

@@ -457,6 +457,9 @@ size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
         case DWBC_J_KT: return B * kMaxLevels * m * 6 * 8;
         case DWBC_QP_VIOL: return B * (kMaxLevels + 1) * 8;
         case DWBC_DUMP_RAW: return B * (size_t)b->dl.total * 8;
+        case DWBC_CMM: case DWBC_J_COM: return B * 6 * n * 8;
+        case DWBC_COM: return B * 3 * 8;
+        case DWBC_COM_INERTIA: return B * 9 * 8;
         default: return 0;
     }
 }
@@ -507,6 +510,10 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
         case DWBC_W_INV: off = dl.W_inv; len = (int)(m * m); break;
         case DWBC_NWJW: off = dl.NwJw; len = (int)m * K; break;
         case DWBC_G: off = dl.G; len = n; break;
+        case DWBC_CMM: off = dl.CMM; len = 6 * n; break;
+        case DWBC_J_COM: off = dl.J_com; len = 6 * n; break;
+        case DWBC_COM: off = dl.com; len = 3; break;
+        case DWBC_COM_INERTIA: off = dl.com_inertia; len = 9; break;
         case DWBC_P_C: off = dl.P_C; len = 12; break;
         case DWBC_LINK_R: off = dl.link_R; len = kMaxBodies * 9; break;
         case DWBC_LINK_P: off = dl.link_p; len = kMaxBodies * 3; break;

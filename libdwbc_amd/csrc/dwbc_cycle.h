@@ -407,6 +407,60 @@ DWBC_DEVN void point_jacobian(Thr th, const double *Rw, const double *pw, const 
 }
 
 // ----------------------------------------------------------------------------------------------
+// Centroidal quantities of RobotData::UpdateKinematics (reference src/dwbc.cpp:318-352), written to the dump record
+// only: com_pos, CMM_ = cm_rot6 * A[0:6,:], COM inertia, jac_com_ = SI_body^-1 CMM_.  None of them feeds the OSF
+// torque path (G_ is taken from A directly), so they are produced on request (dwbc_batch_enable_dump).
+//   A: staged mass matrix (row stride lda), R0: pelvis rotation, q0: base position, mt: total mass
+// ----------------------------------------------------------------------------------------------
+template <int N, int NT>
+DWBC_DEV void dump_centroidal(Thr th, const double *A, int lda, const double *R0, const double *q0, double mt, double *dump,
+                              const DumpLayout &dl) {
+    double c[3];
+    {
+        // skm = R0 * A[3:6,0:3] / mt ;  com_from_pelv = (skm(2,1), skm(0,2), skm(1,0))
+        const int ra[3] = {2, 0, 1}, cb[3] = {1, 2, 0};
+        for (int e = 0; e < 3; e++) {
+            double acc = 0.0;
+            for (int b = 0; b < 3; b++) acc += R0[ra[e] * 3 + b] * A[(3 + b) * lda + cb[e]];
+            c[e] = acc / mt;
+        }
+    }
+    // COM inertia about the COM, world frame
+    double I[9];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            double acc = 0.0;
+            for (int u = 0; u < 3; u++)
+                for (int v = 0; v < 3; v++) acc += R0[a * 3 + u] * A[(3 + u) * lda + 3 + v] * R0[b * 3 + v];
+            const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+            I[a * 3 + b] = acc - mt * ((a == b ? cc : 0.0) - c[a] * c[b]);  // skew(c) skew(c)^T = |c|^2 I - c c^T
+        }
+    const double det = I[0] * (I[4] * I[8] - I[5] * I[7]) - I[1] * (I[3] * I[8] - I[5] * I[6]) + I[2] * (I[3] * I[7] - I[4] * I[6]);
+    const double id = 1.0 / det;
+    const double Ii[9] = {(I[4] * I[8] - I[5] * I[7]) * id, (I[2] * I[7] - I[1] * I[8]) * id, (I[1] * I[5] - I[2] * I[4]) * id,
+                          (I[5] * I[6] - I[3] * I[8]) * id, (I[0] * I[8] - I[2] * I[6]) * id, (I[2] * I[3] - I[0] * I[5]) * id,
+                          (I[3] * I[7] - I[4] * I[6]) * id, (I[1] * I[6] - I[0] * I[7]) * id, (I[0] * I[4] - I[1] * I[3]) * id};
+    if (th.tid == 0) {
+        for (int a = 0; a < 3; a++) dump[dl.com + a] = c[a] + q0[a];
+        for (int a = 0; a < 9; a++) dump[dl.com_inertia + a] = I[a];
+    }
+    // skew(c)^T rows: [0 c2 -c1; -c2 0 c0; c1 -c0 0]
+    const double St[9] = {0.0, c[2], -c[1], -c[2], 0.0, c[0], c[1], -c[0], 0.0};
+    for (int j = th.tid; j < N; j += NT) {
+        double h[3];
+        for (int a = 0; a < 3; a++) {
+            dump[dl.CMM + a * N + j] = A[a * lda + j];
+            dump[dl.J_com + a * N + j] = A[a * lda + j] / mt;
+            double acc = 0.0;
+            for (int b = 0; b < 3; b++) acc += St[a * 3 + b] * A[b * lda + j] + R0[a * 3 + b] * A[(3 + b) * lda + j];
+            h[a] = acc;
+            dump[dl.CMM + (3 + a) * N + j] = acc;
+        }
+        for (int a = 0; a < 3; a++) dump[dl.J_com + (3 + a) * N + j] = Ii[a * 3] * h[0] + Ii[a * 3 + 1] * h[1] + Ii[a * 3 + 2] * h[2];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // QP rows into lanes + solve.  Lane r < M owns torque-limit row r (two sided), lane M + rr owns cone row rr.
 //   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053)
@@ -626,6 +680,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
         for (int j = th.tid; j < N; j += NT) L[S::G + j] = kGrav * A[2 * N + j];  // G_ = -J_com_lin^T m g (dwbc.cpp:358)
         if (dump) {
             for (int idx = th.tid; idx < N * N; idx += NT) dump[dl.A + idx] = A[idx];
+            dump_centroidal<N, NT>(th, A, N, Rw, L + S::q, A[0], dump, dl);  // A(0,0) = total mass
             for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
             for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
         }

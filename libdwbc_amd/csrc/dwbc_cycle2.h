@@ -376,6 +376,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
             for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
             for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
+            dump_centroidal<N, NT>(th, A, N, Rw, L + S::q, A[0], dump, dl);  // A(0,0) = total mass
         }
     }
     DWBC_STAMP(0);  // kinematics + CRBA done

@@ -62,7 +62,7 @@ enum DiagField {
 struct DumpLayout {
     int N, M;
     int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
-    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, stamps, total;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, stamps, total;
     __host__ __device__ static DumpLayout make(int n) {
         DumpLayout d;
         d.N = n;
@@ -91,6 +91,10 @@ struct DumpLayout {
         d.contact_qp = o; o += L * K;
         d.cf_redis = o; o += K;
         d.qp_viol = o; o += L + 1;
+        d.CMM = o; o += 6 * n;          // CMM_ (dwbc.cpp:336)
+        d.com = o; o += 3;              // com_pos (dwbc.cpp:322)
+        d.com_inertia = o; o += 9;      // link_.back().inertia (dwbc.cpp:343)
+        d.J_com = o; o += 6 * n;        // link_.back().jac_com_ (dwbc.cpp:352)
         d.stamps = o; o += 32;  // fine-grained stage stamps (diagnostic build only)
         d.total = o;
         return d;

@@ -207,3 +207,22 @@ def test_bound_torch_tensors_zero_copy():
     tau_r, wr_r, st_r, _ = _oracle(B, q, flags, fstar)
     assert (tst.cpu().numpy() == st_r).all()
     assert np.abs(ttau.cpu().numpy() - tau_r).max() < TOL
+
+
+def test_centroidal_outputs_on_device():
+    """CMM_, com_pos, COM inertia, jac_com_ (reference src/dwbc.cpp:318-352) against the numpy restatement."""
+    from oracle import dwbc_np
+
+    B = 4
+    q, fl, fs = cases.synth_batch(B, seed=91, yaw=True)
+    wbc = _make(B)
+    wbc.enable_dump(True)
+    _run(wbc, q, fl, fs)
+    cmm, com, jc, ic = wbc.get("CMM"), wbc.get("com"), wbc.get("J_com"), wbc.get("com_inertia")
+    for i in range(B):
+        cy = dwbc_np.Cycle(cases.tocabi_model())
+        cy.update_kinematics(q[i])
+        assert np.abs(cmm[i] - cy.CMM).max() < 1e-10
+        assert np.abs(com[i] - cy.com).max() < 1e-12
+        assert np.abs(jc[i] - cy.J_com).max() < 1e-10
+        assert np.abs(ic[i] - ic[i].T).max() < 1e-10 and np.all(np.linalg.eigvalsh(ic[i]) > 0)

@@ -63,3 +63,25 @@ def test_emulated_kernel_vs_oracle_batches(cfg):
     assert ok.mean() > 0.5
     assert np.abs(r["tau"][ok] - tau_r[ok]).max() < 1e-6
     assert np.abs(r["wrench"][ok] - wr_r[ok][:, :12]).max() < 1e-5
+
+
+def test_emulated_centroidal_outputs_vs_numpy_oracle():
+    """CMM_, com_pos, COM inertia and jac_com_ of UpdateKinematics (reference src/dwbc.cpp:318-352) from the kernel's dump
+    record against the numpy restatement; plus the reference's own CMM check (tests/dwbc_test.cpp:560-692): the angular
+    momentum CMM_[3:6] qdot equals the link-sum angular momentum about the COM."""
+    from oracle import dwbc_np
+
+    q, fl, fs = cases.synth_batch(3, seed=77, yaw=True)
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, dump=True)
+    d = r["dump"]
+    for i in range(3):
+        cy = dwbc_np.Cycle(cases.tocabi_model())
+        cy.update_kinematics(q[i])
+        assert np.abs(e.dump_field(d, "CMM", (6, 39))[i] - cy.CMM).max() < 1e-10
+        assert np.abs(e.dump_field(d, "com", (3,))[i] - cy.com).max() < 1e-12
+        assert np.abs(e.dump_field(d, "J_com", (6, 39))[i] - cy.J_com).max() < 1e-10
+        # G_ = -J_com_lin^T m g (dwbc.cpp:354)
+        mtot = cases.tocabi_model()["mass"].sum()
+        Jc = e.dump_field(d, "J_com", (6, 39))[i]
+        assert np.abs(-Jc[:3].T @ (mtot * np.array([0, 0, -9.81])) - e.dump_field(d, "G", (39,))[i]).max() < 1e-9
