@@ -183,12 +183,67 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg), int n
 // Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
 // where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
 // pivot is not positive (rank deficient block => status 0, where the reference would return a pseudo-inverse).
+// n <= 6: the Cholesky factor is computed redundantly by every lane on uniform (LDS-broadcast) data -- 56 FMAs, no
+// cross-lane traffic -- and lane c < n then solves L L^T x = e_c for column c of the inverse with 30 FMAs.  About half
+// the fp64 instructions of the 12-wide register sweep, which matters because one wave issues an fp64 VALU op only
+// every ~12 cycles (tools/ubench).
+DWBC_WDEV int spd_inverse_chol6(const double *Ain, int lda, int n, double *Out, int ldo) {
+    DWBC_LANE_DECL;
+    double Lc[6][6], ri[6];
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Lc[i][j] = (i < n) ? Ain[i * lda + j] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = Lc[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lc[j][k] * Lc[j][k];
+        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        ri[j] = fast_rsqrt(d);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = Lc[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= Lc[i][k] * Lc[j][k];
+            Lc[i][j] = v * ri[j];
+        }
+    }
+    DWBC_SYNC();  // Out may alias Ain
+    LANES {
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double v = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= Lc[i][k] * y[k];
+            y[i] = v * ri[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            double v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) v -= Lc[k][i] * y[k];
+            y[i] = v * ri[i];
+        }
+        if (lane < n) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (i < n) Out[i * ldo + lane] = y[i];
+        }
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
 DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, int ldo, double *colbuf) {
     DWBC_LANE_DECL;
     (void)colbuf;
+    DWBC_SYNC();
+    if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo);
     PLA(double, s, 12);
     PL(double, dg);
-    DWBC_SYNC();
     LANES {
         const int col = lane < n ? lane : 0;
 #pragma unroll
@@ -230,6 +285,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
     for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = 0.0;
     DWBC_SYNC();
+    DWBC_FSTAMP(32);
     {
         double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw, *Rl = L + S::k_Rl;
         const double *q = L + S::q;
@@ -256,22 +312,53 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                         Rl[i * 9 + a * 3 + b] = bd[BF_RT + a * 3] * Rj[b] + bd[BF_RT + a * 3 + 1] * Rj[3 + b] + bd[BF_RT + a * 3 + 2] * Rj[6 + b];
             }
         }
-        for (int d = 1; d <= su.maxdepth; d++) {
+        DWBC_FSTAMP(33);
+        // world transforms by pointer jumping: T_i <- T_anc(i) o T_i, anc(i) <- anc(anc(i)); ceil(log2(depth+1)) rounds of
+        // one 3x3 product per body instead of `depth` dependent rounds.  Buffer 0 = (Rw, pw), buffer 1 = (k_Rl, k_Iw);
+        // ancestor indices ride along as doubles in k_Ic.  (T_a o T_i: R = R_a R_i, p = p_a + R_a p_i.)
+        {
+            int rounds = 0;
+            while ((1 << rounds) < su.maxdepth + 1) rounds++;
+            const bool odd = rounds & 1;  // start in the buffer that makes the last round land in (Rw, pw)
+            double *Rc = odd ? Rl : Rw, *Rn = odd ? Rw : Rl;
+            double *pc = odd ? L + S::k_Iw : pw, *pn = odd ? pw : L + S::k_Iw;
+            double *ac = L + S::k_Ic, *an_ = L + S::k_Ic + NB;
             DWBC_SYNC();
             for (int i = th.tid; i < nb; i += NT) {
-                if (topo[nb + i] != d) continue;
-                const int par = topo[i];
                 const double *bd = body + i * kBodyStride;
-                const double *Rp = Rw + par * 9;
-                for (int a = 0; a < 3; a++) {
-                    for (int b = 0; b < 3; b++)
-                        Rw[i * 9 + a * 3 + b] = Rp[a * 3] * Rl[i * 9 + b] + Rp[a * 3 + 1] * Rl[i * 9 + 3 + b] + Rp[a * 3 + 2] * Rl[i * 9 + 6 + b];
-                    pw[i * 3 + a] = pw[par * 3 + a] + Rp[a * 3] * bd[BF_PT] + Rp[a * 3 + 1] * bd[BF_PT + 1] + Rp[a * 3 + 2] * bd[BF_PT + 2];
+                double Ri[9], pi[3];
+                for (int a = 0; a < 9; a++) Ri[a] = (i == 0) ? Rw[a] : Rl[i * 9 + a];
+                for (int a = 0; a < 3; a++) pi[a] = (i == 0) ? pw[a] : bd[BF_PT + a];
+                const double an = (i == 0) ? -1.0 : (double)topo[i];
+                for (int a = 0; a < 9; a++) Rc[i * 9 + a] = Ri[a];
+                for (int a = 0; a < 3; a++) pc[i * 3 + a] = pi[a];
+                ac[i] = an;
+            }
+            for (int r = 0; r < rounds; r++) {
+                DWBC_SYNC();
+                for (int i = th.tid; i < nb; i += NT) {
+                    // all loads first (the compiler cannot reorder LDS loads across the stores below: same base pointer)
+                    const int an = (int)ac[i];
+                    const int aa = an < 0 ? 0 : an;
+                    double Ri[9], pi[3], Ra[9], pa[3];
+                    for (int a = 0; a < 9; a++) { Ri[a] = Rc[i * 9 + a]; Ra[a] = Rc[aa * 9 + a]; }
+                    for (int a = 0; a < 3; a++) { pi[a] = pc[i * 3 + a]; pa[a] = pc[aa * 3 + a]; }
+                    const double a2 = ac[aa];
+                    double Ro[9], po[3];
+                    for (int a = 0; a < 3; a++) {
+                        for (int c = 0; c < 3; c++) Ro[a * 3 + c] = Ra[a * 3] * Ri[c] + Ra[a * 3 + 1] * Ri[3 + c] + Ra[a * 3 + 2] * Ri[6 + c];
+                        po[a] = pa[a] + Ra[a * 3] * pi[0] + Ra[a * 3 + 1] * pi[1] + Ra[a * 3 + 2] * pi[2];
+                    }
+                    for (int a = 0; a < 9; a++) Rn[i * 9 + a] = an < 0 ? Ri[a] : Ro[a];
+                    for (int a = 0; a < 3; a++) pn[i * 3 + a] = an < 0 ? pi[a] : po[a];
+                    an_[i] = an < 0 ? -1.0 : a2;
                 }
+                { double *t_ = Rc; Rc = Rn; Rn = t_; t_ = pc; pc = pn; pn = t_; t_ = ac; ac = an_; an_ = t_; }
             }
         }
         DWBC_SYNC();
         double *Iw = L + S::k_Iw;
+        DWBC_FSTAMP(34);
         for (int i = th.tid; i < nb; i += NT) {
             const double *bd = body + i * kBodyStride;
             const double *R = Rw + i * 9;
@@ -298,14 +385,52 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 }
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(35);
+        // composite inertia of the subtree [i, i + len_i) (bodies are numbered depth first).  Window sums of length 2^k
+        // by doubling, S_{k+1}[i] = S_k[i] + S_k[i + 2^k] (ping-pong Iw <-> k_Ic); the subtree sum picks S_k at the set bits
+        // of len_i, so no differences of large prefix sums are taken.  Lane i owns body i: its 10 window sums and its
+        // accumulator stay in registers, every round is one batch of independent LDS loads.
         double *Icm = L + S::k_Ic;
-        for (int idx = th.tid; idx < nb * 10; idx += NT) {
-            const int i = idx / 10, c = idx - i * 10;
-            const int e = i + topo[2 * nb + i];
-            double acc = 0.0;
-            for (int j = i; j < e; j++) acc += Iw[j * 10 + c];
-            Icm[idx] = acc;
+        {
+            double *Sc = Iw, *Sn = Icm;
+            PLA(double, sk, 10);
+            PLA(double, acc, 10);
+            PL(int, len);
+            LANES {
+                const int bi = lane < nb ? lane : 0;
+                LV(len) = lane < nb ? topo[2 * nb + bi] : 0;
+#pragma unroll
+                for (int c = 0; c < 10; c++) { LV(sk)[c] = Sc[bi * 10 + c]; LV(acc)[c] = 0.0; }
+            }
+            for (int kbit = 0, off = 1; off < nb; kbit++, off <<= 1) {
+                LANES {
+                    const bool take = (LV(len) >> kbit) & 1;
+                    int pos = lane + (LV(len) & (off - 1));
+                    pos = (take && pos < nb) ? pos : 0;
+                    const bool nbr = lane + off < nb;
+                    const int pn = nbr ? lane + off : 0;
+                    double a_[10], b_[10];
+#pragma unroll
+                    for (int c = 0; c < 10; c++) { a_[c] = Sc[pos * 10 + c]; b_[c] = Sc[pn * 10 + c]; }
+#pragma unroll
+                    for (int c = 0; c < 10; c++) {
+                        LV(acc)[c] += take ? a_[c] : 0.0;
+                        LV(sk)[c] += nbr ? b_[c] : 0.0;
+                        if (lane < nb) Sn[lane * 10 + c] = LV(sk)[c];
+                    }
+                }
+                DWBC_SYNC();
+                { double *t_ = Sc; Sc = Sn; Sn = t_; }
+            }
+            LANES {
+                if (lane < nb) {
+#pragma unroll
+                    for (int c = 0; c < 10; c++) Icm[lane * 10 + c] = LV(acc)[c];
+                }
+            }
+            DWBC_SYNC();
         }
+        DWBC_FSTAMP(36);
         double *Sm = L + S::k_S, *Fm = L + S::k_F;
         for (int j = th.tid; j < N; j += NT) {
             double w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
@@ -324,6 +449,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int a = 0; a < 3; a++) { Sm[j * 6 + a] = w[a]; Sm[j * 6 + 3 + a] = v[a]; }
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(37);
         for (int j = th.tid; j < N; j += NT) {
             const int b = j < 6 ? 0 : j - 5;
             const double *I = Icm + b * 10;
@@ -338,11 +464,19 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(38);
         // A[j][k] = S_k . F_j for k on the path from j to the root (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm), staged
         // through LDS once and then loaded column-per-lane into registers
         double *A = L + S::k_A;
         for (int idx = th.tid; idx < N * N; idx += NT) A[idx] = 0.0;
+        double *pdof = L + S::k_col;  // parent dof of every dof (the walk below would otherwise read topo from HBM per step)
+        for (int j = th.tid; j < N; j += NT) {
+            int pj = j - 1;
+            if (j >= 6) { const int pb = topo[j - 5]; pj = pb == 0 ? 5 : pb + 5; }
+            pdof[j] = (double)pj;
+        }
         DWBC_SYNC();
+        DWBC_FSTAMP(39);
         for (int j = th.tid; j < N; j += NT) {
             const double *f = Fm + j * 6;
             int kk = j;
@@ -352,14 +486,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 A[j * N + kk] = v;
                 A[kk * N + j] = v;
                 if (kk == 0) break;
-                if (kk < 6) kk = kk - 1;
-                else {
-                    const int pb = topo[kk - 5];
-                    kk = pb == 0 ? 5 : pb + 5;
-                }
+                kk = (int)pdof[kk];
             }
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(40);
         LANES {
             const int col = lane < N ? lane : 0;
 #pragma unroll
@@ -367,6 +498,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             LV(dg) = (lane < N) ? A[col * N + col] : 1.0;
             if (lane < N) L[S::G + lane] = kGrav * A[2 * N + col];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
         }
+        DWBC_FSTAMP(41);
         if (dump) {
             LANES {
                 if (lane < N) {

@@ -95,7 +95,7 @@ struct DumpLayout {
         d.com = o; o += 3;              // com_pos (dwbc.cpp:322)
         d.com_inertia = o; o += 9;      // link_.back().inertia (dwbc.cpp:343)
         d.J_com = o; o += 6 * n;        // link_.back().jac_com_ (dwbc.cpp:352)
-        d.stamps = o; o += 32;  // fine-grained stage stamps (diagnostic build only)
+        d.stamps = o; o += 64;  // fine-grained stage stamps (diagnostic build only)
         d.total = o;
         return d;
     }

@@ -68,6 +68,19 @@ DWBC_WDEV double fast_rcp(double d) {
 #endif
 }
 
+// 1/sqrt(d) for positive normal d: hardware estimate + two Newton steps
+DWBC_WDEV double fast_rsqrt(double d) {
+#ifdef DWBC_HOST_EMU
+    return 1.0 / sqrt(d);
+#else
+    double r = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    r = __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+    r = __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+    return r;
+#endif
+}
+
 // element `lane` of a uniform 12-array (avoids dynamic register indexing on the device)
 DWBC_WDEV double pick12(const double *a, int lane) {
     double v = 0.0;

@@ -42,7 +42,7 @@ nb = wbc._L.dwbc_batch_field_bytes(wbc._h, 49)
 raw = np.zeros(nb // 8)
 wbc._L.dwbc_batch_get(wbc._h, 49, raw.ctypes.data, nb)
 raw = raw.reshape(B, -1)
-st = np.median(raw[:, -32:], axis=0)
+st = np.median(raw[:, -64:], axis=0)
 fn = ["start stage1", "J_C", "Y", "Lambda_c", "JbT", "AiNc", "vec,PC", "Vb", "JV", "gj6", "NwJw", "gram+inv", "VG", "FNl", "L0 Jt+T1", "L0 JAJ", "L0 Lambda_t", "all levels", "W+aP", "W sweep", "W corr+grav", "L0 Q,QW", "L0 QWQ inv"]
 prev = st[0]
 print("fine stamps (dump enabled, so absolute values include dump stores):")
@@ -53,3 +53,9 @@ qn = ["post-loop", "slack+argmin", "publish n, r, z", "step/drop", "commit", "ro
 print("level-0 QP solver sections (cycles, summed over iterations):")
 for i, n in enumerate(qn):
     print(f"  {n:16s} {st[23 + i]:10.0f}")
+kn = ["q load", "local rotations", "FK levels", "world inertias", "composite inertias", "S axes", "F = Ic S", "zero A", "CRBA walk", "A -> registers"]
+print("kinematics sections (cycles):")
+prev = 0.0
+for i, n in enumerate(kn):
+    print(f"  {n:20s} {st[32 + i]-prev:10.0f} {st[32 + i]:10.0f}")
+    prev = st[32 + i]
