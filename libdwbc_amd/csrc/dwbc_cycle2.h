@@ -20,6 +20,7 @@ struct Lds2 {
     static constexpr int K = C - 6;
     static constexpr int T = kMaxTaskDof;
     static constexpr int max2(int a, int b) { return a > b ? a : b; }
+    static constexpr int ev(int a) { return (a + 1) & ~1; }  // 16-byte alignment: lets row reads become ds_read_b128
     // ---- persistent
     static constexpr int q = 0;                        // N+1
     static constexpr int G = q + N + 1;
@@ -53,7 +54,7 @@ struct Lds2 {
     static constexpr int c_Vb = tmp;                           // M x K
     static constexpr int c_VG = c_Vb + M * K;                  // M x K
     static constexpr int c_vec = c_VG + M * K;                 // N
-    static constexpr int c_Lt = c_vec + N;                     // levels x T x T
+    static constexpr int c_Lt = ev(c_vec + N);                 // levels x T x T
     static constexpr int c_ov = c_Lt + NLV * T * T;            // two overlaid groups:
     //   (1) contact algebra
     static constexpr int c_JC = c_ov;
@@ -75,7 +76,7 @@ struct Lds2 {
     static constexpr int c_end = max2(c_end1, c_end2);
     // ---- QP scratch (after the task-space phase)
     static constexpr int t_base = tmp;
-    static constexpr int t_F = t_base + M;                     // C x kQpLd
+    static constexpr int t_F = ev(t_base + M);                 // C x kQpLd
     static constexpr int t_fv = t_F + C * kQpLd;
     static constexpr int t_s1 = t_fv + C;                      // C x (T+1)
     static constexpr int qp_V = t_s1 + C * (T + 1);
