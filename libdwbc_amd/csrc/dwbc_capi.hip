@@ -203,6 +203,7 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     std::vector<int> topo;
     m->m.body_table(body);
     m->m.topo_table(topo);
+    setup_set_parents(b->su, topo.data());
     if ((e = hipMalloc(&b->d_body, body.size() * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
     if ((e = hipMalloc(&b->d_topo, topo.size() * sizeof(int))) != hipSuccess) return bad("hipMalloc", e);
     if ((e = hipMemcpy(b->d_body, body.data(), body.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy", e);

@@ -557,16 +557,28 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JCt, 1, 6 * a, 6, 0, C);
     DWBC_SYNC();
     DWBC_FSTAMP(1);  // J_C built
-    // Y[:, lane] = J_C * (lane's column of A^-1)
+    // Y[:, lane] = J_C * (lane's column of A^-1).  Column i of J_C is zero unless dof i lies between the contact link and
+    // the base (su.c_dofmask): uniform branches skip the zero columns, per contact.
+    const unsigned long long cm0 = nc > 0 ? su.c_dofmask[act_c[0]] : 0ull, cm1 = nc > 1 ? su.c_dofmask[act_c[1]] : 0ull;
+    static_assert(C == 12, "two 6D contacts");
     LANES {
         double yc[C];
 #pragma unroll
         for (int p = 0; p < C; p++) yc[p] = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            const double si = LV(s)[i];
+        for (int ib = 0; ib < N; ib += 3) {  // one uniform branch per 3 columns and contact (a branch costs ~40 cycles)
+            if ((cm0 >> ib) & 7) {
 #pragma unroll
-            for (int p = 0; p < C; p++) yc[p] += JCt[i * C + p] * si;
+                for (int i = ib; i < ib + 3 && i < N; i++)
+#pragma unroll
+                    for (int p = 0; p < 6; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
+            }
+            if ((cm1 >> ib) & 7) {
+#pragma unroll
+                for (int i = ib; i < ib + 3 && i < N; i++)
+#pragma unroll
+                    for (int p = 6; p < C; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
+            }
         }
         if (lane < N) {
 #pragma unroll
@@ -711,9 +723,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
-        double *Jt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;
+        double *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
+        const unsigned long long tm = su.t_dofmask[lv];
         DWBC_SYNC();
-        for (int idx = th.tid; idx < T * N; idx += NT) Jt[idx] = 0.0;
+        for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = 0.0;
         DWBC_SYNC();
         int row = 0;
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
@@ -727,23 +740,40 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             double P[3];
             for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
             const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
-            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jt, N, row, rsel == 0 ? 6 : 3, rsel);
+            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
             row += rsel == 0 ? 6 : 3;
         }
         DWBC_SYNC();
-        for (int r = 0; r < T; r++) {
-            LANES {
-                double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        // T1[:, lane] = J_t * (lane's column of A^-1 N_c): all task rows in one pass, zero columns of J_t skipped
+        LANES {
+            double tc_[T];
 #pragma unroll
-                for (int i = 0; i < N; i++) a4[i & 3] += Jt[r * N + i] * LV(s)[i];
-                const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                if (lane < N) T1[r * N + lane] = acc;
-                if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = acc;
+            for (int r = 0; r < T; r++) tc_[r] = 0.0;
+#pragma unroll
+            for (int ib = 0; ib < N; ib += 3) {
+                if ((tm >> ib) & 7) {
+#pragma unroll
+                    for (int i = ib; i < ib + 3 && i < N; i++)
+#pragma unroll
+                        for (int r = 0; r < T; r++) tc_[r] += Jtt[i * T + r] * LV(s)[i];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < T; r++) {
+                if (lane < N) T1[r * N + lane] = tc_[r];
+                if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
             }
         }
         DWBC_SYNC();
         if (lv == 0) DWBC_FSTAMP(14);  // level 0: Jt + T1
-        mm_nt<NT>(th, L + S::c_s2, t, T1, N, Jt, N, t, N, t);
+        for (int idx = th.tid; idx < t * t; idx += NT) {  // J_t A^-1 N_c J_t^T
+            const int i = idx / t, j = idx - i * t;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; c++)
+                if ((tm >> c) & 1) acc += T1[i * N + c] * Jtt[c * T + j];
+            L[S::c_s2 + idx] = acc;
+        }
         if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
         if (lv == 0) DWBC_FSTAMP(15);  // level 0: J A J^T
         spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
@@ -752,7 +782,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (lv == NLV - 1)
             for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
         if (dump) {
-            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jt[idx];
+            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jtt[(idx % N) * T + idx / N];
             for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
         }
     }

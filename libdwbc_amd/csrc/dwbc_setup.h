@@ -17,6 +17,18 @@ inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
     su.qp_max_iter_contact = 300;  // reference src/dwbc.cpp:1546
 }
 
+// parent body of every body (Model::topo_table()[0..nb)); must be installed before contacts / tasks are added
+inline void setup_set_parents(Setup &su, const int *parent) {
+    for (int i = 0; i < su.nb && i < kMaxBodies; i++) su.parent[i] = parent[i];
+}
+
+// dofs on the path from `link` to the floating base: bits 0..5 (base) and bit (b + 5) for every moving body b on the path
+inline unsigned long long link_dofmask(const Setup &su, int link) {
+    unsigned long long m = 0x3full;
+    for (int b = link, guard = 0; b > 0 && guard < kMaxBodies; b = su.parent[b], guard++) m |= 1ull << (b + 5);
+    return m;
+}
+
 inline int task_mode_dof(int mode) { return mode <= TASK_LINK_6D_CUSTOM_FRAME ? 6 : 3; }  // reference src/task.cpp:14-31
 
 inline void setup_fstar_layout(Setup &su) {
@@ -46,6 +58,7 @@ inline int setup_add_contact(Setup &su, int link, int contact_type, const double
     su.c_ly[i] = ly;
     su.c_mu[i] = mu;
     su.c_muz[i] = mu_z;
+    su.c_dofmask[i] = link_dofmask(su, link);
     return i;
 }
 
@@ -69,6 +82,8 @@ inline bool setup_add_task(Setup &su, int level, int mode, int link, const doubl
     su.t_link[level][j] = link;
     for (int a = 0; a < 3; a++) su.t_point[level][j][a] = point ? point[a] : 0.0;
     su.t_nlinks[level]++;
+    su.t_dofmask[level] = 0;
+    for (int a = 0; a < su.t_nlinks[level]; a++) su.t_dofmask[level] |= link_dofmask(su, su.t_link[level][a]);
     setup_fstar_layout(su);
     return true;
 }

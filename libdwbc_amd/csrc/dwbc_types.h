@@ -46,6 +46,11 @@ struct Setup {
     double tau_lim[48];
     int qp_max_iter_task;   // 1000, reference src/dwbc.cpp:1080
     int qp_max_iter_contact; // 300,  reference src/dwbc.cpp:1546
+    // structural support of the Jacobians: bit d set <=> dof d (0..5 base, 6.. joints) moves the link.  Derived from the
+    // kinematic tree when a contact / task link is registered; lets the products J A^-1 and J A^-1 N_c skip zero columns.
+    int parent[kMaxBodies];
+    unsigned long long c_dofmask[kMaxContacts];
+    unsigned long long t_dofmask[kMaxLevels];
 };
 
 // per-instance diagnostics (int32)

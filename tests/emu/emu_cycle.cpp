@@ -31,6 +31,7 @@ EmuCtx *emu_create(const char *urdf) {
     setup_init(c->su, c->model.nb, c->model.ndof, c->model.maxdepth);
     c->model.body_table(c->body);
     c->model.topo_table(c->topo);
+    setup_set_parents(c->su, c->topo.data());
     return c;
 }
 const char *emu_error(EmuCtx *c) { return c->err.c_str(); }
