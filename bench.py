@@ -23,6 +23,21 @@ if ROOT not in sys.path:
 
 F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit (SURVEY 8d / BASELINE.md 3)
 PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
+
+
+def hbm_traffic_per_launch(kernel_name, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes) if they were
+    taken on the same kernel and batch; None otherwise.  The accesses are 8 B per lane, for which the gfx950 FETCH_SIZE
+    correction of MI355X_MICROARCH.md (x2 for 16-B-per-lane streams) is not calibrated: the raw sum is reported."""
+    try:
+        pm = json.load(open(PMC_SUMMARY))
+        k = pm["_kernel"]
+        if not kernel_name.startswith(k["kernel"].split("<")[0].replace("void ", "")) or int(k["grid"]) != batch * 64:
+            return None
+        return (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    except Exception:
+        return None
 
 
 def main():
@@ -146,11 +161,14 @@ def main():
                 "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": None,
-                "kernel": "dwbc_cycle_kernel<39,34,64>",
+                "traffic": hbm_traffic_per_launch(wbc.kernel_name(), B),
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_final_pmc_summary.json)",
+                "kernel": wbc.kernel_name(),
                 "kernel_ms": kern_ms,
                 "flop_per_cycle": F_ALG,
-                "note": "fp64 FMA roof (vector = matrix rate on MI355X, public spec 78.6 TFLOP/s); algorithmic flop of the reference's dense formulas",
+                "note": "fp64 FMA roof (vector = matrix rate on MI355X, public spec 78.6 TFLOP/s); algorithmic flop of the "
+                        "reference's dense formulas.  batch 1024 = one wave per SIMD, where tools/ubench measures 23.3 TFLOP/s "
+                        "for back-to-back fp64 FMAs from a single wave (24.0 for MFMA f64 16x16x4): DESIGN.md 'Measured'",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -133,6 +133,8 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *host_out, size_t bytes);
 size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field);
 /* kernel launch geometry, for DESIGN.md / bench bookkeeping */
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads_per_instance, int *lds_bytes);
+/* name of the kernel the next dwbc_batch_solve will launch (as rocprofv3 prints it), for bench / profile bookkeeping */
+const char *dwbc_batch_kernel_name(const dwbc_batch *b);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("dwbc_batch_get", _i, [_vp, _i, _vp, C.c_size_t]),
     ("dwbc_batch_field_bytes", C.c_size_t, [_vp, _i]),
     ("dwbc_batch_launch_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    ("dwbc_batch_kernel_name", C.c_char_p, [_vp]),
 ]
 
 _lib = None

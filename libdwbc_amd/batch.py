@@ -190,6 +190,9 @@ class Batch:
         self._L.dwbc_batch_launch_info(self._h, C.byref(t), C.byref(l))
         return t.value, l.value
 
+    def kernel_name(self):
+        return self._L.dwbc_batch_kernel_name(self._h).decode()
+
     _SHAPES = dict(
         tau=lambda s: (3, s.m), wrench=lambda s: (12,), status=lambda s: (), diag=lambda s: (90,),
         tau_grav=lambda s: (s.m,), tau_task=lambda s: (s.m,), tau_contact=lambda s: (s.m,), tau_total=lambda s: (s.m,),

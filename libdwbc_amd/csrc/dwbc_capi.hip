@@ -532,6 +532,23 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
     return 1;
 }
 
+const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
+    static thread_local std::string name;
+    const KernelEntry *ke = pick_kernel(b);
+    if (!ke) return "";
+    int n_cu = b->n_cu;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    }
+    const bool v1 = ke->fn_wide == nullptr;
+    const bool wide = !v1 && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
+    name = v1 ? "dwbc_cycle_kernel<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", 64>"
+              : std::string(wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + std::to_string(ke->n) + ", " +
+                    std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+    return name.c_str();
+}
+
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
     const KernelEntry *ke = pick_kernel(b);
     if (threads) *threads = kNT;

@@ -31,6 +31,7 @@ template <int NN>
 __global__ __launch_bounds__(64) void k_sweep(const double* in, double* out, long long* cyc, int reps) {
     const int lane = threadIdx.x;
     double s[NN], dg;
+#pragma unroll
     for (int i = 0; i < NN; i++) s[i] = in[i * 64 + lane];
     dg = in[NN * 64 + lane];
     long long t0 = clock64();
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(64) void k_sweep(const double* in, double* out, lon
     long long t1 = clock64();
     if (lane == 0) cyc[blockIdx.x] = (t1 - t0) / reps;
     double acc = dg + ok;
+#pragma unroll
     for (int i = 0; i < NN; i++) acc += s[i];
     out[blockIdx.x * 64 + lane] = acc;
 }
