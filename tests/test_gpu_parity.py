@@ -226,3 +226,33 @@ def test_centroidal_outputs_on_device():
         assert np.abs(com[i] - cy.com).max() < 1e-12
         assert np.abs(jc[i] - cy.J_com).max() < 1e-10
         assert np.abs(ic[i] - ic[i].T).max() < 1e-10 and np.all(np.linalg.eigvalsh(ic[i]) > 0)
+
+
+@pytest.mark.parametrize("cfg", ["config3_ss_3level_8192", "config4_mixed_65536"])
+def test_full_size_configs_3_and_4(cfg):
+    """BASELINE configs[2] / configs[3] at their full batch sizes.  Size-independent properties:
+    (a) a random sample of 192 instances of the big launch agrees with the oracle to 1e-6 and with the same states
+        solved in a small batch (instances are independent; the small batch runs the wide-register kernel build, the
+        big one the register-capped build);
+    (b) every instance returns a status, |tau_total| <= tau limit where the cycle succeeded, tau_contact = 0 when k = 0."""
+    if cfg.startswith("config3"):
+        B, tasks, kw = 8192, cases.TASKS_3LEVEL_SWING_R, dict(seed=20251226 + 3, contact_mode="L", levels=3)
+    else:
+        B, tasks, kw = 65536, cases.TASKS_2LEVEL, dict(seed=20251226 + 4, contact_mode="mixed")
+    q, flags, fstar = cases.synth_batch(B, **kw)
+    wbc = _make(B, tasks=tasks)
+    tau, wr, st = _run(wbc, q, flags, fstar)
+    assert set(np.unique(st)) <= {0, 1} and st.mean() > 0.9
+    ok = st == 1
+    assert (np.abs(tau[ok].sum(axis=1)) <= 300.0 + 1e-6).all()
+    ss = flags.sum(axis=1) == 1
+    assert np.abs(tau[ss & ok, 2]).max() == 0.0
+    idx = np.random.default_rng(11).choice(B, size=192, replace=False)
+    small = _make(192, tasks=tasks)
+    tau_s, wr_s, st_s = _run(small, q[idx], flags[idx], fstar[idx])
+    assert (st_s == st[idx]).all()
+    assert np.abs(tau_s - tau[idx]).max() < 1e-8
+    tau_r, wr_r, st_r, _ = _oracle(192, q[idx], flags[idx], fstar[idx], tasks=tasks)
+    assert (st_r == st[idx]).all()
+    okr = st_r == 1
+    assert np.abs(tau[idx][okr] - tau_r[okr]).max() < TOL
