@@ -27,24 +27,6 @@ __global__ __launch_bounds__(64) void k_small_inv(const double* in, double* out,
     for (int i = lane; i < 144; i += 64) out[blockIdx.x * 144 + i] = O[i] + ok;
 }
 
-template <int NN>
-__global__ __launch_bounds__(64) void k_sweep(const double* in, double* out, long long* cyc, int reps) {
-    const int lane = threadIdx.x;
-    double s[NN], dg;
-#pragma unroll
-    for (int i = 0; i < NN; i++) s[i] = in[i * 64 + lane];
-    dg = in[NN * 64 + lane];
-    long long t0 = clock64();
-    int ok = 1;
-    for (int r = 0; r < reps; r++) ok &= sweep_inverse_rl<NN>(s, dg, NN);
-    long long t1 = clock64();
-    if (lane == 0) cyc[blockIdx.x] = (t1 - t0) / reps;
-    double acc = dg + ok;
-#pragma unroll
-    for (int i = 0; i < NN; i++) acc += s[i];
-    out[blockIdx.x * 64 + lane] = acc;
-}
-
 // dependent / independent FMA chains fed by v_readlane or by LDS broadcast
 __global__ __launch_bounds__(64) void k_feed(const double* in, double* out, long long* cyc, int mode, int reps) {
     __shared__ double buf[64];
@@ -64,6 +46,9 @@ __global__ __launch_bounds__(64) void k_feed(const double* in, double* out, long
         } else if (mode == 2) {   // 32 FMAs, register operands only, 8 independent accumulators
 #pragma unroll
             for (int j = 0; j < 32; j++) a[j & 7] += x * a[(j + 1) & 7];
+        } else if (mode == 4) {   // 32 FMAs, operands via ds_bpermute (per-lane source lane), 8 independent accumulators
+#pragma unroll
+            for (int j = 0; j < 32; j++) a[j & 7] += __shfl(x, (lane + j) & 63, 64) * a[(j + 1) & 7];
         } else {                  // 32 FMAs, one dependent chain
 #pragma unroll
             for (int j = 0; j < 32; j++) a[0] += x * a[0];
@@ -113,17 +98,10 @@ int main() {
         CK(hipMemcpy(c.data(), dcyc, G * 8, hipMemcpyDeviceToHost));
         printf("spd_inverse_small n=%d: %lld cycles\n", n, median(c));
     }
-    // SPD 39x39 in column-per-lane layout
-    for (int i = 0; i < 40; i++) for (int l = 0; l < 64; l++) h[i * 64 + l] = (i < 39 && l < 39) ? ((i == l ? 40.0 : 0.0) + 1.0 / (1 + i + l)) : 0.0;
-    for (int l = 0; l < 64; l++) h[39 * 64 + l] = l < 39 ? 40.0 + 1.0 / (1 + 2 * l) : 1.0;
-    CK(hipMemcpy(din, h.data(), 40 * 64 * 8, hipMemcpyHostToDevice));
-    k_sweep<39><<<G, 64>>>(din, dout, dcyc, 2); CK(hipDeviceSynchronize());
-    CK(hipMemcpy(c.data(), dcyc, G * 8, hipMemcpyDeviceToHost));
-    printf("sweep_inverse_rl<39>: %lld cycles\n", median(c));
     for (int l = 0; l < 128; l++) h[l] = 1.0 + 1e-9 * l;
     CK(hipMemcpy(din, h.data(), 128 * 8, hipMemcpyHostToDevice));
-    const char* nm[] = {"readlane-fed, 8 acc", "LDS-broadcast-fed, 8 acc", "register, 8 acc", "register, 1 dependent chain"};
-    for (int mode = 0; mode < 4; mode++) {
+    const char* nm[] = {"readlane-fed, 8 acc", "LDS-broadcast-fed, 8 acc", "register, 8 acc", "register, 1 dependent chain", "ds_bpermute-fed, 8 acc"};
+    for (int mode : {0, 1, 2, 3, 4}) {
         k_feed<<<G, 64>>>(din, dout, dcyc, mode, 64); CK(hipDeviceSynchronize());
         CK(hipMemcpy(c.data(), dcyc, G * 8, hipMemcpyDeviceToHost));
         printf("32 fp64 FMAs (%s): %.1f cycles per FMA\n", nm[mode], median(c) / (64.0 * 32));
