@@ -33,7 +33,10 @@ enum {
     DWBC_TASK_LINK_ROTATION, DWBC_TASK_LINK_ROTATION_CUSTOM_FRAME
 };
 enum { DWBC_F64 = 0 };
-enum { DWBC_SOLVE_HQP = 1, DWBC_SOLVE_INIT = 2 };
+/* DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
+ * ReducedCalcGravCompensation, ReducedCalcTaskSpace, ReducedCalcTaskControlTorque, ReducedCalcContactRedistribute --
+ * reference include/dwbc.h:411-416, tests/sp_test/redu_dyn_test.cpp:263-298) instead of the full-model sequence */
+enum { DWBC_SOLVE_HQP = 1, DWBC_SOLVE_INIT = 2, DWBC_SOLVE_REDUCED = 4 };
 
 /* fields for dwbc_batch_get / dwbc_batch_bind_device.  Shapes are per instance, row-major. */
 enum dwbc_field {

@@ -22,7 +22,7 @@ CONTACT_6D = 0
 TASK_LINK_6D, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME = 0, 1, 2
 TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME, TASK_LINK_POSITION_CUSTOM_FRAME = 3, 4, 5
 TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME = 6, 7
-SOLVE_HQP, SOLVE_INIT = 1, 2
+SOLVE_HQP, SOLVE_INIT, SOLVE_REDUCED = 1, 2, 4
 
 # field ids of include/dwbc_batch.h
 FIELDS = dict(
@@ -174,15 +174,16 @@ class Batch:
         _check(self._L.dwbc_batch_enable_dump(self._h, 1 if on else 0))
 
     # ---- the cycle
-    def solve(self, hqp=True, init=True):
-        _check(self._L.dwbc_batch_solve(self._h, (SOLVE_HQP if hqp else 0) | (SOLVE_INIT if init else 0)))
+    def solve(self, hqp=True, init=True, reduced=False):
+        """reduced=True: the Reduced* call sequence of the reference (include/dwbc.h:411-416) instead of the full model"""
+        _check(self._L.dwbc_batch_solve(self._h, (SOLVE_HQP if hqp else 0) | (SOLVE_INIT if init else 0) | (SOLVE_REDUCED if reduced else 0)))
 
     def sync(self):
         _check(self._L.dwbc_batch_sync(self._h))
 
-    def time_solves(self, steps):
+    def time_solves(self, steps, reduced=False):
         ms = C.c_float(0)
-        _check(self._L.dwbc_batch_time_solves(self._h, SOLVE_HQP | SOLVE_INIT, int(steps), C.byref(ms)))
+        _check(self._L.dwbc_batch_time_solves(self._h, SOLVE_HQP | SOLVE_INIT | (SOLVE_REDUCED if reduced else 0), int(steps), C.byref(ms)))
         return ms.value
 
     def launch_info(self):

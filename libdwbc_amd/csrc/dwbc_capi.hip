@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "../../include/dwbc_batch.h"
-#include "dwbc_cycle2.h"
+#include "dwbc_reduced.h"
 #include "dwbc_model.h"
 #include "dwbc_setup.h"
 
@@ -49,6 +49,18 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, cons
     DWBC_V2_BODY
 }
 
+// reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
+    static_assert(NT == 64, "one wavefront per instance");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    int *iL = reinterpret_cast<int *>(lds + LdsR<N, NB, NLV>::rtotal);
+    cycle_instance_reduced<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+}
+
 namespace {
 thread_local std::string g_err;
 int fail(const std::string &s) {
@@ -77,6 +89,12 @@ const KernelEntry kKernels[] = {
     {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT>},
     {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT>},
 };
+const KernelEntry kKernelsReduced[] = {
+    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr},
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
+    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr},
+    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr},
+};
 const KernelEntry kKernelsV1[] = {
     {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
 };
@@ -99,6 +117,7 @@ struct dwbc_batch {
     bool own_q = false, own_fstar = false, own_flags = false, own_tau = false, own_wrench = false, own_status = false;
     int fstar_alloc = 0, flags_alloc = 0;
     bool dump_on = false;
+    bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
     // host mirrors of the inputs
     std::vector<double> h_q, h_fstar;
     std::vector<unsigned char> h_flags;
@@ -353,7 +372,12 @@ static int upload_inputs(dwbc_batch *b) {
     return 1;
 }
 
-static const KernelEntry *pick_kernel(const dwbc_batch *b) {
+static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
+    if (reduced) {
+        for (const auto &k : kKernelsReduced)
+            if (k.n == b->n && k.nb == b->su.nb && k.nlv == b->su.n_levels) return &k;
+        return nullptr;
+    }
     const char *kv = getenv("DWBC_KERNEL");
     if (kv && std::string(kv) == "v1") {
         for (const auto &k : kKernelsV1)
@@ -365,8 +389,8 @@ static const KernelEntry *pick_kernel(const dwbc_batch *b) {
     return nullptr;
 }
 
-static int launch(dwbc_batch *b) {
-    const KernelEntry *ke = pick_kernel(b);
+static int launch(dwbc_batch *b, bool reduced = false) {
+    const KernelEntry *ke = pick_kernel(b, reduced);
     if (!ke) return fail("no kernel for this model / number of task levels");
     if (ke != b->kern) {
         b->kern = ke;
@@ -403,9 +427,14 @@ int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
     if (!(flags & DWBC_SOLVE_HQP)) return fail("hqp=false (closed-form ContactRedistributetwomod) is not on the device path");
     if (b->su.n_levels < 1) return fail("no task space");
     if (b->su.n_contacts < 1) return fail("no contact constraint");
+    const bool reduced = flags & DWBC_SOLVE_REDUCED;
+    b->last_reduced = reduced;
+    if (reduced && b->su.has_tau_lim)
+        return fail("reduced dynamics path with a torque limit is inconsistent in the reference (src/dwbc.cpp:3462-3467,3513; "
+                    "its harness disables the limit, tests/sp_test/redu_dyn_test.cpp:63): call dwbc_batch_set_torque_limit(b, NULL)");
     HIP_OK(hipSetDevice(b->device));
     if (!upload_inputs(b)) return 0;
-    return launch(b);
+    return launch(b, reduced);
 }
 
 int dwbc_batch_sync(dwbc_batch *b) {
@@ -422,7 +451,7 @@ int dwbc_batch_time_solves(dwbc_batch *b, unsigned flags, int steps, float *ms) 
     HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, b->stream));
     for (int i = 0; i < steps; i++)
-        if (!launch(b)) return 0;
+        if (!launch(b, flags & DWBC_SOLVE_REDUCED)) return 0;
     HIP_OK(hipEventRecord(e1, b->stream));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipEventElapsedTime(ms, e0, e1));
@@ -534,8 +563,12 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 
 const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     static thread_local std::string name;
-    const KernelEntry *ke = pick_kernel(b);
+    const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     if (!ke) return "";
+    if (b->last_reduced) {
+        name = "dwbc_cycle_kernel_reduced<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+        return name.c_str();
+    }
     int n_cu = b->n_cu;
     if (!n_cu) {
         hipDeviceProp_t prop;
@@ -550,7 +583,7 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
-    const KernelEntry *ke = pick_kernel(b);
+    const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     if (threads) *threads = kNT;
     if (lds) *lds = ke ? ke->lds_bytes : 0;
     return 1;

@@ -60,6 +60,7 @@ constexpr double kGrav = 9.81;
 constexpr double kQpScaleGI = 1.0e4;      // c = s * c_hat while the active set is searched
 constexpr double kQpScalePolish = 1.0e9;  // weight of the final (row-sorted, column-pivoted) least-norm solve
 constexpr double kQpTol = 1.0e-9;
+constexpr double kQpZeroRow = 1.0e-9;     // rows with a smaller norm are the constraint 0 <= hi
 constexpr double kQpFeasTol = 1.0e-7;     // acceptance of the lexicographic point (slack / |row|)
 constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
 }  // namespace dwbc

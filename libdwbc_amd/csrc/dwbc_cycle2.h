@@ -282,372 +282,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     PLA(double, s, N);  // column `lane` of A -> A^-1 -> A^-1 N_c
     PL(double, dg);     // its diagonal element
 
-    // ================= stage 0: kinematics and CRBA (src/dwbc.cpp:279-371) =================
-    for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
-    for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = 0.0;
-    DWBC_SYNC();
-    DWBC_FSTAMP(32);
-    {
-        double *Rw = L + S::Rw, *pw = L + S::pw, *aw = L + S::aw, *Rl = L + S::k_Rl;
-        const double *q = L + S::q;
-        for (int i = th.tid; i < nb; i += NT) {
-            const double *bd = body + i * kBodyStride;
-            if (i == 0) {
-                const double x = q[3], y = q[4], z = q[5], w = q[N];
-                double *R = Rw;
-                R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
-                R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
-                R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
-                pw[0] = q[0]; pw[1] = q[1]; pw[2] = q[2];
-            } else {
-                const double ax = bd[BF_AXIS], ay = bd[BF_AXIS + 1], az = bd[BF_AXIS + 2];
-                double sn, cs;
-                sincos(q[6 + i - 1], &sn, &cs);
-                const double c1 = 1.0 - cs;
-                double Rj[9];
-                Rj[0] = cs + ax * ax * c1; Rj[1] = ax * ay * c1 - az * sn; Rj[2] = ax * az * c1 + ay * sn;
-                Rj[3] = ay * ax * c1 + az * sn; Rj[4] = cs + ay * ay * c1; Rj[5] = ay * az * c1 - ax * sn;
-                Rj[6] = az * ax * c1 - ay * sn; Rj[7] = az * ay * c1 + ax * sn; Rj[8] = cs + az * az * c1;
-                for (int a = 0; a < 3; a++)
-                    for (int b = 0; b < 3; b++)
-                        Rl[i * 9 + a * 3 + b] = bd[BF_RT + a * 3] * Rj[b] + bd[BF_RT + a * 3 + 1] * Rj[3 + b] + bd[BF_RT + a * 3 + 2] * Rj[6 + b];
-            }
-        }
-        DWBC_FSTAMP(33);
-        // world transforms by pointer jumping: T_i <- T_anc(i) o T_i, anc(i) <- anc(anc(i)); ceil(log2(depth+1)) rounds of
-        // one 3x3 product per body instead of `depth` dependent rounds.  Buffer 0 = (Rw, pw), buffer 1 = (k_Rl, k_Iw);
-        // ancestor indices ride along as doubles in k_Ic.  (T_a o T_i: R = R_a R_i, p = p_a + R_a p_i.)
-        {
-            int rounds = 0;
-            while ((1 << rounds) < su.maxdepth + 1) rounds++;
-            const bool odd = rounds & 1;  // start in the buffer that makes the last round land in (Rw, pw)
-            double *Rc = odd ? Rl : Rw, *Rn = odd ? Rw : Rl;
-            double *pc = odd ? L + S::k_Iw : pw, *pn = odd ? pw : L + S::k_Iw;
-            double *ac = L + S::k_Ic, *an_ = L + S::k_Ic + NB;
-            DWBC_SYNC();
-            for (int i = th.tid; i < nb; i += NT) {
-                const double *bd = body + i * kBodyStride;
-                double Ri[9], pi[3];
-                for (int a = 0; a < 9; a++) Ri[a] = (i == 0) ? Rw[a] : Rl[i * 9 + a];
-                for (int a = 0; a < 3; a++) pi[a] = (i == 0) ? pw[a] : bd[BF_PT + a];
-                const double an = (i == 0) ? -1.0 : (double)topo[i];
-                for (int a = 0; a < 9; a++) Rc[i * 9 + a] = Ri[a];
-                for (int a = 0; a < 3; a++) pc[i * 3 + a] = pi[a];
-                ac[i] = an;
-            }
-            for (int r = 0; r < rounds; r++) {
-                DWBC_SYNC();
-                for (int i = th.tid; i < nb; i += NT) {
-                    // all loads first (the compiler cannot reorder LDS loads across the stores below: same base pointer)
-                    const int an = (int)ac[i];
-                    const int aa = an < 0 ? 0 : an;
-                    double Ri[9], pi[3], Ra[9], pa[3];
-                    for (int a = 0; a < 9; a++) { Ri[a] = Rc[i * 9 + a]; Ra[a] = Rc[aa * 9 + a]; }
-                    for (int a = 0; a < 3; a++) { pi[a] = pc[i * 3 + a]; pa[a] = pc[aa * 3 + a]; }
-                    const double a2 = ac[aa];
-                    double Ro[9], po[3];
-                    for (int a = 0; a < 3; a++) {
-                        for (int c = 0; c < 3; c++) Ro[a * 3 + c] = Ra[a * 3] * Ri[c] + Ra[a * 3 + 1] * Ri[3 + c] + Ra[a * 3 + 2] * Ri[6 + c];
-                        po[a] = pa[a] + Ra[a * 3] * pi[0] + Ra[a * 3 + 1] * pi[1] + Ra[a * 3 + 2] * pi[2];
-                    }
-                    for (int a = 0; a < 9; a++) Rn[i * 9 + a] = an < 0 ? Ri[a] : Ro[a];
-                    for (int a = 0; a < 3; a++) pn[i * 3 + a] = an < 0 ? pi[a] : po[a];
-                    an_[i] = an < 0 ? -1.0 : a2;
-                }
-                { double *t_ = Rc; Rc = Rn; Rn = t_; t_ = pc; pc = pn; pn = t_; t_ = ac; ac = an_; an_ = t_; }
-            }
-        }
-        DWBC_SYNC();
-        double *Iw = L + S::k_Iw;
-        DWBC_FSTAMP(34);
-        for (int i = th.tid; i < nb; i += NT) {
-            const double *bd = body + i * kBodyStride;
-            const double *R = Rw + i * 9;
-            for (int a = 0; a < 3; a++) aw[i * 3 + a] = R[a * 3] * bd[BF_AXIS] + R[a * 3 + 1] * bd[BF_AXIS + 1] + R[a * 3 + 2] * bd[BF_AXIS + 2];
-            const double m = bd[BF_MASS];
-            double r[3];
-            for (int a = 0; a < 3; a++)
-                r[a] = pw[i * 3 + a] + R[a * 3] * bd[BF_COM] + R[a * 3 + 1] * bd[BF_COM + 1] + R[a * 3 + 2] * bd[BF_COM + 2] - pw[a];
-            const double Ic[9] = {bd[BF_ICOM], bd[BF_ICOM + 1], bd[BF_ICOM + 2], bd[BF_ICOM + 1], bd[BF_ICOM + 3],
-                                  bd[BF_ICOM + 4], bd[BF_ICOM + 2], bd[BF_ICOM + 4], bd[BF_ICOM + 5]};
-            double Tm[9];
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) Tm[a * 3 + b] = R[a * 3] * Ic[b] + R[a * 3 + 1] * Ic[3 + b] + R[a * 3 + 2] * Ic[6 + b];
-            const double rr2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-            double *o = Iw + i * 10;
-            o[0] = m;
-            o[1] = m * r[0]; o[2] = m * r[1]; o[3] = m * r[2];
-            int c = 4;
-            for (int a = 0; a < 3; a++)
-                for (int b = a; b < 3; b++) {
-                    double v = Tm[a * 3] * R[b * 3] + Tm[a * 3 + 1] * R[b * 3 + 1] + Tm[a * 3 + 2] * R[b * 3 + 2];
-                    v += m * ((a == b ? rr2 : 0.0) - r[a] * r[b]);
-                    o[c++] = v;
-                }
-        }
-        DWBC_SYNC();
-        DWBC_FSTAMP(35);
-        // composite inertia of the subtree [i, i + len_i) (bodies are numbered depth first).  Window sums of length 2^k
-        // by doubling, S_{k+1}[i] = S_k[i] + S_k[i + 2^k] (ping-pong Iw <-> k_Ic); the subtree sum picks S_k at the set bits
-        // of len_i, so no differences of large prefix sums are taken.  Lane i owns body i: its 10 window sums and its
-        // accumulator stay in registers, every round is one batch of independent LDS loads.
-        double *Icm = L + S::k_Ic;
-        {
-            double *Sc = Iw, *Sn = Icm;
-            PLA(double, sk, 10);
-            PLA(double, acc, 10);
-            PL(int, len);
-            LANES {
-                const int bi = lane < nb ? lane : 0;
-                LV(len) = lane < nb ? topo[2 * nb + bi] : 0;
-#pragma unroll
-                for (int c = 0; c < 10; c++) { LV(sk)[c] = Sc[bi * 10 + c]; LV(acc)[c] = 0.0; }
-            }
-            for (int kbit = 0, off = 1; off < nb; kbit++, off <<= 1) {
-                LANES {
-                    const bool take = (LV(len) >> kbit) & 1;
-                    int pos = lane + (LV(len) & (off - 1));
-                    pos = (take && pos < nb) ? pos : 0;
-                    const bool nbr = lane + off < nb;
-                    const int pn = nbr ? lane + off : 0;
-                    double a_[10], b_[10];
-#pragma unroll
-                    for (int c = 0; c < 10; c++) { a_[c] = Sc[pos * 10 + c]; b_[c] = Sc[pn * 10 + c]; }
-#pragma unroll
-                    for (int c = 0; c < 10; c++) {
-                        LV(acc)[c] += take ? a_[c] : 0.0;
-                        LV(sk)[c] += nbr ? b_[c] : 0.0;
-                        if (lane < nb) Sn[lane * 10 + c] = LV(sk)[c];
-                    }
-                }
-                DWBC_SYNC();
-                { double *t_ = Sc; Sc = Sn; Sn = t_; }
-            }
-            LANES {
-                if (lane < nb) {
-#pragma unroll
-                    for (int c = 0; c < 10; c++) Icm[lane * 10 + c] = LV(acc)[c];
-                }
-            }
-            DWBC_SYNC();
-        }
-        DWBC_FSTAMP(36);
-        double *Sm = L + S::k_S, *Fm = L + S::k_F;
-        for (int j = th.tid; j < N; j += NT) {
-            double w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
-            if (j < 3) {
-                v[j] = 1.0;
-            } else if (j < 6) {
-                for (int a = 0; a < 3; a++) w[a] = Rw[a * 3 + (j - 3)];
-            } else {
-                const int b = j - 5;
-                for (int a = 0; a < 3; a++) w[a] = aw[b * 3 + a];
-                const double d0 = pw[b * 3] - pw[0], d1 = pw[b * 3 + 1] - pw[1], d2 = pw[b * 3 + 2] - pw[2];
-                v[0] = d1 * w[2] - d2 * w[1];
-                v[1] = d2 * w[0] - d0 * w[2];
-                v[2] = d0 * w[1] - d1 * w[0];
-            }
-            for (int a = 0; a < 3; a++) { Sm[j * 6 + a] = w[a]; Sm[j * 6 + 3 + a] = v[a]; }
-        }
-        DWBC_SYNC();
-        DWBC_FSTAMP(37);
-        for (int j = th.tid; j < N; j += NT) {
-            const int b = j < 6 ? 0 : j - 5;
-            const double *I = Icm + b * 10;
-            const double *sv = Sm + j * 6;
-            const double m = I[0], h0 = I[1], h1 = I[2], h2 = I[3];
-            const double w0 = sv[0], w1 = sv[1], w2 = sv[2], v0 = sv[3], v1 = sv[4], v2 = sv[5];
-            Fm[j * 6 + 0] = I[4] * w0 + I[5] * w1 + I[6] * w2 + (h1 * v2 - h2 * v1);
-            Fm[j * 6 + 1] = I[5] * w0 + I[7] * w1 + I[8] * w2 + (h2 * v0 - h0 * v2);
-            Fm[j * 6 + 2] = I[6] * w0 + I[8] * w1 + I[9] * w2 + (h0 * v1 - h1 * v0);
-            Fm[j * 6 + 3] = m * v0 + (w1 * h2 - w2 * h1);
-            Fm[j * 6 + 4] = m * v1 + (w2 * h0 - w0 * h2);
-            Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
-        }
-        DWBC_SYNC();
-        DWBC_FSTAMP(38);
-        // A[j][k] = S_k . F_j for k on the path from j to the root (CRBA, [ext] RBDL CompositeRigidBodyAlgorithm), staged
-        // through LDS once and then loaded column-per-lane into registers
-        double *A = L + S::k_A;
-        for (int idx = th.tid; idx < N * N; idx += NT) A[idx] = 0.0;
-        double *pdof = L + S::k_col;  // parent dof of every dof (the walk below would otherwise read topo from HBM per step)
-        for (int j = th.tid; j < N; j += NT) {
-            int pj = j - 1;
-            if (j >= 6) { const int pb = topo[j - 5]; pj = pb == 0 ? 5 : pb + 5; }
-            pdof[j] = (double)pj;
-        }
-        DWBC_SYNC();
-        DWBC_FSTAMP(39);
-        for (int j = th.tid; j < N; j += NT) {
-            const double *f = Fm + j * 6;
-            int kk = j;
-            for (;;) {
-                const double *sv = Sm + kk * 6;
-                const double v = sv[0] * f[0] + sv[1] * f[1] + sv[2] * f[2] + sv[3] * f[3] + sv[4] * f[4] + sv[5] * f[5];
-                A[j * N + kk] = v;
-                A[kk * N + j] = v;
-                if (kk == 0) break;
-                kk = (int)pdof[kk];
-            }
-        }
-        DWBC_SYNC();
-        DWBC_FSTAMP(40);
-        LANES {
-            const int col = lane < N ? lane : 0;
-#pragma unroll
-            for (int i = 0; i < N; i++) LV(s)[i] = (lane < N) ? A[i * N + col] : 0.0;
-            LV(dg) = (lane < N) ? A[col * N + col] : 1.0;
-            if (lane < N) L[S::G + lane] = kGrav * A[2 * N + col];  // G_ = -J_com_lin^T m g = 9.81 * A[2,:] (dwbc.cpp:358)
-        }
-        DWBC_FSTAMP(41);
-        if (dump) {
-            LANES {
-                if (lane < N) {
-#pragma unroll
-                    for (int i = 0; i < N; i++) dump[dl.A + i * N + lane] = LV(s)[i];
-                }
-            }
-            for (int idx = th.tid; idx < nb * 9; idx += NT) dump[dl.link_R + idx] = Rw[idx];
-            for (int idx = th.tid; idx < nb * 3; idx += NT) dump[dl.link_p + idx] = pw[idx];
-            dump_centroidal<N, NT>(th, A, N, Rw, L + S::q, A[0], dump, dl);  // A(0,0) = total mass
-        }
-    }
-    DWBC_STAMP(0);  // kinematics + CRBA done
-    int st_contact = 1;
-    // A_inv (dwbc.cpp:307)
-    if (!sweep_inverse_rl<N>(s, dg)) st_contact = 0;
-    if (dump) {
-        LANES {
-            if (lane < N) {
-#pragma unroll
-                for (int i = 0; i < N; i++) dump[dl.A_inv + i * N + lane] = LV(s)[i];
-            }
-        }
-        for (int j = th.tid; j < N; j += NT) dump[dl.G + j] = L[S::G + j];
-    }
-    DWBC_STAMP(1);  // A_inv done
+#include "dwbc_cycle2_stage0.inc"
 
-    // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
-    const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
-    int act_c[kMaxActiveContacts] = {0, 0};
-    int nc = 0;
-    for (int i = 0; i < su.n_contacts; i++)
-        if (fl[i] && nc < kMaxActiveContacts) act_c[nc++] = i;
-    const int cd = 6 * nc, k = cd > 6 ? cd - 6 : 0;
-    DWBC_SYNC();
-    for (int a = 0; a < nc; a++) {
-        const int ci = act_c[a], link = su.c_link[ci];
-        const double *R = L + S::Rw + link * 9;
-        for (int r = th.tid; r < 12; r += NT) {
-            if (r < 9) L[S::Rc + a * 9 + r] = R[r];
-            else {
-                const int x = r - 9;
-                L[S::Pc + a * 3 + x] = L[S::pw + link * 3 + x] + R[x * 3] * su.c_point[ci][0] + R[x * 3 + 1] * su.c_point[ci][1] + R[x * 3 + 2] * su.c_point[ci][2];
-            }
-        }
-    }
-    DWBC_SYNC();
-    // J_C and Y = J_C A^-1 are kept TRANSPOSED in LDS (N x C): all C contact rows of one column are 96 contiguous bytes,
-    // so "own column . all rows" products fetch them with broadcast b128 reads and run C independent FMA chains
-    double *JCt = L + S::c_JC, *Yt = L + S::c_Y, *Lam = L + S::c_Lam, *JbT = L + S::JbT;
-    DWBC_FSTAMP(0);
-    for (int idx = th.tid; idx < C * N; idx += NT) { JCt[idx] = 0.0; Yt[idx] = 0.0; JbT[idx] = 0.0; }  // (the staged A is dead)
-    DWBC_SYNC();
-    for (int a = 0; a < nc; a++)
-        point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JCt, 1, 6 * a, 6, 0, C);
-    DWBC_SYNC();
-    DWBC_FSTAMP(1);  // J_C built
-    // Y[:, lane] = J_C * (lane's column of A^-1).  Column i of J_C is zero unless dof i lies between the contact link and
-    // the base (su.c_dofmask): uniform branches skip the zero columns, per contact.
-    const unsigned long long cm0 = nc > 0 ? su.c_dofmask[act_c[0]] : 0ull, cm1 = nc > 1 ? su.c_dofmask[act_c[1]] : 0ull;
-    static_assert(C == 12, "two 6D contacts");
-    LANES {
-        double yc[C];
-#pragma unroll
-        for (int p = 0; p < C; p++) yc[p] = 0.0;
-#pragma unroll
-        for (int ib = 0; ib < N; ib += 3) {  // one uniform branch per 3 columns and contact (a branch costs ~40 cycles)
-            if ((cm0 >> ib) & 7) {
-#pragma unroll
-                for (int i = ib; i < ib + 3 && i < N; i++)
-#pragma unroll
-                    for (int p = 0; p < 6; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
-            }
-            if ((cm1 >> ib) & 7) {
-#pragma unroll
-                for (int i = ib; i < ib + 3 && i < N; i++)
-#pragma unroll
-                    for (int p = 6; p < C; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
-            }
-        }
-        if (lane < N) {
-#pragma unroll
-            for (int p = 0; p < C; p++) Yt[lane * C + p] = yc[p];
-        }
-    }
-    DWBC_SYNC();
-    DWBC_FSTAMP(2);  // Y
-    for (int idx = th.tid; idx < cd * cd; idx += NT) {  // J A^-1 J^T = Y J_C^T
-        const int i = idx / cd, j = idx - i * cd;
-        double a4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c = 0; c < N; c++) a4[c & 3] += Yt[c * C + i] * JCt[c * C + j];
-        L[S::c_s2 + idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    }
-    if (cd > 0) {
-        if (!spd_inverse_small(L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
-    }
-    DWBC_SYNC();
-    DWBC_FSTAMP(3);  // Lambda_c
-    // J̄^T = Lambda J A^-1 (wbd.cpp:116), then A^-1 N_c = A^-1 - Y^T J̄^T (wbd.cpp:117-118, N_c never materialised)
-    LANES {
-        double yc[C], jb[C];
-        const int col = lane < N ? lane : 0;
-#pragma unroll
-        for (int p = 0; p < C; p++) yc[p] = Yt[col * C + p];
-#pragma unroll
-        for (int p = 0; p < C; p++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int p2 = 0; p2 < C; p2++) acc += ((p < cd && p2 < cd) ? Lam[p * cd + p2] : 0.0) * yc[p2];
-            jb[p] = acc;
-            if (lane < N) JbT[p * N + lane] = acc;
-        }
-        double dsub = 0.0;
-#pragma unroll
-        for (int p = 0; p < C; p++) dsub += yc[p] * jb[p];
-        LV(dg) -= dsub;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int p = 0; p < C; p += 2) { a0 += Yt[i * C + p] * jb[p]; a1 += Yt[i * C + p + 1] * jb[p + 1]; }
-            LV(s)[i] -= a0 + a1;
-        }
-    }
-    DWBC_SYNC();
-    if (dump) {
-        for (int idx = th.tid; idx < cd * N; idx += NT) { dump[dl.J_C + idx] = JCt[(idx % N) * C + idx / N]; dump[dl.J_C_INV_T + idx] = JbT[idx]; }
-        for (int idx = th.tid; idx < cd * cd; idx += NT) dump[dl.Lambda_c + idx] = Lam[idx];
-        LANES {
-            if (lane < N) {
-#pragma unroll
-                for (int i = 0; i < N; i++) dump[dl.A_inv_N_C + i * N + lane] = LV(s)[i];
-            }
-        }
-    }
-    DWBC_FSTAMP(5);  // AiNc
-    // gravity pre-vector (A^-1 N_c G) and P_C = J̄^T G  (wbd.cpp:186-192)
-    LANES {
-        double a4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < N; i++) a4[i & 3] += LV(s)[i] * L[S::G + i];
-        const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        if (lane < N) L[S::c_vec + lane] = acc;
-    }
-    mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
-    DWBC_STAMP(2);  // J_C, Lambda_c, J̄, A^-1 N_c done
-    DWBC_FSTAMP(6);  // vec, PC
+#include "dwbc_cycle2_stage1.inc"
     // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
     double *Vb = L + S::c_Vb, *VG = L + S::c_VG;
     if (k > 0) {

@@ -93,16 +93,19 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             s2 += g2;
             a2 += (j < t) ? g2 : g2 * (1.0 / (kQpScaleGI * kQpScaleGI));
         }
-        const double gn = s2 < 1e-300 ? 1e-150 : sqrt(s2);
-        const double rg = 1.0 / gn;
-        LV(fs) = a2 < 1e-300 ? 1.0 : gn / sqrt(a2);
+        // a numerically zero row (|g| < kQpZeroRow) is the constraint 0 <= hi: its coefficients are dropped and its
+        // slack is taken unnormalised, so noise never becomes a unit normal (oracle: QP_ZERO_ROW)
+        const bool zrow = s2 < kQpZeroRow * kQpZeroRow;
+        const double gn = zrow ? 1.0 : sqrt(s2);
+        const double rg = zrow ? 0.0 : 1.0 / gn;
+        LV(fs) = zrow ? 1.0 : gn / sqrt(a2);
 #pragma unroll
         for (int j = 0; j < kQpN; j++) {
             LV(R.g)[j] *= rg;
             LV(Mx)[j] = (lane == j) ? 1.0 : 0.0;
         }
-        if (LV(R.hi) < DWBC_QP_INF) LV(R.hi) *= rg;
-        if (LV(R.lo) < DWBC_QP_INF) LV(R.lo) *= rg;
+        if (LV(R.hi) < DWBC_QP_INF && !zrow) LV(R.hi) *= rg;
+        if (LV(R.lo) < DWBC_QP_INF && !zrow) LV(R.lo) *= rg;
         LV(d) = 0.0;
         LV(u) = 0.0;
         LV(akey) = 0;

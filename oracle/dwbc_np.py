@@ -233,6 +233,7 @@ def force_const(mu, muz):
 # ----------------------------------------------------------------------------------------------
 QP_SCALE = 1.0e4  # c = QP_SCALE * c_hat ; eps = 1/QP_SCALE^2 Tikhonov weight used to FIND the active set
 QP_TOL = 1.0e-9
+QP_ZERO_ROW = 1.0e-9  # rows with a smaller norm are treated as 0 . x <= b (their slack is taken unnormalised)
 
 
 def _gi_least_distance(G, b, max_iter):
@@ -243,7 +244,8 @@ def _gi_least_distance(G, b, max_iter):
     x = np.zeros(n)
     act = []
     u = np.zeros(0)
-    gnorm = np.maximum(np.linalg.norm(G, axis=1), 1e-300)
+    gnorm = np.linalg.norm(G, axis=1)
+    gnorm[gnorm < QP_ZERO_ROW] = 1.0  # a numerically zero row is the constraint 0 <= b: never normalised by its noise
     it = 0
     while True:
         s = b - G @ x
@@ -332,7 +334,8 @@ QP_FEAS_TOL = 1.0e-7  # acceptance of the lexicographic point: slack / |row| >= 
 
 
 def _worst_slack(A, ub, x):
-    nrm = np.maximum(np.linalg.norm(A, axis=1), 1e-300)
+    nrm = np.linalg.norm(A, axis=1)
+    nrm[nrm < QP_ZERO_ROW] = 1.0
     return float(((ub - A @ x) / nrm).min()) if A.shape[0] else 0.0
 
 

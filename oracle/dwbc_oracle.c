@@ -21,6 +21,7 @@
 #define GRAV 9.81
 #define QP_SCALE 1.0e4
 #define QP_TOL 1.0e-9
+#define QP_ZERO_ROW 1.0e-9 /* rows with a smaller norm are treated as 0 . x <= b */
 #define QP_FEAS_TOL 1.0e-7
 
 int orc_sizeof_model(void) { return (int)sizeof(orc_model); }
@@ -278,7 +279,7 @@ static int gi_least_distance(const double *G, const double *b, int m, int n, int
         double s = 0.0;
         for (int j = 0; j < n; j++) s += G[i * n + j] * G[i * n + j];
         gnorm[i] = sqrt(s);
-        if (gnorm[i] < 1e-300) gnorm[i] = 1e-300;
+        if (gnorm[i] < QP_ZERO_ROW) gnorm[i] = 1.0; /* numerically zero row = the constraint 0 <= b: slack taken as is */
     }
     for (int j = 0; j < n; j++) x[j] = 0.0;
     for (;;) {
@@ -453,7 +454,7 @@ int orc_solve_qp(const double *A, const double *ub, int rows, int nv, int t, int
             double sl = ub[i], nr = 0.0;
             for (int j = 0; j < nv; j++) { sl -= A[i * nv + j] * x[j]; nr += A[i * nv + j] * A[i * nv + j]; }
             nr = sqrt(nr);
-            if (nr < 1e-300) nr = 1e-300;
+            if (nr < QP_ZERO_ROW) nr = 1.0;
             if (sl / nr < worst) worst = sl / nr;
         }
         if (worst < -QP_FEAS_TOL) use_tikhonov = 1;

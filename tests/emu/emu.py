@@ -27,6 +27,7 @@ def lib():
         L.emu_set_tau_lim.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_dump_offset.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.emu_run_reduced.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         _lib = L
     return _lib
 
@@ -63,7 +64,7 @@ class Emu:
         self.L.emu_get_model(self.h, *[out[k].ctypes.data for k in ("parent", "R_T", "p_T", "axis", "mass", "com", "inertia")])
         return out
 
-    def run(self, q, flags, fstar, dump=False):
+    def run(self, q, flags, fstar, dump=False, reduced=False):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -74,7 +75,7 @@ class Emu:
         st = np.zeros(B, np.int32)
         diag = np.zeros((B, 90), np.int32)
         dmp = np.zeros((B, self.D)) if dump else None
-        ok = self.L.emu_run(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
+        ok = (self.L.emu_run_reduced if reduced else self.L.emu_run)(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
                             st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)
         assert ok == 1, self.L.emu_error(self.h)
         return dict(tau=tau, wrench=wr, status=st, diag=diag, dump=dmp)

@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "../../libdwbc_amd/csrc/dwbc_cycle2.h"
+#include "../../libdwbc_amd/csrc/dwbc_reduced.h"
 #include "../../libdwbc_amd/csrc/dwbc_model.h"
 #include "../../libdwbc_amd/csrc/dwbc_setup.h"
 
@@ -72,6 +72,24 @@ int emu_diag_count() { return DG_COUNT; }
 int emu_lds_bytes() { return Lds<39, 34>::total_bytes; }
 
 int emu_lds_bytes_v2(int nlv) { return nlv == 1 ? Lds2<39, 34, 1>::total_bytes : nlv == 2 ? Lds2<39, 34, 2>::total_bytes : nlv == 3 ? Lds2<39, 34, 3>::total_bytes : Lds2<39, 34, 4>::total_bytes; }
+
+int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau,
+                    double *wrench, int *status, int *diag, double *dump) {
+    if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
+    BatchIO io{};
+    io.B = B; io.q = q; io.flags = flags; io.fstar = fstar; io.tau = tau; io.wrench = wrench; io.status = status;
+    io.diag = diag; io.dump = dump; io.body = c->body.data(); io.topo = c->topo.data();
+    std::vector<double> lds(LdsR<39, 34, 4>::rtotal + 64);
+    std::vector<int> ilds(64);
+    for (int b = 0; b < B; b++) {
+        Thr th{0};
+        if (c->su.n_levels == 1) cycle_instance_reduced<39, 34, 1, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 2) cycle_instance_reduced<39, 34, 2, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 3) cycle_instance_reduced<39, 34, 3, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        else cycle_instance_reduced<39, 34, 4, 1>(th, c->su, io, b, lds.data(), ilds.data());
+    }
+    return 1;
+}
 
 int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
             int *status, int *diag, double *dump) {
