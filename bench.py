@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--workload", default="ds2", choices=["ds2", "ss3", "mixed", "reduced"],
+                    help="ds2 = BASELINE configs[1] (the metric's config, default); ss3 / mixed / reduced = configs[2] / [3] / [4] "
+                         "(parity-test cases; measured for DESIGN.md only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -77,9 +80,21 @@ def main():
         wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
     wbc.add_task(0, D.TASK_LINK_6D, 0)
     wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
-    wbc.set_torque_limit(np.array(cases.TAU_LIM))
-
-    q, flags, fstar = cases.synth_batch(B, seed=20251226 + 2 + 1000 * rank)
+    wl = args.workload
+    reduced = wl == "reduced"
+    if wl == "ss3":
+        wbc.add_task(2, D.TASK_LINK_6D, 12)  # swing (right) foot, SURVEY 8d config 3
+    if not reduced:
+        wbc.set_torque_limit(np.array(cases.TAU_LIM))  # the reference's reduced path runs without the limit (App. C-10)
+    f_alg = {"ds2": F_ALG, "ss3": 1.37e6, "mixed": F_ALG, "reduced": F_ALG}[wl]
+    workload_name = {
+        "ds2": "BASELINE configs[1]: batch=1024 per GPU, TOCABI double support, 2-level HQP (pelvis 6D + upper-body rotation), tau limit 300, fp64",
+        "ss3": "BASELINE configs[2]: TOCABI left single support + swing-foot task (3-level HQP), tau limit 300, fp64",
+        "mixed": "BASELINE configs[3]: TOCABI mixed contact modes LR/L/R = 1/2,1/4,1/4 per instance, 2-level HQP, tau limit 300, fp64",
+        "reduced": "BASELINE configs[4] in fp64: TOCABI double support through the reduced (centroidal) dynamics path, 2-level HQP, no tau limit",
+    }[wl]
+    kw = {"ss3": dict(contact_mode="L", levels=3), "mixed": dict(contact_mode="mixed")}.get(wl, {})
+    q, flags, fstar = cases.synth_batch(B, seed=20251226 + 2 + 1000 * rank, **kw)
     tq = torch.from_numpy(q).to(dev)
     tf = torch.from_numpy(flags).to(dev)
     ts = torch.from_numpy(fstar).to(dev)
@@ -101,7 +116,7 @@ def main():
         return out
 
     for _ in range(args.warmup):
-        wbc.solve()
+        wbc.solve(reduced=reduced)
     gather_final()
     torch.cuda.synchronize()
     if world > 1:
@@ -109,7 +124,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wbc.solve()
+        wbc.solve(reduced=reduced)
     gather_final()
     torch.cuda.synchronize()
     if world > 1:
@@ -126,14 +141,14 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream)
     for _ in range(args.steps):
-        wbc.solve()
+        wbc.solve(reduced=reduced)
     ev1.record(stream)
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
     if rank == 0:
         value = world * B * args.steps / dt
-        achieved = F_ALG * B / (kern_ms * 1e-3) / 1e12
+        achieved = f_alg * B / (kern_ms * 1e-3) / 1e12
         nt, lds = wbc.launch_info()
         line = {
             "metric": "HQP control cycles/sec (batched TOCABI)",
@@ -149,7 +164,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: batch=1024 per GPU, TOCABI double support, 2-level HQP (pelvis 6D + upper-body rotation), tau limit 300, fp64",
+                "workload": workload_name,
                 "batch_per_gpu": B,
                 "threads_per_instance": nt,
                 "lds_bytes_per_instance": lds,
@@ -165,13 +180,13 @@ def main():
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_final_pmc_summary.json)",
                 "kernel": wbc.kernel_name(),
                 "kernel_ms": kern_ms,
-                "flop_per_cycle": F_ALG,
+                "flop_per_cycle": f_alg,
                 "note": "fp64 FMA roof (vector = matrix rate on MI355X, public spec 78.6 TFLOP/s); algorithmic flop of the "
                         "reference's dense formulas.  batch 1024 = one wave per SIMD, where tools/ubench measures 23.3 TFLOP/s "
                         "for back-to-back fp64 FMAs from a single wave (24.0 for MFMA f64 16x16x4): DESIGN.md 'Measured'",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl == "ds2":
             from oracle import orc
 
             M = orc.make_model(cases.tocabi_model())

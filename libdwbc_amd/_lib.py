@@ -7,7 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DWBC_TIMED=1 selects the diagnostic build with in-kernel stage stamps (never used for reported numbers)
-LIB_PATH = os.path.join(_HERE, "libdwbc_hip_timed.so" if os.environ.get("DWBC_TIMED") == "1" else "libdwbc_hip.so")
+_VARIANT = os.environ.get("DWBC_LIB_VARIANT")  # development A/B builds (csrc/Makefile target `experiment`)
+LIB_PATH = os.path.join(_HERE, "libdwbc_hip_timed.so" if os.environ.get("DWBC_TIMED") == "1" else (f"libdwbc_hip_{_VARIANT}.so" if _VARIANT else "libdwbc_hip.so"))
 
 # every symbol include/dwbc_batch.h declares: (name, restype, argtypes)
 _vp, _i, _d, _cp = C.c_void_p, C.c_int, C.c_double, C.c_char_p

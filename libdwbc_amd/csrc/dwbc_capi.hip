@@ -83,6 +83,15 @@ struct KernelEntry {
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
 // index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
+#ifdef DWBC_EXPERIMENT
+// A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
+const KernelEntry kKernels[] = {
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
+};
+const KernelEntry kKernelsReduced[] = {
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
+};
+#else
 const KernelEntry kKernels[] = {
     {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT>},
     {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
@@ -95,9 +104,14 @@ const KernelEntry kKernelsReduced[] = {
     {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr},
     {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr},
 };
+#endif
+#ifdef DWBC_EXPERIMENT
+const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr}};
+#else
 const KernelEntry kKernelsV1[] = {
     {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
 };
+#endif
 }  // namespace
 
 struct dwbc_model {

@@ -26,7 +26,7 @@
 //
 // Scope (device sets status 0 otherwise): 1 or 2 active CONTACT_6D contacts whose chains occupy the leading joint
 // dofs (TOCABI: L+R or L), every task level made of links that are all on / all off the contact chains, level 0 on
-// the chains, at most one non-contact level, no COM ("cmm") task, no torque limit (reference App. C-7/C-10).
+// the chains, no COM ("cmm") task, no torque limit (reference App. C-7/C-10).
 #pragma once
 #include "dwbc_cycle2.h"
 
@@ -53,8 +53,11 @@ struct LdsR : Lds2<N, NB, NLV> {
     static constexpr int XR = UR + NLV * RMX * T;     // NLV x RMX x T   J_kt_R Lambda
     static constexpr int YR = XR + NLV * RMX * T;     // NLV x T x RMX   (J_task_R A_R_inv N_CR)[:,6:]
     static constexpr int UNC = YR + NLV * T * RMX;    // RMX x T   Null J_base_R_kt_
-    static constexpr int MT = UNC + RMX * T;          // N x T     J_task^T Lambda of the non-contact level
-    static constexpr int JR = MT + N * T;             // T x RSX
+    static constexpr int MT = UNC + RMX * T;          // NLV x N x T   J_task^T Lambda of a non-contact level
+    static constexpr int PN = MT + NLV * N * T;       // NLV x N x T   J_{l-1}^T Lambda_{l-1} J_{l-1} A^-1 N_c J_l^T Lambda_l (dwbc.cpp:3313-3316)
+    static constexpr int JttP = PN + NLV * N * T;     // N x T     previous level's J_task^T
+    static constexpr int T1P = JttP + N * T;          // T x N     previous level's J_task A^-1 N_c
+    static constexpr int JR = T1P + T * N;            // T x RSX
     static constexpr int T1R = JR + T * RSX;          // T x RSX
     static constexpr int QRr = T1R + T * RSX;         // T x RMX
     static constexpr int QWR = QRr + T * RMX;         // T x RMX
@@ -554,7 +557,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             if (co) nco++; else nnc++;
         }
         kind[lv] = (nco && !nnc) ? 1 : ((nnc && !nco) ? 2 : 0);
-        if (kind[lv] == 2) { if (first_nc < 0) first_nc = lv; else kind[lv] = 0; }
+        if (kind[lv] == 2 && first_nc < 0) first_nc = lv;
         if (kind[lv] == 0 || (lv == 0 && kind[lv] != 1)) st_task = 0;
     }
     for (int lv = 0; lv < su.n_levels && st_task; lv++) {
@@ -637,8 +640,64 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 double acc = 0.0;
                 if (r2 < t)
                     for (int r = 0; r < t; r++) acc += Jtt[j * T + r] * Lt[r * t + r2];
-                L[S::MT + idx] = acc;
+                L[S::MT + lv * N * T + idx] = acc;
             }
+            DWBC_SYNC();
+            if (lv != first_nc) {
+                // later non-contact levels (nc_heirarchy_ >= 1): PN = J_p^T Lambda_p (J_p A^-1 N_c J^T) Lambda with p = lv - 1,
+                // so that J_p^T null_force_ = PN f* (dwbc.cpp:3313-3316)
+                const int tp = su.t_dof[lv - 1];
+                const double *Ltp = L + S::c_Lt + (lv - 1) * T * T, *T1P = L + S::T1P, *JttP = L + S::JttP;
+                double *B1 = L + S::sm, *B2 = L + S::sm + 36, *B3 = L + S::sm + 72;
+                for (int idx = th.tid; idx < tp * t; idx += NT) {
+                    const int i = idx / t, j = idx - i * t;
+                    double acc = 0.0;
+                    for (int c = 0; c < N; c++) acc += T1P[i * N + c] * Jtt[c * T + j];
+                    B1[idx] = acc;
+                }
+                DWBC_SYNC();
+                for (int idx = th.tid; idx < tp * t; idx += NT) {
+                    const int i = idx / t, j = idx - i * t;
+                    double acc = 0.0;
+                    for (int a = 0; a < tp; a++) acc += Ltp[i * tp + a] * B1[a * t + j];
+                    B2[idx] = acc;
+                }
+                DWBC_SYNC();
+                for (int idx = th.tid; idx < tp * t; idx += NT) {
+                    const int i = idx / t, j = idx - i * t;
+                    double acc = 0.0;
+                    for (int a = 0; a < t; a++) acc += B2[i * t + a] * Lt[a * t + j];
+                    B3[idx] = acc;
+                }
+                DWBC_SYNC();
+                for (int idx = th.tid; idx < N * T; idx += NT) {
+                    const int j = idx / T, r = idx - j * T;
+                    double acc = 0.0;
+                    if (r < t)
+                        for (int a = 0; a < tp; a++) acc += JttP[j * T + a] * B3[a * t + r];
+                    L[S::PN + lv * N * T + idx] = acc;
+                }
+                DWBC_SYNC();
+            }
+        }
+        // keep J^T and J A^-1 N_c of this level if the next one is a later non-contact level
+        if (lv + 1 < su.n_levels && kind[lv + 1] == 2 && lv + 1 != first_nc) {
+            if (kind[lv] == 1) {
+                LANES {
+                    double tc_[T];
+#pragma unroll
+                    for (int r = 0; r < T; r++) tc_[r] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; i++)
+#pragma unroll
+                        for (int r = 0; r < T; r++) tc_[r] += Jtt[i * T + r] * LV(s)[i];
+#pragma unroll
+                    for (int r = 0; r < T; r++)
+                        if (lane < N) T1[r * N + lane] = tc_[r];
+                }
+                DWBC_SYNC();
+            }
+            for (int idx = th.tid; idx < N * T; idx += NT) { L[S::JttP + idx] = Jtt[idx]; L[S::T1P + idx] = T1[idx]; }
             DWBC_SYNC();
         }
     }
@@ -664,10 +723,16 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             const int t = su.t_dof[qi];
             const double *fs = fs_in + su.fstar_off[qi];
             double *tmpv = L + S::Bmt;  // N
+            double *tmp2 = L + S::tmpE;  // N: J_p^T null_force_ for the later non-contact levels, else 0
+            const bool later = qi != first_nc;
             for (int j = th.tid; j < N; j += NT) {
-                double acc = 0.0;
-                for (int r = 0; r < t; r++) acc += L[S::MT + j * T + r] * fs[r];
+                double acc = 0.0, acc2 = 0.0;
+                for (int r = 0; r < t; r++) {
+                    acc += L[S::MT + qi * N * T + j * T + r] * fs[r];
+                    if (later) acc2 += L[S::PN + qi * N * T + j * T + r] * fs[r];
+                }
                 tmpv[j] = acc;
+                tmp2[j] = acc2;
             }
             DWBC_SYNC();
             double *fo = L + S::v6 + 6;  // this task's force_on_nc_
@@ -675,18 +740,23 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 double v;
                 if (a < 3) v = tmpv[a];
                 else v = L[S::Rw + (a - 3) * 3] * tmpv[3] + L[S::Rw + (a - 3) * 3 + 1] * tmpv[4] + L[S::Rw + (a - 3) * 3 + 2] * tmpv[5];
-                fo[a] = v;
-                fon[a] += v;
+                // later levels: temp_torque_ = J_p^T null_force_, angular part rotated (dwbc.cpp:3316-3318); both the level's
+                // force on the non-contact group and force_on_nc_r_ lose it (dwbc.cpp:3320,3324)
+                double v2;
+                if (a < 3) v2 = tmp2[a];
+                else v2 = L[S::Rw + (a - 3) * 3] * tmp2[3] + L[S::Rw + (a - 3) * 3 + 1] * tmp2[4] + L[S::Rw + (a - 3) * 3 + 2] * tmp2[5];
+                fo[a] = v - v2;
+                fon[a] += v - v2;
             }
             DWBC_SYNC();
             double *thR = L + S::thR;
             for (int i = th.tid; i < RM; i += NT) {
                 double acc = 0.0;
                 if (i < cod) { for (int a = 0; a < 6; a++) acc += Jbk[i * T + a] * fo[a]; }
-                else { for (int c = 0; c < ncd; c++) acc += JIiT[(i - cod) * NCX + c] * tmpv[vcd + c]; }
-                thR[i] = acc;
+                else { for (int c = 0; c < ncd; c++) acc += JIiT[(i - cod) * NCX + c] * (tmpv[vcd + c] - tmp2[vcd + c]); }
+                thR[i] = acc;  // torque_h_R_ (first level) / null_torque_h_r (later levels, dwbc.cpp:3320-3321)
             }
-            for (int i = th.tid; i < ncd; i += NT) tNC[i] += tmpv[vcd + i];  // torque_null_h_nc_ = torque_nc_ (nc_heirarchy_ == 0)
+            for (int i = th.tid; i < ncd; i += NT) tNC[i] += tmpv[vcd + i] - tmp2[vcd + i];  // torque_null_h_nc_ (dwbc.cpp:3309,3317)
             DWBC_SYNC();
             for (int pl = qi - 1; pl >= 0; pl--) {  // torque_null_h_R_ = Null_task_R_{qi-1} torque_h_R_
                 if (kind[pl] != 1 || pl == su.n_levels - 1) continue;

@@ -316,7 +316,10 @@ class ReducedCycle(Cycle):
                     temp[3:6] = R0 @ temp[3:6]
                     nthr = np.zeros(rm)
                     nthr[:cod] = th_R[i][:cod] - self.J_base_R_kt[:cod] @ temp[0:6]
-                    nthr[cod : cod + 6] = self.J_I_nc_inv_T @ (t_nc[i] - self.J_task_NC[i - 1].T @ null_force)
+                    # ts_[i-1].J_task_NC_ is only assigned for non-contact tasks (task.cpp:128); after a contact-chain
+                    # task the reference reads an unsized matrix.  Its definition is used for every previous level.
+                    JpNC = Jp[:, vcd : vcd + ncd]
+                    nthr[cod : cod + 6] = self.J_I_nc_inv_T @ (t_nc[i] - JpNC.T @ null_force)
                     tnull_R[i] = self.Null_R[i - 1] @ nthr
                     force_on_nc_r = force_on_nc_r - temp[0:6]
             else:

@@ -111,6 +111,33 @@ def test_emulated_reduced_kernel_vs_oracle(cfg):
     assert np.abs(r["tau"][:, 0] - tau[:, 0]).max() < 1e-8
 
 
+HIERARCHIES = {
+    # reference tests/sp_test/redu_dyn_test.cpp:98-103 without its COM level: pelvis, upper body (first non-contact level),
+    # right hand (a later non-contact level: the null_force_ branch, dwbc.cpp:3311-3325)
+    "pelvis_rot-upper-rhand": ([[(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(0, 33, (0, 0, 0))]], 12),
+    "pelvis6d-upper-rhand-lhandpos": ([[(0, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(0, 33, (0, 0, 0))], [(3, 23, (0, 0, 0))]], 18),
+    # a contact-chain level after the non-contact one (Null_task_R_ is carried over it, dwbc.cpp:3247-3250)
+    "pelvis_rot-upper-hiproll_pos": ([[(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(3, 1, (0, 0, 0))]], 9),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HIERARCHIES))
+def test_emulated_reduced_kernel_task_hierarchies(name):
+    from tests.emu.emu import Emu
+
+    tasks, nf = HIERARCHIES[name]
+    B = 6
+    q, fl, _ = cases.synth_batch(B, seed=11)
+    fs = 2.5 * np.random.default_rng(3).uniform(-1, 1, size=(B, nf))
+    e = Emu(cases.URDF, cases.CONTACTS_2, tasks, None)
+    r = e.run(q, fl, fs, reduced=True)
+    tau, wr, st = oracle_batch(q, fl, fs, tasks)
+    assert (r["status"] == st).all() and st.all()
+    assert np.abs(tau[:, 1]).max() > 1.0  # the hierarchy does something
+    assert np.abs(r["tau"] - tau).max() < TOL_TAU
+    assert np.abs(r["wrench"] - wr).max() < 1e-5
+
+
 def test_emulated_reduced_kernel_rejects_out_of_scope():
     from tests.emu.emu import Emu
 
