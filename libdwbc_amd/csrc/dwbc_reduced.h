@@ -36,32 +36,41 @@ template <int N, int NB, int NLV>
 struct LdsR : Lds2<N, NB, NLV> {
     using B2 = Lds2<N, NB, NLV>;
     static constexpr int RSX = 24, RMX = 18, NCX = N - 12, T = kMaxTaskDof, C = 6 * kMaxActiveContacts;
-    static constexpr int x0 = (B2::total + 1) & ~1;
+    // regions of the full-model map that the reduced cycle does not use hold reduced data:
+    //   [NwJw, Rw) (NwJw, FNl, U, Xl, T1r of dwbc_cycle2.h; free once the staged mass matrix is dead, i.e. after J_I_nc)
+    static constexpr int rblk = RSX * RSX + C * RSX + RMX * 6 + C * 6;
+    static constexpr int xb = (B2::total + 1) & ~1;
+    static constexpr bool reuse = (B2::Rw - ((B2::NwJw + 1) & ~1)) >= rblk;
+    static constexpr int AR = reuse ? ((B2::NwJw + 1) & ~1) : xb;  // RSX x RSX A_R_inv, later A_R_inv N_CR
+    static constexpr int JbR = AR + RSX * RSX;        // C x RSX   J_CR_INV_T
+    static constexpr int NwR = JbR + C * RSX;         // RMX x 6   NwJw_R
+    static constexpr int FNR = NwR + RMX * 6;         // C x 6     A_rot J̄_R[:,6:] NwJw_R
+    //   c_Y .. (dead after stage 1; the full model's c_Q / c_QW / c_Pi / c_Z slots of the task-space phase)
+    static constexpr int JR = (B2::c_Y + 1) & ~1;     // T x RSX
+    static constexpr int T1R = JR + T * RSX;          // T x RSX
+    static constexpr int QRr = T1R + T * RSX;         // T x RMX
+    static_assert(QRr + T * RMX <= B2::c_s1, "jkt scratch must stay below the small-inverse scratch");
+    static constexpr int x0 = reuse ? xb : xb + rblk;
     static constexpr int JIt = x0;                    // NCX x 6   J_I_nc transposed
     static constexpr int JIiT = JIt + NCX * 6;        // 6 x NCX   J_I_nc_inv_T
-    static constexpr int AR = JIiT + 6 * NCX;         // RSX x RSX A_R_inv, later A_R_inv N_CR
-    static constexpr int Bmt = AR + RSX * RSX;        // N x 6
+    static constexpr int Bmt = JIiT + 6 * NCX;        // N x 6
     static constexpr int tmpE = Bmt + N * 6;          // N x 6
-    static constexpr int ARrow = tmpE + N * 6;        // 6 x RSX   rows vc_dof.. of A_R
-    static constexpr int GR = ARrow + 6 * RSX;        // RSX
-    static constexpr int JbR = GR + RSX;              // C x RSX   J_CR_INV_T
-    static constexpr int PCR = JbR + C * RSX;         // C
-    static constexpr int NwR = PCR + C;               // RMX x 6   NwJw_R
-    static constexpr int FNR = NwR + RMX * 6;         // C x 6     A_rot J̄_R[:,6:] NwJw_R
-    static constexpr int Jbk = FNR + C * 6;           // RMX x T   J_base_R_kt_
+    static constexpr int GR = tmpE + N * 6;           // RSX
+    static constexpr int PCR = GR + RSX;              // C
+    static constexpr int Jbk = PCR + C;               // RMX x T   J_base_R_kt_
     static constexpr int UR = Jbk + RMX * T;          // NLV x RMX x T   Null_{l-1} J_kt_R Lambda
     static constexpr int XR = UR + NLV * RMX * T;     // NLV x RMX x T   J_kt_R Lambda
     static constexpr int YR = XR + NLV * RMX * T;     // NLV x T x RMX   (J_task_R A_R_inv N_CR)[:,6:]
     static constexpr int UNC = YR + NLV * T * RMX;    // RMX x T   Null J_base_R_kt_
-    static constexpr int MT = UNC + RMX * T;          // NLV x N x T   J_task^T Lambda of a non-contact level
-    static constexpr int PN = MT + NLV * N * T;       // NLV x N x T   J_{l-1}^T Lambda_{l-1} J_{l-1} A^-1 N_c J_l^T Lambda_l (dwbc.cpp:3313-3316)
-    static constexpr int JttP = PN + NLV * N * T;     // N x T     previous level's J_task^T
-    static constexpr int T1P = JttP + N * T;          // T x N     previous level's J_task A^-1 N_c
-    static constexpr int JR = T1P + T * N;            // T x RSX
-    static constexpr int T1R = JR + T * RSX;          // T x RSX
-    static constexpr int QRr = T1R + T * RSX;         // T x RMX
-    static constexpr int QWR = QRr + T * RMX;         // T x RMX
+    static constexpr int MT = UNC + RMX * T;          // (NLV-1) x N x T   J_task^T Lambda of non-contact level l at slot l-1
+    // later non-contact levels need >= 3 levels (level 0 is a contact-chain task, one level is the first non-contact one)
+    static constexpr int NPN = NLV >= 3 ? NLV : 0;
+    static constexpr int PN = MT + (NLV - 1) * N * T;       // NPN x N x T   J_{l-1}^T Lambda_{l-1} J_{l-1} A^-1 N_c J_l^T Lambda_l (dwbc.cpp:3313-3316)
+    static constexpr int JttP = PN + NPN * N * T;     // N x T     previous level's J_task^T
+    static constexpr int T1P = JttP + (NPN ? N * T : 0);  // T x N     previous level's J_task A^-1 N_c
+    static constexpr int QWR = T1P + (NPN ? T * N : 0);   // T x RMX
     static constexpr int sm = QWR + T * RMX;          // 6 small 6x6 blocks
+    static constexpr int ARrow = sm;                  // 6 x RSX   rows vc_dof.. of A_R (reduced-dynamics phase only)
     static constexpr int tgR = sm + 6 * 36;           // RMX
     static constexpr int ttR = tgR + RMX;             // RMX
     static constexpr int sumR = ttR + RMX;            // RMX
@@ -110,6 +119,7 @@ DWBC_DEV void reduce_to_R(Thr th, PLA_REF(double, s, N), const double *JIt, int 
     for (int idx = th.tid; idx < 36; idx += NT) {
         const int r = idx / 6, r2 = idx - r * 6;
         double acc = 0.0;
+        _Pragma("unroll 8")
         for (int i = 0; i < ncd; i++) acc += tmpE[(vcd + i) * 6 + r] * JIt[i * 6 + r2];
         Out[(vcd + r) * RSX + vcd + r2] = acc;
     }
@@ -184,6 +194,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
     for (int idx = th.tid; idx < t * RS; idx += NT) {
         const int r = idx / RS, b = idx - r * RS;
         double acc = 0.0;
+        _Pragma("unroll 8")
         for (int a = 0; a < RS; a++) acc += JRm[r * RSX + a] * AR[a * RSX + b];
         T1R[r * RSX + b] = acc;
     }
@@ -191,6 +202,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
     for (int idx = th.tid; idx < t * t; idx += NT) {
         const int i = idx / t, j = idx - i * t;
         double acc = 0.0;
+        _Pragma("unroll 8")
         for (int a = 0; a < RS; a++) acc += T1R[i * RSX + a] * JRm[j * RSX + a];
         s2[idx] = acc;
     }
@@ -200,6 +212,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
         const int i = idx / RM, c = idx - i * RM;
         double acc = 0.0;
         if (i < t)
+            _Pragma("unroll 8")
             for (int p = 0; p < t; p++) acc += Lam[i * t + p] * T1R[p * RSX + 6 + c];
         Q[i * RMX + c] = acc;
         if (i < t) Yo[i * RMX + c] = T1R[i * RSX + 6 + c];
@@ -217,6 +230,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
     for (int idx = th.tid; idx < t * t; idx += NT) {
         const int i = idx / t, j = idx - i * t;
         double acc = 0.0;
+        _Pragma("unroll 8")
         for (int a = 0; a < RM; a++) acc += QW[i * RMX + a] * Q[j * RMX + a];
         s2[idx] = acc;
     }
@@ -226,6 +240,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
         const int i = idx / T, r2 = idx - i * T;
         double acc = 0.0;
         if (r2 < t)
+            _Pragma("unroll 8")
             for (int r = 0; r < t; r++) acc += QW[r * RMX + i] * Pi[r * t + r2];
         Jkt[i * T + r2] = acc;
     }
@@ -234,6 +249,7 @@ DWBC_DEV int jkt_reduced(Thr th, double *L, PLA_REF(double, w, 18), int t, int R
         const int i = idx / T, r3 = idx - i * T;
         double acc = 0.0;
         if (r3 < t)
+            _Pragma("unroll 8")
             for (int r2 = 0; r2 < t; r2++) acc += Jkt[i * T + r2] * Lam[r2 * t + r3];
         Xo[i * T + r3] = acc;
     }
@@ -377,6 +393,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         }
         DWBC_SYNC();
     }
+    DWBC_STAMP(3);  // reduced dynamics: J_I_nc, A_R_inv, A_R, J_I_nc_inv_T
     const double *JIiT = L + S::JIiT;
 
 #include "dwbc_cycle2_stage1.inc"
@@ -391,6 +408,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         if (p < cd) {
             if (a < vcd) acc = JbT[p * N + a];
             else
+                _Pragma("unroll 8")
                 for (int i = 0; i < ncd; i++) acc += JbT[p * N + vcd + i] * JIt[i * 6 + (a - vcd)];
         }
         JbR[p * RSX + a] = acc;
@@ -400,6 +418,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         if (a < vcd) acc = L[S::G + a];
         else {
             acc = 0.0;
+            _Pragma("unroll 8")
             for (int i = 0; i < ncd; i++) acc += JIiT[(a - vcd) * NCX + i] * L[S::G + vcd + i];  // dwbc.cpp:2984
         }
         GR[a] = acc;
@@ -408,15 +427,18 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     for (int p = th.tid; p < C; p += NT) {
         double acc = 0.0;
         if (p < cd)
+            _Pragma("unroll 8")
             for (int a = 0; a < RS; a++) acc += JbR[p * RSX + a] * GR[a];
         PCR[p] = acc;  // P_CR (dwbc.cpp:3149)
     }
     for (int a = th.tid; a < RM; a += NT) {
         double acc = 0.0;
+        _Pragma("unroll 8")
         for (int b = 0; b < RS; b++) acc += AR[(6 + a) * RSX + b] * GR[b];
         L[S::vecR + a] = acc;  // (A_R_inv N_CR)[6:, :] G_R  (dwbc.cpp:3146)
     }
     DWBC_SYNC();
+    DWBC_STAMP(4);  // A_R_inv N_CR, J_CR_INV_T, G_R, P_CR
     // ---- NwJw_R and the projector on null(W_R): internal-wrench basis restricted to the chain joints
     double *Vb = L + S::c_Vb, *VG = L + S::c_VG, *NwR = L + S::NwR, *FNR = L + S::FNR;
     if (k > 0) {
@@ -446,6 +468,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         for (int idx = th.tid; idx < k * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;
             double acc = 0.0;
+            _Pragma("unroll 8")
             for (int c = 0; c < RM; c++) acc += JbR[i * RSX + 6 + c] * Vb[c * k + j];
             JV[idx] = acc;
         }
@@ -466,6 +489,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         for (int idx = th.tid; idx < cd * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;
             double acc = 0.0;
+            _Pragma("unroll 8")
             for (int c = 0; c < RM; c++) acc += JbR[i * RSX + 6 + c] * NwR[c * k + j];
             s1[idx] = acc;
         }
@@ -479,6 +503,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         }
         DWBC_SYNC();
     }
+    DWBC_STAMP(5);  // NwJw_R
     // ---- W_R^+ = (W_R + alpha P)^-1 - P / alpha, column per lane; torque_grav_R_ (dwbc.cpp:3146)
     PLA(double, w, 18);
     PL(double, dw);
@@ -532,6 +557,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     }
     DWBC_SYNC();
 
+    DWBC_STAMP(6);  // W_R^+ and gravity torque
     // ================= ReducedCalcTaskSpace (dwbc.cpp:3152-3253) =================
     int st_task = 1;
     double *JRm = L + S::JR, *Jbk = L + S::Jbk;
@@ -547,6 +573,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         if (!jkt_reduced<N, NB, NLV, NT>(th, L, w, 6, RS, RM, L + S::sm + 72, L + S::QWR /*Y scratch*/, Jbk, L + S::UNC /*X scratch*/))
             st_task = 0;
     }
+    DWBC_STAMP(7);  // J_base_R_kt_
     int kind[NLV];      // 1 = contact-chain ("reduced") task, 2 = non-contact task, 0 = unsupported mix
     int first_nc = -1;
     for (int lv = 0; lv < su.n_levels; lv++) {
@@ -600,6 +627,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < tp * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int c = 0; c < RM; c++) acc += Yp[i * RMX + c] * Ul[c * T + j];
                     Z[idx] = acc;
                 }
@@ -607,6 +635,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < RM * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double acc = Ul[i * T + j];
+                    _Pragma("unroll 8")
                     for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * Z[p * t + j];
                     Ul[i * T + j] = acc;
                 }
@@ -630,6 +659,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             for (int idx = th.tid; idx < t * t; idx += NT) {
                 const int i = idx / t, j = idx - i * t;
                 double acc = 0.0;
+                _Pragma("unroll 8")
                 for (int c = 0; c < N; c++) acc += T1[i * N + c] * Jtt[c * T + j];
                 L[S::sm + idx] = acc;
             }
@@ -639,8 +669,9 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 const int j = idx / T, r2 = idx - j * T;
                 double acc = 0.0;
                 if (r2 < t)
+                    _Pragma("unroll 8")
                     for (int r = 0; r < t; r++) acc += Jtt[j * T + r] * Lt[r * t + r2];
-                L[S::MT + lv * N * T + idx] = acc;
+                L[S::MT + (lv - 1) * N * T + idx] = acc;
             }
             DWBC_SYNC();
             if (lv != first_nc) {
@@ -652,6 +683,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < tp * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int c = 0; c < N; c++) acc += T1P[i * N + c] * Jtt[c * T + j];
                     B1[idx] = acc;
                 }
@@ -659,6 +691,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < tp * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int a = 0; a < tp; a++) acc += Ltp[i * tp + a] * B1[a * t + j];
                     B2[idx] = acc;
                 }
@@ -666,6 +699,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < tp * t; idx += NT) {
                     const int i = idx / t, j = idx - i * t;
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int a = 0; a < t; a++) acc += B2[i * t + a] * Lt[a * t + j];
                     B3[idx] = acc;
                 }
@@ -674,6 +708,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                     const int j = idx / T, r = idx - j * T;
                     double acc = 0.0;
                     if (r < t)
+                        _Pragma("unroll 8")
                         for (int a = 0; a < tp; a++) acc += JttP[j * T + a] * B3[a * t + r];
                     L[S::PN + lv * N * T + idx] = acc;
                 }
@@ -703,6 +738,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     }
     DWBC_SYNC();
 
+    DWBC_STAMP(8);  // task-space dynamics of every level
     // ================= ReducedCalcTaskControlTorque(hqp = true) (dwbc.cpp:3255-3446) =================
     const int ncone = 10 * nc;
     int st_redis = 1;
@@ -728,7 +764,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             for (int j = th.tid; j < N; j += NT) {
                 double acc = 0.0, acc2 = 0.0;
                 for (int r = 0; r < t; r++) {
-                    acc += L[S::MT + qi * N * T + j * T + r] * fs[r];
+                    acc += L[S::MT + (qi - 1) * N * T + j * T + r] * fs[r];
                     if (later) acc2 += L[S::PN + qi * N * T + j * T + r] * fs[r];
                 }
                 tmpv[j] = acc;
@@ -765,12 +801,14 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 double *Z = L + S::sm;
                 for (int i = th.tid; i < tp; i += NT) {
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int c = 0; c < RM; c++) acc += Yp[i * RMX + c] * thR[c];
                     Z[i] = acc;
                 }
                 DWBC_SYNC();
                 for (int i = th.tid; i < RM; i += NT) {
                     double acc = thR[i];
+                    _Pragma("unroll 8")
                     for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * Z[p];
                     thR[i] = acc;
                 }
@@ -797,6 +835,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < tp * 6; idx += NT) {
                     const int i = idx / 6, j = idx - i * 6;
                     double acc = 0.0;
+                    _Pragma("unroll 8")
                     for (int c = 0; c < RM; c++) acc += Yp[i * RMX + c] * Ul[c * T + j];
                     Z[idx] = acc;
                 }
@@ -804,6 +843,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
                 for (int idx = th.tid; idx < RM * 6; idx += NT) {
                     const int i = idx / 6, j = idx - i * 6;
                     double acc = Ul[i * T + j];
+                    _Pragma("unroll 8")
                     for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * Z[p * 6 + j];
                     Ul[i * T + j] = acc;
                 }
@@ -813,6 +853,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         DWBC_SYNC();
         for (int i = th.tid; i < RM; i += NT) {
             double acc = tgR[i] + ttR[i];
+            _Pragma("unroll 8")
             for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j];
             base[i] = acc;
         }
@@ -821,8 +862,10 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             const int i = fdt1.div(idx), j = idx - i * (t + 1);
             double acc = 0.0;
             if (j < t) {
+                _Pragma("unroll 8")
                 for (int c = 0; c < RM; c++) acc += JbR[i * RSX + 6 + c] * Ul[c * T + j];
             } else {
+                _Pragma("unroll 8")
                 for (int c = 0; c < RM; c++) acc += JbR[i * RSX + 6 + c] * base[c];
                 acc -= PCR[i];
             }
@@ -852,6 +895,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         if (is_level) {
             for (int i = th.tid; i < RM; i += NT) {
                 double acc = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
                 ttR[i] += acc;  // torque_task_R_ += Null J_kt_R Lambda (f* + f*_qp)  (dwbc.cpp:3346-3362)
             }
@@ -872,6 +916,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     }
     DWBC_SYNC();
 
+    DWBC_STAMP(9);  // task cascade + non-contact force QP
     // ================= ReducedCalcContactRedistribute(hqp = true) (dwbc.cpp:3758-3770, 4776-4941) =================
     if (k > 0 && st_task) {
         // torque_input = torque_grav_R_ + torque_task_R_ ; wrench (contact frame) fvr = A_rot (J̄_R[:,6:] tau_in - P_CR)
@@ -880,6 +925,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         double *s1 = L + S::t_s1;
         for (int i = th.tid; i < cd; i += NT) {
             double acc = -PCR[i];
+            _Pragma("unroll 8")
             for (int c = 0; c < RM; c++) acc += JbR[i * RSX + 6 + c] * base[c];
             s1[i] = acc;
         }
@@ -946,6 +992,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             DWBC_SYNC();
             for (int i = th.tid; i < RM; i += NT) {
                 double acc = 0.0;
+                _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) acc += NwR[i * k + j] * cv[j];
                 L[S::tcR + i] = acc;  // torque_contact_R_ = NwJw_R qpres (dwbc.cpp:4923)
             }
@@ -955,11 +1002,13 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         DWBC_SYNC();
     }
 
+    DWBC_STAMP(10);  // redistribution QP
     // ================= outputs: torque_grav_ (dwbc.cpp:3147-3148), torque_task_ (:3442-3443), torque_contact_ (:3765-3766)
     {
         double *z6 = L + S::v6 + 18;
         for (int r = th.tid; r < 6; r += NT) {
             double acc = 0.0;
+            _Pragma("unroll 8")
             for (int i = 0; i < ncd; i++) acc += JIiT[r * NCX + i] * tNC[i];
             z6[r] = acc;
         }

@@ -71,6 +71,7 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
 int emu_diag_count() { return DG_COUNT; }
 int emu_lds_bytes() { return Lds<39, 34>::total_bytes; }
 
+int emu_lds_bytes_reduced(int nlv) { return nlv == 1 ? LdsR<39, 34, 1>::total_bytes : nlv == 2 ? LdsR<39, 34, 2>::total_bytes : nlv == 3 ? LdsR<39, 34, 3>::total_bytes : LdsR<39, 34, 4>::total_bytes; }
 int emu_lds_bytes_v2(int nlv) { return nlv == 1 ? Lds2<39, 34, 1>::total_bytes : nlv == 2 ? Lds2<39, 34, 2>::total_bytes : nlv == 3 ? Lds2<39, 34, 3>::total_bytes : Lds2<39, 34, 4>::total_bytes; }
 
 int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau,
