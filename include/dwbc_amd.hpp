@@ -55,6 +55,10 @@ struct TaskSpaceView {  // the fields of DWBC::TaskSpace callers read (include/d
     Mat J_task_, Lambda_task_, J_kt_;
     int qp_error = 0;
 };
+struct LinkView {  // the kinematic fields of DWBC::Link callers read (include/dwbc_link.h; src/link.cpp:76-96)
+    Vec3 xpos, v, w;
+    Mat rotm;
+};
 struct ContactView {  // include/dwbc_contact_constraint.h:27-80
     int link_number_ = -1;
     bool contact = false;
@@ -67,7 +71,8 @@ class RobotData {
     bool is_floating_ = true;
     double total_mass_ = 0.0;
     Vec q_system_, q_dot_system_, q_ddot_system_;
-    Vec G_, torque_grav_, torque_task_, torque_contact_, torque_limit_;
+    Vec G_, B_, torque_grav_, torque_task_, torque_contact_, torque_limit_;  // B_ = C qdot + g (dwbc.cpp:343-344)
+    std::vector<LinkView> link_;  // link_[i].xpos / rotm / v / w (src/link.cpp:78-88)
     Mat A_, A_inv_, J_C, Lambda_contact, J_C_INV_T, N_C, A_inv_N_C, W, W_inv, NwJw;
     Mat CMM_, J_com_, com_inertia_;  // include/dwbc.h:114, link_.back().jac_com_, link_.back().inertia
     Vec3 com_pos;                    // include/dwbc.h:141
@@ -185,6 +190,30 @@ class RobotData {
         redistributed_ = true;
         return diag_[2];
     }
+    // ---- reduced (centroidal) dynamics model: the Reduced* call sequence (dwbc.h:411-416,
+    //      tests/sp_test/redu_dyn_test.cpp:263-298).  One fused launch serves the whole sequence, like the full model.
+    void ReducedDynamicsCalculate(bool = false) { if (!reduced_) dirty_ = true; reduced_ = true; }
+    int ReducedCalcContactConstraint() { reduced_on(); return refresh() ? diag_[0] : 0; }
+    void ReducedCalcGravCompensation() { reduced_on(); refresh(); }
+    void ReducedCalcTaskSpace(bool = true) { reduced_on(); }
+    int ReducedCalcTaskControlTorque(bool hqp = true, bool init = true, bool = true) {
+        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        reduced_on();
+        if (!refresh(init)) return 0;
+        torque_contact_.assign(model_dof_, 0.0);  // the reduced cascade does not touch torque_contact_ (dwbc.cpp:3255-3446)
+        return diag_[1];
+    }
+    int ReducedCalcContactRedistribute(bool hqp = true, bool init = true) {
+        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        reduced_on();
+        if (!refresh(init)) return 0;
+        if (contact_dof_ <= 6) return 0;  // dwbc.cpp:3760-3769: nothing happens in single support
+        torque_contact_ = tau_contact_final_;
+        return diag_[2];
+    }
+    // back to the full model for the next CalcContactConstraint / CalcTaskControlTorque
+    void UseFullDynamics() { if (reduced_) dirty_ = true; reduced_ = false; }
+
     int CalcAll(bool init = true) { int ok = refresh(init); torque_contact_ = tau_contact_final_; return ok && diag_[0] && diag_[1] && diag_[2]; }
     Vec getContactForce(const Vec &command_torque) {  // wbd.cpp:268-271: J_C_INV_T[:,6:] tau - P_C
         Vec f(contact_dof_, 0.0);
@@ -200,7 +229,8 @@ class RobotData {
     dwbc_model *model_ = nullptr;
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
-    bool dirty_ = true, redistributed_ = false;
+    bool dirty_ = true, redistributed_ = false, reduced_ = false;
+    void reduced_on() { if (!reduced_) { reduced_ = true; dirty_ = true; } }
     int diag_[96] = {0};
     Vec tau_contact_final_;
 
@@ -221,7 +251,7 @@ class RobotData {
     int refresh(bool init = true) {
         if (!batch_) return 0;
         if (!dirty_) return 1;
-        if (!dwbc_batch_solve(batch_, DWBC_SOLVE_HQP | (init ? DWBC_SOLVE_INIT : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        if (!dwbc_batch_solve(batch_, DWBC_SOLVE_HQP | (init ? DWBC_SOLVE_INIT : 0) | (reduced_ ? DWBC_SOLVE_REDUCED : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         const int n = system_dof_, m = model_dof_, cd = contact_dof_, k = cd > 6 ? cd - 6 : 0;
         std::vector<double> tau(3 * m);
         dwbc_batch_get(batch_, DWBC_TAU, tau.data(), tau.size() * 8);
@@ -232,11 +262,23 @@ class RobotData {
         A_ = fetch(DWBC_A, n, n); A_inv_ = fetch(DWBC_A_INV, n, n); A_inv_N_C = fetch(DWBC_A_INV_N_C, n, n);
         J_C = fetch(DWBC_J_C, cd, n); J_C_INV_T = fetch(DWBC_J_C_INV_T, cd, n);
         Lambda_contact = fetch(DWBC_LAMBDA_C, cd, cd, cd);
-        W_inv = fetch(DWBC_W_INV, m, m); NwJw = fetch(DWBC_NWJW, m, k, k > 0 ? k : 1);
+        if (!reduced_) { W_inv = fetch(DWBC_W_INV, m, m); NwJw = fetch(DWBC_NWJW, m, k, k > 0 ? k : 1); }
         Mat g = fetch(DWBC_G, 1, n), pc = fetch(DWBC_P_C, 1, cd, 12);
         G_ = g.d; P_C = pc.d;
         CMM_ = fetch(DWBC_CMM, 6, n); J_com_ = fetch(DWBC_J_COM, 6, n); com_inertia_ = fetch(DWBC_COM_INERTIA, 3, 3);
         { Mat cp = fetch(DWBC_COM, 1, 3); com_pos = Vec3(cp.d[0], cp.d[1], cp.d[2]); }
+        {
+            Mat bb = fetch(DWBC_B, 1, n), lr = fetch(DWBC_LINK_R, 48, 9), lp = fetch(DWBC_LINK_P, 48, 3), lv = fetch(DWBC_LINK_V, 48, 3), lw = fetch(DWBC_LINK_W, 48, 3);
+            B_ = bb.d;
+            link_.resize(link_num_);
+            for (unsigned i = 0; i < link_num_; i++) {
+                link_[i].xpos = Vec3(lp(i, 0), lp(i, 1), lp(i, 2));
+                link_[i].v = Vec3(lv(i, 0), lv(i, 1), lv(i, 2));
+                link_[i].w = Vec3(lw(i, 0), lw(i, 1), lw(i, 2));
+                link_[i].rotm = Mat(3, 3);
+                for (int a = 0; a < 9; a++) link_[i].rotm.d[a] = lr(i, a);
+            }
+        }
         W = Mat(m, m);
         for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) W(i, j) = A_inv_N_C(6 + i, 6 + j);
         N_C = Mat(n, n);  // N_C = I - J_C^T J_C_INV_T (wbd.cpp:117)
@@ -245,6 +287,7 @@ class RobotData {
             for (int c = 0; c < cd; c++) s -= J_C(c, i) * J_C_INV_T(c, j);
             N_C(i, j) = s;
         }
+        if (reduced_) { dirty_ = false; return 1; }  // W_inv, NwJw, ts_[i].J_kt_ ... are full-model fields
         Mat fq = fetch(DWBC_FSTAR_QP, 4, 6), cq = fetch(DWBC_CONTACT_QP, 4, 6), cr = fetch(DWBC_CF_REDIS, 1, 6);
         cf_redis_qp_.assign(cr.d.begin(), cr.d.begin() + k);
         std::vector<double> jt(dwbc_batch_field_bytes(batch_, DWBC_J_TASK) / 8), lt(dwbc_batch_field_bytes(batch_, DWBC_LAMBDA_TASK) / 8), jk(dwbc_batch_field_bytes(batch_, DWBC_J_KT) / 8);

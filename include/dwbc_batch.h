@@ -75,7 +75,11 @@ enum dwbc_field {
     DWBC_CMM = 50,        /* (6, n)   CMM_                      (src/dwbc.cpp:336) */
     DWBC_COM = 51,        /* (3)      com_pos                   (src/dwbc.cpp:322) */
     DWBC_COM_INERTIA = 52,/* (3, 3)   link_.back().inertia      (src/dwbc.cpp:343) */
-    DWBC_J_COM = 53       /* (6, n)   link_.back().jac_com_     (src/dwbc.cpp:352) */
+    DWBC_J_COM = 53,      /* (6, n)   link_.back().jac_com_     (src/dwbc.cpp:352) */
+    /* velocity-dependent outputs of UpdateKinematics: need a qdot in dwbc_batch_set_state */
+    DWBC_B = 54,          /* (n)      B_ = C qdot + g (RNEA)    (src/dwbc.cpp:343-344) */
+    DWBC_LINK_V = 55,     /* (48, 3)  link_[i].v                (src/link.cpp:87) */
+    DWBC_LINK_W = 56      /* (48, 3)  link_[i].w                (src/link.cpp:88) */
 };
 
 const char *dwbc_last_error(void);
@@ -113,7 +117,8 @@ int dwbc_batch_set_torque_limit(dwbc_batch *b, const double *tau_lim);      /* S
 int dwbc_batch_fstar_size(const dwbc_batch *b);
 int dwbc_batch_task_dof(const dwbc_batch *b, int level);
 
-/* UpdateKinematics(q, qdot, qddot) include/dwbc.h:251 : q is B x (ndof+1); qdot/qddot may be NULL (unused by the torque path) */
+/* UpdateKinematics(q, qdot, qddot) include/dwbc.h:251 : q is B x (ndof+1); qdot (B x ndof) may be NULL: only B_, the link
+ * velocities and the on-device task reference read it; qddot is accepted for signature parity and unused */
 int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot);
 /* SetContact(bool...) include/dwbc.h:291 : flags is B x n_contacts */
 int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags);

@@ -125,6 +125,9 @@ struct dwbc_batch {
     const KernelEntry *kern = nullptr;
     hipStream_t stream = nullptr;
     // device buffers (owned unless bound)
+    double *d_qdot = nullptr;  // B x n, allocated when the caller passes a qdot
+    std::vector<double> h_qdot;
+    bool dirty_qdot = false;
     double *d_q = nullptr, *d_fstar = nullptr, *d_tau = nullptr, *d_wrench = nullptr, *d_dump = nullptr, *d_body = nullptr;
     unsigned char *d_flags = nullptr;
     int *d_status = nullptr, *d_diag = nullptr, *d_topo = nullptr;
@@ -260,6 +263,7 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     if (!b) return;
     hipSetDevice(b->device);
     if (b->own_q) hipFree(b->d_q);
+    if (b->d_qdot) hipFree(b->d_qdot);
     if (b->own_fstar) hipFree(b->d_fstar);
     if (b->own_flags) hipFree(b->d_flags);
     if (b->own_tau) hipFree(b->d_tau);
@@ -316,11 +320,15 @@ int dwbc_batch_fstar_size(const dwbc_batch *b) { return b->su.fstar_total; }
 int dwbc_batch_task_dof(const dwbc_batch *b, int level) { return (level >= 0 && level < b->su.n_levels) ? b->su.t_dof[level] : 0; }
 
 int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot) {
-    (void)qdot; (void)qddot;  // B_ (RNEA) is not on the OSF torque path
+    (void)qddot;  // the reference hands it to RBDL's UpdateKinematicsCustom only; nothing on this path reads accelerations
     if (!q) return fail("q is NULL");
     if (!b->own_q) return fail("q is bound to a device buffer");
     memcpy(b->h_q.data(), q, b->h_q.size() * sizeof(double));
     b->dirty_q = true;
+    if (qdot) {  // B_, link velocities (dump record) and the on-device task reference need it; the torque path does not
+        b->h_qdot.assign(qdot, qdot + (size_t)b->B * b->n);
+        b->dirty_qdot = true;
+    }
     return 1;
 }
 
@@ -379,6 +387,11 @@ static int upload_inputs(dwbc_batch *b) {
         b->fstar_alloc = b->su.fstar_total;
         b->dirty_fstar = true;
     }
+    if (b->dirty_qdot) {
+        if (!b->d_qdot) HIP_OK(hipMalloc(&b->d_qdot, (size_t)b->B * b->n * sizeof(double)));
+        HIP_OK(hipMemcpyAsync(b->d_qdot, b->h_qdot.data(), b->h_qdot.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        b->dirty_qdot = false;
+    }
     if (b->dirty_q && b->own_q) HIP_OK(hipMemcpyAsync(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     if (b->dirty_flags && b->own_flags) HIP_OK(hipMemcpyAsync(b->d_flags, b->h_flags.data(), b->h_flags.size(), hipMemcpyHostToDevice, b->stream));
     if (b->dirty_fstar && b->own_fstar) HIP_OK(hipMemcpyAsync(b->d_fstar, b->h_fstar.data(), b->h_fstar.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -413,6 +426,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     BatchIO io{};
     io.B = b->B;
     io.q = b->d_q;
+    io.qdot = b->d_qdot;
     io.flags = b->d_flags;
     io.fstar = b->d_fstar;
     io.tau = b->d_tau;
@@ -504,6 +518,8 @@ size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
         case DWBC_CMM: case DWBC_J_COM: return B * 6 * n * 8;
         case DWBC_COM: return B * 3 * 8;
         case DWBC_COM_INERTIA: return B * 9 * 8;
+        case DWBC_B: return B * n * 8;
+        case DWBC_LINK_V: case DWBC_LINK_W: return B * kMaxBodies * 3 * 8;
         default: return 0;
     }
 }
@@ -558,6 +574,9 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
         case DWBC_J_COM: off = dl.J_com; len = 6 * n; break;
         case DWBC_COM: off = dl.com; len = 3; break;
         case DWBC_COM_INERTIA: off = dl.com_inertia; len = 9; break;
+        case DWBC_B: off = dl.B; len = n; break;
+        case DWBC_LINK_V: off = dl.link_v; len = kMaxBodies * 3; break;
+        case DWBC_LINK_W: off = dl.link_w; len = kMaxBodies * 3; break;
         case DWBC_P_C: off = dl.P_C; len = 12; break;
         case DWBC_LINK_R: off = dl.link_R; len = kMaxBodies * 9; break;
         case DWBC_LINK_P: off = dl.link_p; len = kMaxBodies * 3; break;

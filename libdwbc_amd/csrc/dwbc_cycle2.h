@@ -10,6 +10,7 @@
 // Reference functions restated: see the table at the top of dwbc_cycle.h.
 #pragma once
 #include "dwbc_cycle.h"
+#include "dwbc_velocity.h"
 
 namespace dwbc {
 

@@ -67,7 +67,7 @@ enum DiagField {
 struct DumpLayout {
     int N, M;
     int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
-    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, stamps, total;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, B, link_v, link_w, stamps, total;
     __host__ __device__ static DumpLayout make(int n) {
         DumpLayout d;
         d.N = n;
@@ -100,6 +100,9 @@ struct DumpLayout {
         d.com = o; o += 3;              // com_pos (dwbc.cpp:322)
         d.com_inertia = o; o += 9;      // link_.back().inertia (dwbc.cpp:343)
         d.J_com = o; o += 6 * n;        // link_.back().jac_com_ (dwbc.cpp:352)
+        d.B = o; o += n;                // B_ (dwbc.cpp:343-344), needs qdot
+        d.link_v = o; o += kMaxBodies * 3;  // link_[i].v (link.cpp:87), needs qdot
+        d.link_w = o; o += kMaxBodies * 3;  // link_[i].w (link.cpp:88)
         d.stamps = o; o += 64;  // fine-grained stage stamps (diagnostic build only)
         d.total = o;
         return d;
@@ -109,6 +112,7 @@ struct DumpLayout {
 struct BatchIO {
     int B;
     const double *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
+    const double *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
     const unsigned char *flags;  // B x n_contacts
     const double *fstar;         // B x fstar_total
     double *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_

@@ -601,3 +601,60 @@ class Cycle:
         ok_c = self.calc_contact_redistribute()
         self.status = int(ok and ok_t and ok_c)
         return self.tau_grav + self.tau_task + self.tau_contact
+
+
+# ----------------------------------------------------------------------------------------------
+# velocity-dependent outputs of UpdateKinematics (reference src/dwbc.cpp:340-344,362-367, src/link.cpp:76-96)
+# ----------------------------------------------------------------------------------------------
+def nonlinear_effects(model, q, qd, gravity=GRAV):
+    """B_ = C(q, qd) qd + g(q): recursive Newton-Euler with zero joint acceleration in body coordinates
+    ([ext] RBDL NonlinearEffects; spatial vectors [ang; lin]).  DoF conventions as crba()."""
+    nb, n = model["nb"], model["ndof"]
+    par = model["parent"]
+    Rb = quat_to_R(q[3], q[4], q[5], q[n])
+
+    def crm(v):  # spatial motion cross product matrix
+        out = np.zeros((6, 6))
+        out[:3, :3] = skew(v[:3])
+        out[3:, :3] = skew(v[3:])
+        out[3:, 3:] = skew(v[:3])
+        return out
+
+    I = [_spatial_inertia(model["mass"][i], model["com"][i], model["inertia"][i]) for i in range(nb)]
+    Xl, S, v, a, f = [None] * nb, [None] * nb, [None] * nb, [None] * nb, [None] * nb
+    # base: world-axis translation then body-frame spherical joint.  In body-0 coordinates the velocity is
+    # [omega_b ; R^T v_world]; the spatial acceleration with zero generalised acceleration is [0 ; -omega_b x (R^T v)]
+    # plus the fictitious upward acceleration that stands for gravity.
+    wb = np.asarray(qd[3:6], float)
+    vb = Rb.T @ np.asarray(qd[0:3], float)
+    v[0] = np.concatenate([wb, vb])
+    a[0] = np.concatenate([np.zeros(3), -np.cross(wb, vb) + Rb.T @ np.array([0, 0, gravity])])
+    for i in range(1, nb):
+        Rj = axis_angle_R(model["axis"][i], q[6 + i - 1])
+        Xl[i] = _X((model["R_T"][i] @ Rj).T, model["p_T"][i])
+        S[i] = np.concatenate([model["axis"][i], np.zeros(3)])
+        vj = S[i] * qd[6 + i - 1]
+        v[i] = Xl[i] @ v[par[i]] + vj
+        a[i] = Xl[i] @ a[par[i]] + crm(v[i]) @ vj
+    for i in range(nb):
+        f[i] = I[i] @ a[i] - crm(v[i]).T @ (I[i] @ v[i])
+    tau = np.zeros(n)
+    for i in range(nb - 1, 0, -1):
+        tau[6 + i - 1] = S[i] @ f[i]
+        f[par[i]] = f[par[i]] + Xl[i].T @ f[i]
+    tau[0:3] = Rb @ f[0][3:]  # world-axis translation dofs
+    tau[3:6] = f[0][:3]       # body-frame spherical dofs
+    return tau
+
+
+def link_velocities(model, R, p, qd):
+    """link_[i].v / .w / .vi (reference src/link.cpp:85-95): 6-D velocity of each link origin and the linear
+    velocity of its centre of mass, world frame, from the point Jacobians."""
+    nb = model["nb"]
+    v, w, vi = np.zeros((nb, 3)), np.zeros((nb, 3)), np.zeros((nb, 3))
+    for i in range(nb):
+        J = point_jacobian(model, R, p, i, np.zeros(3))
+        v[i] = J[:3] @ qd
+        w[i] = J[3:] @ qd
+        vi[i] = v[i] + np.cross(w[i], R[i] @ model["com"][i])
+    return v, w, vi

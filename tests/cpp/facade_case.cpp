@@ -3,6 +3,7 @@
 // CalcContactRedistribute) and a few matrices' checksums as JSON for tests/test_facade_cpp.py.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "dwbc_amd.hpp"
 
@@ -37,7 +38,8 @@ int main(int argc, char **argv) {
     rd_.AddContactConstraint(31, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.04, 0.04);
     rd_.AddTaskSpace(0, TASK_LINK_6D, 0, Vec3());
     rd_.AddTaskSpace(1, TASK_LINK_ROTATION, "upperbody_link", Vec3());
-    rd_.SetTorqueLimit(Vec(rd_.model_dof_, 300.0));
+    const bool with_reduced = argc > 3 && std::string(argv[3]) == "reduced";
+    if (!with_reduced) rd_.SetTorqueLimit(Vec(rd_.model_dof_, 300.0));  // the reduced sequence runs without it (redu_dyn_test.cpp:63)
     rd_.UpdateKinematics(q, qdot, qddot);
     rd_.SetContact(true, true);
     int ok_c = rd_.CalcContactConstraint();
@@ -61,6 +63,20 @@ int main(int argc, char **argv) {
     print_vec("N_C", rd_.N_C.d);
     print_vec("W", rd_.W.d);
     print_vec("NwJw", rd_.NwJw.d);
+    if (with_reduced) {
+        // reference tests/sp_test/redu_dyn_test.cpp:263-298 on the same state
+        rd_.SetContact(true, true);
+        rd_.ReducedDynamicsCalculate();
+        int rk_c = rd_.ReducedCalcContactConstraint();
+        rd_.ReducedCalcGravCompensation();
+        rd_.ReducedCalcTaskSpace();
+        int rk_t = rd_.ReducedCalcTaskControlTorque(true, true, false);
+        int rk_r = rd_.ReducedCalcContactRedistribute(true, true);
+        printf("\"reduced_ok\": [%d, %d, %d],\n", rk_c, rk_t, rk_r);
+        print_vec("reduced_torque_grav_", rd_.torque_grav_);
+        print_vec("reduced_torque_task_", rd_.torque_task_);
+        print_vec("reduced_torque_contact_", rd_.torque_contact_);
+    }
     print_vec("contact_qp_last", rd_.ts_.back().contact_qp_, true);
     printf("}\n");
     return 0;

@@ -64,7 +64,7 @@ class Emu:
         self.L.emu_get_model(self.h, *[out[k].ctypes.data for k in ("parent", "R_T", "p_T", "axis", "mass", "com", "inertia")])
         return out
 
-    def run(self, q, flags, fstar, dump=False, reduced=False):
+    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -75,6 +75,8 @@ class Emu:
         st = np.zeros(B, np.int32)
         diag = np.zeros((B, 90), np.int32)
         dmp = np.zeros((B, self.D)) if dump else None
+        qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
+        self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))
         ok = (self.L.emu_run_reduced if reduced else self.L.emu_run)(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
                             st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)
         assert ok == 1, self.L.emu_error(self.h)

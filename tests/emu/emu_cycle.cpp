@@ -64,7 +64,7 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
     std::string n(name);
 #define F(x) if (n == #x) return d.x;
     F(A) F(A_inv) F(J_C) F(Lambda_c) F(J_C_INV_T) F(A_inv_N_C) F(W_inv) F(NwJw) F(Vb) F(G) F(P_C) F(link_R) F(link_p)
-    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com)
+    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com) F(B) F(link_v) F(link_w)
 #undef F
     return -1;
 }
@@ -92,12 +92,16 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     return 1;
 }
 
+static const double *g_emu_qdot = nullptr;
+void emu_set_qdot(const double *qd) { g_emu_qdot = qd; }
+
 int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
             int *status, int *diag, double *dump) {
     if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
     BatchIO io{};
     io.B = B;
     io.q = q;
+    io.qdot = g_emu_qdot;
     io.flags = flags;
     io.fstar = fstar;
     io.tau = tau;

@@ -46,3 +46,18 @@ def test_facade_reproduces_reference_cases(case):
     # before redistribution torque_contact_ = NwJw * contact_qp_(last level) (reference src/dwbc.cpp:851); the
     # redistribution adds the min-norm increment, zero here because the point is already feasible
     assert e(r["torque_contact_before_redis"], r["torque_contact_"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_facade_reduced_sequence():
+    """The Reduced* call sequence of the reference (tests/sp_test/redu_dyn_test.cpp:263-298) through the facade: gravity and
+    task torques equal the full model's on the same state (the reference's own side-by-side check, :304-317)."""
+    _build()
+    out = subprocess.check_output([EXE, cases.URDF, "1", "reduced"], text=True)
+    r = json.loads(out[out.index("{"):])
+    e = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b).reshape(-1)).max())
+    assert r["ok"] == [1, 1, 1] and r["reduced_ok"] == [1, 1, 1]
+    assert e(r["reduced_torque_grav_"], r["torque_grav_"]) < 1e-8
+    assert e(r["reduced_torque_task_"], r["torque_task_"]) < 1e-6
+    assert e(r["reduced_torque_grav_"], cases.golden(1, "torque_grav_")) < 1e-6
+    assert np.abs(np.asarray(r["reduced_torque_contact_"])[12:]).max() == 0.0  # only the contact-chain joints (dwbc.cpp:3766)
