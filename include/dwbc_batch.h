@@ -113,6 +113,17 @@ int dwbc_batch_clear_contacts(dwbc_batch *b);                               /* C
 /* AddTaskSpace(level, mode, link, point) include/dwbc.h:319 (same level twice appends a link, src/dwbc.cpp:592-600) */
 int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const double point[3]);
 int dwbc_batch_clear_tasks(dwbc_batch *b);                                  /* ClearTaskSpace */
+/* ---- on-device task reference (reference src/task.cpp:223-339, src/dwbc.cpp:708-780): a task link with a trajectory gets its
+ * f* segment from the quintic / slerp trajectory + PD law on the device; link_index = position of the link inside its level.
+ * TaskLink::SetTaskGain(pos_p, pos_d, pos_a, rot_p, rot_d, rot_a)  include/dwbc_task.h:108 (shared by the batch) */
+int dwbc_batch_set_task_gain(dwbc_batch *b, int level, int link_index, const double pos_p[3], const double pos_d[3],
+                             const double pos_a[3], const double rot_p[3], const double rot_d[3], const double rot_a[3]);
+/* TaskLink::SetTrajectoryQuintic + SetTrajectoryRotation  include/dwbc_task.h:104-106 : traj is B x 34 doubles per instance
+ *   t_start t_end | pos_init[3] vel_init[3] pos_desired[3] vel_desired[3] | rot_init[9] rot_desired[9] (row-major) |
+ *   has_pos has_rot (traj_pos_set / traj_rot_set);  NULL = back to the SetTaskSpace values for this link */
+int dwbc_batch_set_trajectory(dwbc_batch *b, int level, int link_index, const double *traj);
+/* RobotData::control_time_ (include/dwbc.h:86), one value per instance */
+int dwbc_batch_set_control_time(dwbc_batch *b, const double *control_time);
 int dwbc_batch_set_torque_limit(dwbc_batch *b, const double *tau_lim);      /* SetTorqueLimit include/dwbc.h:249; NULL = unset */
 int dwbc_batch_fstar_size(const dwbc_batch *b);
 int dwbc_batch_task_dof(const dwbc_batch *b, int level);

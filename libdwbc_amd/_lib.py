@@ -31,6 +31,9 @@ SYMBOLS = [
     ("dwbc_batch_clear_contacts", _i, [_vp]),
     ("dwbc_batch_add_task", _i, [_vp, _i, _i, _i, _vp]),
     ("dwbc_batch_clear_tasks", _i, [_vp]),
+    ("dwbc_batch_set_task_gain", _i, [_vp, _i, _i] + [_vp] * 6),
+    ("dwbc_batch_set_trajectory", _i, [_vp, _i, _i, _vp]),
+    ("dwbc_batch_set_control_time", _i, [_vp, _vp]),
     ("dwbc_batch_set_torque_limit", _i, [_vp, _vp]),
     ("dwbc_batch_fstar_size", _i, [_vp]),
     ("dwbc_batch_task_dof", _i, [_vp, _i]),

@@ -144,6 +144,24 @@ class Batch:
             assert qd.shape == (self.B, self.n), qd.shape
         _check(self._L.dwbc_batch_set_state(self._h, q.ctypes.data, qd.ctypes.data if qd is not None else None, None))
 
+    def set_task_gain(self, level, link_index, pos_p, pos_d, pos_a, rot_p, rot_d, rot_a=(0, 0, 0)):
+        """TaskLink::SetTaskGain (reference include/dwbc_task.h:108)"""
+        arrs = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (3,))) for a in (pos_p, pos_d, pos_a, rot_p, rot_d, rot_a)]
+        _check(self._L.dwbc_batch_set_task_gain(self._h, int(level), int(link_index), *[a.ctypes.data for a in arrs]))
+
+    def set_trajectory(self, level, link_index, traj):
+        """per-instance trajectory records (B, 34): SetTrajectoryQuintic + SetTrajectoryRotation; None clears"""
+        if traj is None:
+            _check(self._L.dwbc_batch_set_trajectory(self._h, int(level), int(link_index), None))
+            return
+        t = np.ascontiguousarray(traj, np.float64)
+        assert t.shape == (self.B, 34), t.shape
+        _check(self._L.dwbc_batch_set_trajectory(self._h, int(level), int(link_index), t.ctypes.data))
+
+    def set_control_time(self, t):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, np.float64), (self.B,)))
+        _check(self._L.dwbc_batch_set_control_time(self._h, t.ctypes.data))
+
     def set_contact(self, flags):
         f = np.ascontiguousarray(flags, np.uint8)
         assert f.shape == (self.B, self.n_contacts), f.shape

@@ -126,6 +126,9 @@ struct dwbc_batch {
     hipStream_t stream = nullptr;
     // device buffers (owned unless bound)
     double *d_qdot = nullptr;  // B x n, allocated when the caller passes a qdot
+    double *d_traj = nullptr, *d_ctime = nullptr;  // on-device task reference inputs (dwbc_fstar.h)
+    std::vector<double> h_traj, h_ctime;
+    bool dirty_traj = false, dirty_ctime = false;
     std::vector<double> h_qdot;
     bool dirty_qdot = false;
     double *d_q = nullptr, *d_fstar = nullptr, *d_tau = nullptr, *d_wrench = nullptr, *d_dump = nullptr, *d_body = nullptr;
@@ -264,6 +267,8 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     hipSetDevice(b->device);
     if (b->own_q) hipFree(b->d_q);
     if (b->d_qdot) hipFree(b->d_qdot);
+    if (b->d_traj) hipFree(b->d_traj);
+    if (b->d_ctime) hipFree(b->d_ctime);
     if (b->own_fstar) hipFree(b->d_fstar);
     if (b->own_flags) hipFree(b->d_flags);
     if (b->own_tau) hipFree(b->d_tau);
@@ -306,6 +311,53 @@ int dwbc_batch_clear_tasks(dwbc_batch *b) {
     b->su.n_levels = 0;
     setup_fstar_layout(b->su);
     b->h_fstar.clear();
+    b->su.n_traj = 0;
+    for (int l = 0; l < kMaxLevels; l++)
+        for (int j = 0; j < kMaxTaskLinks; j++) b->su.t_traj_slot[l][j] = -1;
+    b->h_traj.clear();
+    return 1;
+}
+
+int dwbc_batch_set_task_gain(dwbc_batch *b, int level, int link_index, const double *pos_p, const double *pos_d, const double *pos_a,
+                             const double *rot_p, const double *rot_d, const double *rot_a) {
+    if (level < 0 || level >= b->su.n_levels || link_index < 0 || link_index >= b->su.t_nlinks[level]) return fail("bad task level / link index");
+    (void)rot_a;  // stored by the reference, never read by GetFstarRotPD (src/task.cpp:338)
+    double *g = b->su.t_gain[level][link_index];
+    for (int a = 0; a < 3; a++) { g[a] = pos_p[a]; g[3 + a] = pos_d[a]; g[6 + a] = pos_a[a]; g[9 + a] = rot_p[a]; g[12 + a] = rot_d[a]; }
+    return 1;
+}
+
+int dwbc_batch_set_trajectory(dwbc_batch *b, int level, int link_index, const double *traj) {
+    if (level < 0 || level >= b->su.n_levels || link_index < 0 || link_index >= b->su.t_nlinks[level]) return fail("bad task level / link index");
+    int &slot = b->su.t_traj_slot[level][link_index];
+    if (!traj) {  // back to SetTaskSpace values for this link (slots of other links keep their place)
+        slot = -1;
+        return 1;
+    }
+    if (slot < 0) {
+        if (b->su.n_traj >= kMaxLevels * kMaxTaskLinks) return fail("too many trajectories");
+        // records are instance-major: re-stride the host copy for the new slot count
+        const int old = b->su.n_traj, now = old + 1;
+        std::vector<double> h((size_t)b->B * now * kTrajStride, 0.0);
+        for (int i = 0; i < b->B; i++)
+            for (int sidx = 0; sidx < old; sidx++)
+                memcpy(&h[((size_t)i * now + sidx) * kTrajStride], &b->h_traj[((size_t)i * old + sidx) * kTrajStride], kTrajStride * sizeof(double));
+        b->h_traj.swap(h);
+        slot = old;
+        b->su.n_traj = now;
+        if (b->d_traj) { hipFree(b->d_traj); b->d_traj = nullptr; }
+    }
+    const int ns = b->su.n_traj;
+    for (int i = 0; i < b->B; i++)
+        memcpy(&b->h_traj[((size_t)i * ns + slot) * kTrajStride], traj + (size_t)i * kTrajStride, kTrajStride * sizeof(double));
+    b->dirty_traj = true;
+    return 1;
+}
+
+int dwbc_batch_set_control_time(dwbc_batch *b, const double *t) {
+    if (!t) return fail("control time is NULL");
+    b->h_ctime.assign(t, t + b->B);
+    b->dirty_ctime = true;
     return 1;
 }
 
@@ -387,6 +439,16 @@ static int upload_inputs(dwbc_batch *b) {
         b->fstar_alloc = b->su.fstar_total;
         b->dirty_fstar = true;
     }
+    if (b->dirty_traj && b->su.n_traj > 0) {
+        if (!b->d_traj) HIP_OK(hipMalloc(&b->d_traj, b->h_traj.size() * sizeof(double)));
+        HIP_OK(hipMemcpyAsync(b->d_traj, b->h_traj.data(), b->h_traj.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        b->dirty_traj = false;
+    }
+    if (b->dirty_ctime) {
+        if (!b->d_ctime) HIP_OK(hipMalloc(&b->d_ctime, (size_t)b->B * sizeof(double)));
+        HIP_OK(hipMemcpyAsync(b->d_ctime, b->h_ctime.data(), b->h_ctime.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        b->dirty_ctime = false;
+    }
     if (b->dirty_qdot) {
         if (!b->d_qdot) HIP_OK(hipMalloc(&b->d_qdot, (size_t)b->B * b->n * sizeof(double)));
         HIP_OK(hipMemcpyAsync(b->d_qdot, b->h_qdot.data(), b->h_qdot.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -427,6 +489,8 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.B = b->B;
     io.q = b->d_q;
     io.qdot = b->d_qdot;
+    io.traj = b->su.n_traj > 0 ? b->d_traj : nullptr;
+    io.ctime = b->d_ctime;
     io.flags = b->d_flags;
     io.fstar = b->d_fstar;
     io.tau = b->d_tau;

@@ -11,6 +11,7 @@
 #pragma once
 #include "dwbc_cycle.h"
 #include "dwbc_velocity.h"
+#include "dwbc_fstar.h"
 
 namespace dwbc {
 
@@ -31,7 +32,8 @@ struct Lds2 {
     static constexpr int PC = tc + M;
     static constexpr int Rc = PC + C;
     static constexpr int Pc = Rc + kMaxActiveContacts * 9;
-    static constexpr int JbT = Pc + kMaxActiveContacts * 3;   // C x N            (written from stage 1 on)
+    static constexpr int fs = Pc + kMaxActiveContacts * 3;    // f* of every level (SetTaskSpace values or the on-device task reference)
+    static constexpr int JbT = fs + kMaxLevels * kMaxTaskDof;  // C x N            (written from stage 1 on)
     static constexpr int NwJw = JbT + C * N;                   // M x K
     static constexpr int FNl = NwJw + M * K;                   // C x K
     static constexpr int U = FNl + C * K;                      // levels x (M x T)
@@ -591,7 +593,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
     int st_task = 1, fail_level = -1, st_redis = 1;
-    const double *fs_in = io.fstar + (size_t)inst * su.fstar_total;
+    const double *fs_in = L + S::fs;  // filled by task_reference() after stage 0
     double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;

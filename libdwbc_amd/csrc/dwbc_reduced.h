@@ -742,7 +742,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     // ================= ReducedCalcTaskControlTorque(hqp = true) (dwbc.cpp:3255-3446) =================
     const int ncone = 10 * nc;
     int st_redis = 1;
-    const double *fs_in = io.fstar + (size_t)inst * su.fstar_total;
+    const double *fs_in = L + S::fs;  // filled by task_reference() after stage 0
     double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
     double *tgR = L + S::tgR, *ttR = L + S::ttR, *sumR = L + S::sumR, *tNC = L + S::tNC, *tRqp = L + S::tRqp;
     double *fon = L + S::v6;  // force_on_nc_r_

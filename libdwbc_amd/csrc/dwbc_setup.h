@@ -15,6 +15,8 @@ inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
     su.maxdepth = maxdepth;
     su.qp_max_iter_task = 1000;    // reference src/dwbc.cpp:1080
     su.qp_max_iter_contact = 300;  // reference src/dwbc.cpp:1546
+    for (int l = 0; l < kMaxLevels; l++)
+        for (int j = 0; j < kMaxTaskLinks; j++) su.t_traj_slot[l][j] = -1;
 }
 
 // parent body of every body (Model::topo_table()[0..nb)); must be installed before contacts / tasks are added

@@ -51,6 +51,11 @@ struct Setup {
     int parent[kMaxBodies];
     unsigned long long c_dofmask[kMaxContacts];
     unsigned long long t_dofmask[kMaxLevels];
+    // on-device task reference (dwbc_fstar.h): gains of TaskLink::SetTaskGain (pos_p pos_d pos_a rot_p rot_d, 3 each) and the
+    // trajectory slot of every task link (-1: f* comes from SetTaskSpace)
+    double t_gain[kMaxLevels][kMaxTaskLinks][15];
+    int t_traj_slot[kMaxLevels][kMaxTaskLinks];
+    int n_traj;
 };
 
 // per-instance diagnostics (int32)
@@ -115,6 +120,8 @@ struct BatchIO {
     const double *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
     const unsigned char *flags;  // B x n_contacts
     const double *fstar;         // B x fstar_total
+    const double *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
+    const double *ctime;         // B control times (RobotData::control_time_) or nullptr
     double *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
     double *wrench;              // B x 12    : getContactForce(tau_total), zero padded
     int *status;                 // B         : 1 ok / 0 fail (reference int returns ANDed)

@@ -64,7 +64,11 @@ class Emu:
         self.L.emu_get_model(self.h, *[out[k].ctypes.data for k in ("parent", "R_T", "p_T", "axis", "mass", "com", "inertia")])
         return out
 
-    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None):
+    def set_traj(self, level, link_index, slot, gains15):
+        g = np.ascontiguousarray(gains15, np.float64)
+        self.L.emu_set_traj(C.c_void_p(self.h), level, link_index, slot, C.c_void_p(g.ctypes.data))
+
+    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -77,6 +81,9 @@ class Emu:
         dmp = np.zeros((B, self.D)) if dump else None
         qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
         self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))
+        tr = None if traj is None else np.ascontiguousarray(traj, np.float64)
+        ct = None if ctime is None else np.ascontiguousarray(ctime, np.float64)
+        self.L.emu_set_traj_data(C.c_void_p(tr.ctypes.data if tr is not None else None), C.c_void_p(ct.ctypes.data if ct is not None else None))
         ok = (self.L.emu_run_reduced if reduced else self.L.emu_run)(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
                             st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)
         assert ok == 1, self.L.emu_error(self.h)

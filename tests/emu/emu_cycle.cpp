@@ -92,6 +92,13 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     return 1;
 }
 
+static const double *g_emu_traj = nullptr, *g_emu_ctime = nullptr;
+void emu_set_traj(EmuCtx *c, int level, int link_index, int slot, const double *gains15) {
+    c->su.t_traj_slot[level][link_index] = slot;
+    if (slot + 1 > c->su.n_traj) c->su.n_traj = slot + 1;
+    for (int a = 0; a < 15; a++) c->su.t_gain[level][link_index][a] = gains15[a];
+}
+void emu_set_traj_data(const double *traj, const double *ctime) { g_emu_traj = traj; g_emu_ctime = ctime; }
 static const double *g_emu_qdot = nullptr;
 void emu_set_qdot(const double *qd) { g_emu_qdot = qd; }
 
@@ -102,6 +109,8 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.B = B;
     io.q = q;
     io.qdot = g_emu_qdot;
+    io.traj = c->su.n_traj > 0 ? g_emu_traj : nullptr;
+    io.ctime = g_emu_ctime;
     io.flags = flags;
     io.fstar = fstar;
     io.tau = tau;
