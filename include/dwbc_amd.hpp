@@ -49,8 +49,28 @@ enum TASK_LINK_MODE {                                                           
     TASK_LINK_POSITION_CUSTOM_FRAME, TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME
 };
 
+struct TaskLinkView {  // DWBC::TaskLink: trajectory + PD reference of one task link (include/dwbc_task.h:49-128)
+    bool traj_pos_set = false, traj_rot_set = false, dirty = false;
+    double rec[34] = {0};   // the C-ABI trajectory record (include/dwbc_batch.h, dwbc_batch_set_trajectory)
+    double gain[18] = {0};  // pos_p pos_d pos_a rot_p rot_d rot_a
+    void SetTrajectoryQuintic(double start_time, double end_time, Vec3 pos_init, Vec3 vel_init, Vec3 pos_desired, Vec3 vel_desired) {
+        rec[0] = start_time; rec[1] = end_time;
+        for (int a = 0; a < 3; a++) { rec[2 + a] = pos_init.v[a]; rec[5 + a] = vel_init.v[a]; rec[8 + a] = pos_desired.v[a]; rec[11 + a] = vel_desired.v[a]; }
+        traj_pos_set = true; rec[32] = 1.0; dirty = true;
+    }
+    void SetTrajectoryRotation(double start_time, double end_time, const Mat &rot_init, Vec3 /*twist_init*/, const Mat &rot_desired, Vec3 /*twist_desired*/) {
+        rec[0] = start_time; rec[1] = end_time;
+        for (int a = 0; a < 9; a++) { rec[14 + a] = rot_init.d[a]; rec[23 + a] = rot_desired.d[a]; }
+        traj_rot_set = true; rec[33] = 1.0; dirty = true;
+    }
+    void SetTaskGain(Vec3 pos_p, Vec3 pos_d, Vec3 pos_a, Vec3 rot_p, Vec3 rot_d, Vec3 rot_a) {
+        for (int a = 0; a < 3; a++) { gain[a] = pos_p.v[a]; gain[3 + a] = pos_d.v[a]; gain[6 + a] = pos_a.v[a]; gain[9 + a] = rot_p.v[a]; gain[12 + a] = rot_d.v[a]; gain[15 + a] = rot_a.v[a]; }
+        dirty = true;
+    }
+};
 struct TaskSpaceView {  // the fields of DWBC::TaskSpace callers read (include/dwbc_task.h:130-171)
     int task_dof_ = 0;
+    std::vector<TaskLinkView> task_link_;
     Vec f_star_, f_star_qp_, contact_qp_;
     Mat J_task_, Lambda_task_, J_kt_;
     int qp_error = 0;
@@ -70,6 +90,7 @@ class RobotData {
     unsigned int system_dof_ = 0, model_dof_ = 0, contact_dof_ = 0, contact_link_num_ = 0, link_num_ = 0;
     bool is_floating_ = true;
     double total_mass_ = 0.0;
+    double control_time_ = 0.0;  // include/dwbc.h:86: time fed to the task-link trajectories
     Vec q_system_, q_dot_system_, q_ddot_system_;
     Vec G_, B_, torque_grav_, torque_task_, torque_contact_, torque_limit_;  // B_ = C qdot + g (dwbc.cpp:343-344)
     std::vector<LinkView> link_;  // link_[i].xpos / rotm / v / w (src/link.cpp:78-88)
@@ -152,6 +173,7 @@ class RobotData {
         if (!dwbc_batch_add_task(batch_, heirarchy, task_mode, link_number, task_point.data())) { std::cout << dwbc_last_error() << std::endl; return; }
         if ((int)ts_.size() <= heirarchy) ts_.resize(heirarchy + 1);
         ts_[heirarchy].task_dof_ = dwbc_batch_task_dof(batch_, heirarchy);
+        ts_[heirarchy].task_link_.emplace_back();
         ts_[heirarchy].f_star_.assign(ts_[heirarchy].task_dof_, 0.0);
         if (verbose) std::cout << "#" << heirarchy << " Task Space Added : " << dwbc_model_link_name(model_, link_number) << std::endl;
     }
@@ -230,6 +252,7 @@ class RobotData {
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
     bool dirty_ = true, redistributed_ = false, reduced_ = false;
+    double sent_time_ = -1.0e300;
     void reduced_on() { if (!reduced_) { reduced_ = true; dirty_ = true; } }
     int diag_[96] = {0};
     Vec tau_contact_final_;
@@ -250,6 +273,16 @@ class RobotData {
     }
     int refresh(bool init = true) {
         if (!batch_) return 0;
+        for (size_t l = 0; l < ts_.size(); l++)  // task-link trajectories / gains set since the last launch
+            for (size_t j = 0; j < ts_[l].task_link_.size(); j++) {
+                TaskLinkView &tl = ts_[l].task_link_[j];
+                if (!tl.dirty) continue;
+                dwbc_batch_set_task_gain(batch_, (int)l, (int)j, tl.gain, tl.gain + 3, tl.gain + 6, tl.gain + 9, tl.gain + 12, tl.gain + 15);
+                if (tl.traj_pos_set || tl.traj_rot_set) dwbc_batch_set_trajectory(batch_, (int)l, (int)j, tl.rec);
+                tl.dirty = false;
+                dirty_ = true;
+            }
+        if (control_time_ != sent_time_) { dwbc_batch_set_control_time(batch_, &control_time_); sent_time_ = control_time_; dirty_ = true; }
         if (!dirty_) return 1;
         if (!dwbc_batch_solve(batch_, DWBC_SOLVE_HQP | (init ? DWBC_SOLVE_INIT : 0) | (reduced_ ? DWBC_SOLVE_REDUCED : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         const int n = system_dof_, m = model_dof_, cd = contact_dof_, k = cd > 6 ? cd - 6 : 0;
