@@ -194,6 +194,7 @@ int dwbc_model_system_dof(const dwbc_model *m) { return m->m.ndof; }
 double dwbc_model_total_mass(const dwbc_model *m) { return m->m.total_mass; }
 int dwbc_model_link_id(const dwbc_model *m, const char *name) { return m->m.link_id(name); }
 const char *dwbc_model_link_name(const dwbc_model *m, int link) {
+    if (link == m->m.nb) return "COM";
     return (link >= 0 && link < m->m.nb) ? m->m.names[link].c_str() : "";
 }
 int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, double *p_T, double *axis, double *mass, double *com,
@@ -309,6 +310,7 @@ int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const doub
 
 int dwbc_batch_clear_tasks(dwbc_batch *b) {
     b->su.n_levels = 0;
+    b->su.has_com_task = 0;
     setup_fstar_layout(b->su);
     b->h_fstar.clear();
     b->su.n_traj = 0;

@@ -461,6 +461,63 @@ DWBC_DEV void dump_centroidal(Thr th, const double *A, int lda, const double *R0
     }
 }
 
+// Jacobian of the synthetic "COM" link, jac_ = jac_com_ = SI_body^-1 CMM_ (reference src/dwbc.cpp:318-353), 6 x N row-major
+// [linear; angular], followed by com_pos (3).  Same arithmetic as dump_centroidal, kept in LDS for COM task levels.
+template <int N, int NT>
+DWBC_DEV void com_jacobian(Thr th, const double *A, int lda, const double *R0, const double *q0, double *Jcm) {
+    const double mt = A[0];
+    double c[3];
+    {
+        const int ra[3] = {2, 0, 1}, cb[3] = {1, 2, 0};
+        for (int e = 0; e < 3; e++) {
+            double acc = 0.0;
+            for (int b = 0; b < 3; b++) acc += R0[ra[e] * 3 + b] * A[(3 + b) * lda + cb[e]];
+            c[e] = acc / mt;
+        }
+    }
+    double I[9];
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            double acc = 0.0;
+            for (int u = 0; u < 3; u++)
+                for (int v = 0; v < 3; v++) acc += R0[a * 3 + u] * A[(3 + u) * lda + 3 + v] * R0[b * 3 + v];
+            const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+            I[a * 3 + b] = acc - mt * ((a == b ? cc : 0.0) - c[a] * c[b]);
+        }
+    const double det = I[0] * (I[4] * I[8] - I[5] * I[7]) - I[1] * (I[3] * I[8] - I[5] * I[6]) + I[2] * (I[3] * I[7] - I[4] * I[6]);
+    const double id = 1.0 / det;
+    const double Ii[9] = {(I[4] * I[8] - I[5] * I[7]) * id, (I[2] * I[7] - I[1] * I[8]) * id, (I[1] * I[5] - I[2] * I[4]) * id,
+                          (I[5] * I[6] - I[3] * I[8]) * id, (I[0] * I[8] - I[2] * I[6]) * id, (I[2] * I[3] - I[0] * I[5]) * id,
+                          (I[3] * I[7] - I[4] * I[6]) * id, (I[1] * I[6] - I[0] * I[7]) * id, (I[0] * I[4] - I[1] * I[3]) * id};
+    const double St[9] = {0.0, c[2], -c[1], -c[2], 0.0, c[0], c[1], -c[0], 0.0};
+    // read every A entry this thread needs before any store: Jcm may overlay dead rows of the staged A
+    for (int j = th.tid; j < N; j += NT) {
+        double al[3], ab[3], h[3];
+        for (int a = 0; a < 3; a++) { al[a] = A[a * lda + j]; ab[a] = A[(3 + a) * lda + j]; }
+        for (int a = 0; a < 3; a++) {
+            double acc = 0.0;
+            for (int b = 0; b < 3; b++) acc += St[a * 3 + b] * al[b] + R0[a * 3 + b] * ab[b];
+            h[a] = acc;
+        }
+        for (int a = 0; a < 3; a++) {
+            Jcm[a * N + j] = al[a] / mt;
+            Jcm[(3 + a) * N + j] = Ii[a * 3] * h[0] + Ii[a * 3 + 1] * h[1] + Ii[a * 3 + 2] * h[2];
+        }
+    }
+    if (th.tid == 0)
+        for (int a = 0; a < 3; a++) Jcm[6 * N + a] = c[a] + q0[a];
+}
+
+// rows of a COM task level into the transposed task Jacobian Jtt (N x T): rsel 0 -> 6 rows, 1 -> linear, 2 -> angular
+template <int N, int NT>
+DWBC_DEV void com_task_rows(Thr th, const double *Jcm, double *Jtt, int row0, int rsel, int T) {
+    for (int j = th.tid; j < N; j += NT) {
+        if (rsel == 0) { for (int a = 0; a < 6; a++) Jtt[j * T + row0 + a] = Jcm[a * N + j]; }
+        else if (rsel == 1) { for (int a = 0; a < 3; a++) Jtt[j * T + row0 + a] = Jcm[a * N + j]; }
+        else { for (int a = 0; a < 3; a++) Jtt[j * T + row0 + a] = Jcm[(3 + a) * N + j]; }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // QP rows into lanes + solve.  Lane r < M owns torque-limit row r (two sided), lane M + rr owns cone row rr.
 //   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)

@@ -85,7 +85,12 @@ struct Lds2 {
     static constexpr int qp_V = t_s1 + C * (T + 1);
     static constexpr int qp_x = qp_V + kQpLd * kQpLd + 32;
     static constexpr int t_end = qp_x + kQpLd;
-    static constexpr int total = max2(max2(k_end, c_end), t_end);
+    static constexpr int total0 = max2(max2(k_end, c_end), t_end);
+    // Jacobian of the COM link + com_pos (6 N + 3), for COM task levels: written at the end of stage 0 and read while the task
+    // Jacobians are built, i.e. before stage 3a first writes U -- so it borrows the U block when that is large enough
+    static constexpr bool jcm_in_U = NLV * M * T >= 6 * N + 4;
+    static constexpr int Jcm = jcm_in_U ? U : ev(total0);
+    static constexpr int total = jcm_in_U ? total0 : ev(total0) + 6 * N + 4;
     static constexpr int total_bytes = total * 8 + 64;
 };
 
@@ -372,15 +377,19 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
             double pl[3] = {0, 0, 0};
-            if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
+            if ((mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME) && link < nb)
                 for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
             else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
                 for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
-            const double *R = L + S::Rw + link * 9;
-            double P[3];
-            for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
             const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
-            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
+            if (link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
+                com_task_rows<N, NT>(th, L + S::Jcm, Jtt, row, rsel, T);
+            } else {
+                const double *R = L + S::Rw + link * 9;
+                double P[3];
+                for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+                point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
+            }
             row += rsel == 0 ? 6 : 3;
         }
         DWBC_SYNC();

@@ -145,6 +145,7 @@ DWBC_DEV void link_fstar(int mode, double t, const double *tr, const double *g, 
 template <class S, int N, int NB, int NT>
 DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int inst, const double *body, double *L, const double *Vb) {
     double *fs = L + S::fs;
+    const double *qd = io.qdot ? io.qdot + (size_t)inst * N : nullptr;
     const double *fin = io.fstar + (size_t)inst * su.fstar_total;
     for (int i = th.tid; i < su.fstar_total; i += NT) fs[i] = fin[i];
     DWBC_SYNC();
@@ -158,9 +159,14 @@ DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int ins
         int off = su.fstar_off[lv];
         for (int a = 0; a < li; a++) off += su.t_mode[lv][a] <= TASK_LINK_6D_CUSTOM_FRAME ? 6 : 3;
         const int link = su.t_link[lv][li];
-        const double *R = L + S::Rw + link * 9, *p = L + S::pw + link * 3, *O = L + S::pw;
+        const bool is_com = link == su.nb;  // COM link: xpos = com_pos, rotm = pelvis rotm, (v, w) = jac_ qdot (dwbc.cpp:326,350,360-367)
+        const double *R = L + S::Rw + (is_com ? 0 : link) * 9, *p = is_com ? L + S::Jcm + 6 * N : L + S::pw + link * 3, *O = L + S::pw;
         double w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
-        if (Vb) {
+        if (is_com) {
+            if (qd)
+                for (int j = 0; j < N; j++)
+                    for (int a = 0; a < 3; a++) { v[a] += L[S::Jcm + a * N + j] * qd[j]; w[a] += L[S::Jcm + (3 + a) * N + j] * qd[j]; }
+        } else if (Vb) {
             const double *V = Vb + link * 6;
             const double d0 = p[0] - O[0], d1 = p[1] - O[1], d2 = p[2] - O[2];
             w[0] = V[0]; w[1] = V[1]; w[2] = V[2];
@@ -169,7 +175,7 @@ DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int ins
             v[2] = V[5] + (w[0] * d1 - w[1] * d0);
         }
         link_fstar(su.t_mode[lv][li], tnow, io.traj + ((size_t)inst * su.n_traj + slot) * kTrajStride, su.t_gain[lv][li], R, p, w, v,
-                   body + link * kBodyStride + BF_COM, su.t_point[lv][li], fs + off);
+                   body + (is_com ? 0 : link) * kBodyStride + BF_COM, su.t_point[lv][li], fs + off);
     }
     DWBC_SYNC();
 }

@@ -256,6 +256,7 @@ void Model::finalize() {
 int Model::link_id(const char *name) const {
     for (int i = 0; i < nb; i++)
         if (strcasecmp(names[i].c_str(), name) == 0) return i;
+    if (strcasecmp(name, "COM") == 0) return nb;  // the synthetic centre-of-mass link, id = link_num_ (reference src/dwbc.cpp:230-231)
     return -1;
 }
 

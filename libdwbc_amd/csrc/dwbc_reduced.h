@@ -80,7 +80,8 @@ struct LdsR : Lds2<N, NB, NLV> {
     static constexpr int tNC = tcR + RMX;             // NCX
     static constexpr int vecR = tNC + NCX;            // RSX
     static constexpr int v6 = vecR + RSX;             // 4 x 6 small vectors
-    static constexpr int rtotal = v6 + 24;
+    static constexpr int Jcm = v6 + 24;               // 6 N + 3: Jacobian of the COM link + com_pos (the U block holds A_R here)
+    static constexpr int rtotal = Jcm + 6 * N + 4;
     static constexpr int total_bytes = rtotal * 8 + 64;
 };
 
@@ -577,15 +578,18 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     int kind[NLV];      // 1 = contact-chain ("reduced") task, 2 = non-contact task, 0 = unsupported mix
     int first_nc = -1;
     for (int lv = 0; lv < su.n_levels; lv++) {
-        int nco = 0, nnc = 0;
+        int nco = 0, nnc = 0, ncm = 0;
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int link = su.t_link[lv][li];
+            if (link == nb) { ncm++; continue; }  // the COM link: "cmm_task" (dwbc.cpp:3190-3195)
             const bool co = link == 0 || ((comask >> (link + 5)) & 1ull);
             if (co) nco++; else nnc++;
         }
-        kind[lv] = (nco && !nnc) ? 1 : ((nnc && !nco) ? 2 : 0);
+        // 1 = contact-chain task, 2 = non-contact task, 3 = centroidal (COM) task: like 1 with the non-contact columns of the
+        // Jacobian folded through J_I_nc_inv_T (task.cpp:106-114); mixed levels are undefined in the reference (task.cpp:134-141)
+        kind[lv] = (ncm && !nco && !nnc) ? 3 : ((nco && !nnc && !ncm) ? 1 : ((nnc && !nco && !ncm) ? 2 : 0));
         if (kind[lv] == 2 && first_nc < 0) first_nc = lv;
-        if (kind[lv] == 0 || (lv == 0 && kind[lv] != 1)) st_task = 0;
+        if (kind[lv] == 0 || (lv == 0 && kind[lv] == 2)) st_task = 0;
     }
     for (int lv = 0; lv < su.n_levels && st_task; lv++) {
         const int t = su.t_dof[lv];
@@ -597,30 +601,39 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
             double pl[3] = {0, 0, 0};
-            if (mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME)
+            if ((mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME) && link < nb)
                 for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
             else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
                 for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
-            const double *R = L + S::Rw + link * 9;
-            double P[3];
-            for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
             const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
-            point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
+            if (link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
+                com_task_rows<N, NT>(th, L + S::Jcm, Jtt, row, rsel, T);
+            } else {
+                const double *R = L + S::Rw + link * 9;
+                double P[3];
+                for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+                point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
+            }
             row += rsel == 0 ? 6 : 3;
         }
         DWBC_SYNC();
-        if (kind[lv] == 1) {
-            // J_task_R_ = [J_task[:, :vc], 0] (task.cpp:119), CalculateJKT_R, Null_task_R_ chain (dwbc.cpp:3236-3246)
+        if (kind[lv] != 2) {
+            // J_task_R_ = [J_task[:, :vc], 0] (task.cpp:119) or, for a COM task, [J_task[:, :vc], J_task[:, nc] J_I_nc_inv_T^T]
+            // (task.cpp:109-110); CalculateJKT_R, Null_task_R_ chain (dwbc.cpp:3236-3246)
             for (int idx = th.tid; idx < T * RSX; idx += NT) {
                 const int r = idx / RSX, a = idx - r * RSX;
-                JRm[idx] = (r < t && a < vcd) ? Jtt[a * T + r] : 0.0;
+                double v = 0.0;
+                if (r < t && a < vcd) v = Jtt[a * T + r];
+                else if (r < t && a < RS && kind[lv] == 3)
+                    for (int i = 0; i < ncd; i++) v += Jtt[(vcd + i) * T + r] * JIiT[(a - vcd) * NCX + i];
+                JRm[idx] = v;
             }
             double *Xs = L + S::XR + lv * RMX * T, *Ys = L + S::YR + lv * T * RMX, *Ul = L + S::UR + lv * RMX * T;
             if (!jkt_reduced<N, NB, NLV, NT>(th, L, w, t, RS, RM, Lt, Ys, L + S::Bmt /*J_kt scratch*/, Xs)) st_task = 0;
             for (int idx = th.tid; idx < RM * T; idx += NT) Ul[idx] = Xs[idx];
             DWBC_SYNC();
             for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U over the earlier contact-chain levels
-                if (kind[pl] != 1) continue;
+                if (kind[pl] == 2) continue;
                 const int tp = su.t_dof[pl];
                 const double *Xp = L + S::XR + pl * RMX * T, *Yp = L + S::YR + pl * T * RMX;
                 double *Z = L + S::sm;
@@ -717,7 +730,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         }
         // keep J^T and J A^-1 N_c of this level if the next one is a later non-contact level
         if (lv + 1 < su.n_levels && kind[lv + 1] == 2 && lv + 1 != first_nc) {
-            if (kind[lv] == 1) {
+            if (kind[lv] != 2) {
                 LANES {
                     double tc_[T];
 #pragma unroll
@@ -795,7 +808,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             for (int i = th.tid; i < ncd; i += NT) tNC[i] += tmpv[vcd + i] - tmp2[vcd + i];  // torque_null_h_nc_ (dwbc.cpp:3309,3317)
             DWBC_SYNC();
             for (int pl = qi - 1; pl >= 0; pl--) {  // torque_null_h_R_ = Null_task_R_{qi-1} torque_h_R_
-                if (kind[pl] != 1 || pl == su.n_levels - 1) continue;
+                if (kind[pl] == 2 || pl == su.n_levels - 1) continue;
                 const int tp = su.t_dof[pl];
                 const double *Xp = L + S::XR + pl * RMX * T, *Yp = L + S::YR + pl * T * RMX;
                 double *Z = L + S::sm;
@@ -828,7 +841,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             for (int idx = th.tid; idx < RM * T; idx += NT) Ul[idx] = Jbk[idx];
             DWBC_SYNC();
             for (int pl = first_nc - 1; pl >= 0; pl--) {
-                if (kind[pl] != 1) continue;
+                if (kind[pl] == 2) continue;
                 const int tp = su.t_dof[pl];
                 const double *Xp = L + S::XR + pl * RMX * T, *Yp = L + S::YR + pl * T * RMX;
                 double *Z = L + S::sm;

@@ -67,7 +67,10 @@ inline int setup_add_contact(Setup &su, int link, int contact_type, const double
 inline bool setup_add_task(Setup &su, int level, int mode, int link, const double *point, std::string &err) {
     if (level < 0 || level > su.n_levels || level >= kMaxLevels) { err = "bad task level (levels must be added in order)"; return false; }
     if (mode < 0 || mode > TASK_LINK_ROTATION_CUSTOM_FRAME) { err = "bad task mode"; return false; }
-    if (link < 0 || link >= su.nb) { err = "bad link id"; return false; }
+    if (link < 0 || link > su.nb) { err = "bad link id"; return false; }
+    // link == nb: the synthetic "COM" link (reference src/dwbc.cpp:230-231); its Jacobian is jac_com_ = SI_body^-1 CMM_.  The
+    // *_CUSTOM_FRAME position modes ask RBDL for a point Jacobian of a body the COM link does not have (dwbc.cpp:739,766)
+    if (link == su.nb && (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)) { err = "custom-frame task on the COM link is undefined in the reference"; return false; }
     for (int l = 0; l < su.n_levels; l++)
         for (int j = 0; j < su.t_nlinks[l]; j++)
             if (su.t_link[l][j] == link) { err = "Task Space Already Exist for Link"; return false; }  // src/dwbc.cpp:536-546
@@ -85,7 +88,11 @@ inline bool setup_add_task(Setup &su, int level, int mode, int link, const doubl
     for (int a = 0; a < 3; a++) su.t_point[level][j][a] = point ? point[a] : 0.0;
     su.t_nlinks[level]++;
     su.t_dofmask[level] = 0;
-    for (int a = 0; a < su.t_nlinks[level]; a++) su.t_dofmask[level] |= link_dofmask(su, su.t_link[level][a]);
+    for (int a = 0; a < su.t_nlinks[level]; a++)
+        su.t_dofmask[level] |= su.t_link[level][a] == su.nb ? ((1ull << su.ndof) - 1ull) : link_dofmask(su, su.t_link[level][a]);
+    su.has_com_task = 0;
+    for (int l = 0; l < su.n_levels; l++)
+        for (int a = 0; a < su.t_nlinks[l]; a++) su.has_com_task |= su.t_link[l][a] == su.nb;
     setup_fstar_layout(su);
     return true;
 }

@@ -56,6 +56,7 @@ struct Setup {
     double t_gain[kMaxLevels][kMaxTaskLinks][15];
     int t_traj_slot[kMaxLevels][kMaxTaskLinks];
     int n_traj;
+    int has_com_task;  // some task level controls the synthetic COM link (link id = nb)
 };
 
 // per-instance diagnostics (int32)

@@ -463,6 +463,10 @@ class Cycle:
     def task_jacobian(self, level):
         rows = []
         for mode, link, pt in self.tasks[level]:
+            if link == self.model["nb"]:  # the synthetic "COM" link: jac_ = jac_com_ = SI_body^-1 CMM_ (dwbc.cpp:230-231,352-353)
+                J = self.J_com
+                rows.append(J if mode <= TASK_LINK_6D_CUSTOM_FRAME else (J[:3] if mode <= TASK_LINK_POSITION_CUSTOM_FRAME else J[3:]))
+                continue
             com_l = self.model["com"][link]
             if mode in (TASK_LINK_6D, TASK_LINK_POSITION, TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME):
                 J = point_jacobian(self.model, self.R, self.p, link, np.zeros(3))

@@ -733,8 +733,9 @@ void orc_cycle(const orc_model *mdl, const orc_setup *su, const double *q, const
     }
     mm(CMM, n, cm, 6, A, n, 6, 6, n);
     double G[ORC_MAXN];
+    double Jcom[6 * ORC_MAXN]; /* link_.back().jac_ = jac_com_ (dwbc.cpp:352-353): the Jacobian of the "COM" link */
     {
-        double A33[9], T[9], Icom[9], S[9], SSt[9], SI[36], SIi[36], Jcom[6 * ORC_MAXN];
+        double A33[9], T[9], Icom[9], S[9], SSt[9], SI[36], SIi[36];
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) A33[a * 3 + b] = A[(3 + a) * n + 3 + b];
         m3mul(T, R[0], A33);
@@ -853,9 +854,10 @@ void orc_cycle(const orc_model *mdl, const orc_setup *su, const double *q, const
             int mode = su->t_mode[lv][li], link = su->t_link[lv][li];
             double J6[6 * ORC_MAXN];
             const double *pt = zero3;
-            if (mode == 1 || mode == 4) pt = mdl->com[link];
+            if ((mode == 1 || mode == 4) && link < mdl->nb) pt = mdl->com[link];
             else if (mode == 2 || mode == 5) pt = su->t_point[lv][li];
-            point_jacobian(mdl, R, p, link, pt, J6, n);
+            if (link == mdl->nb) memcpy(J6, Jcom, sizeof(double) * 6 * n); /* the COM link (dwbc.cpp:230-231,708-780) */
+            else point_jacobian(mdl, R, p, link, pt, J6, n);
             if (mode <= 2) { memcpy(Jt[lv] + t * n, J6, sizeof(double) * 6 * n); t += 6; }
             else if (mode <= 5) { memcpy(Jt[lv] + t * n, J6, sizeof(double) * 3 * n); t += 3; }
             else { memcpy(Jt[lv] + t * n, J6 + 3 * n, sizeof(double) * 3 * n); t += 3; }

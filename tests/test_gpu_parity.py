@@ -256,3 +256,35 @@ def test_full_size_configs_3_and_4(cfg):
     assert (st_r == st[idx]).all()
     okr = st_r == 1
     assert np.abs(tau[idx][okr] - tau_r[okr]).max() < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_com_task_hierarchy_vs_oracle():
+    """COM position + pelvis rotation + upper-body rotation: the COM link's Jacobian is jac_com_ (reference
+    src/dwbc.cpp:352-353); link id = link_num_ = 34, also reachable as model.link_id("COM")"""
+    import libdwbc_amd as D
+    from oracle import orc
+
+    B = 64
+    tasks = [[(3, 34, (0, 0, 0))], [(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))]]
+    q, fl, _ = cases.synth_batch(B, seed=77, yaw=True)
+    fs = 1.5 * np.random.default_rng(7).uniform(-1, 1, size=(B, 9))
+    model = D.Model.from_urdf(cases.URDF)
+    assert model.link_id("COM") == 34
+    wbc = D.Batch(model, B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    for lv, links in enumerate(tasks):
+        for mode, link, pt in links:
+            wbc.add_task(lv, mode, link, pt)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar_all(fs)
+    wbc.solve()
+    M = orc.make_model(cases.tocabi_model())
+    S = orc.make_setup(cases.CONTACTS_2, tasks, cases.TAU_LIM)
+    tau, wr, st, _ = orc.cycle_batch(M, S, q, fl, fs, 0)
+    assert (wbc.get("status") == st).all() and st.mean() > 0.9
+    ok = st == 1
+    assert np.abs(wbc.get("tau")[ok] - tau[ok]).max() < 1e-6

@@ -85,3 +85,32 @@ def test_emulated_centroidal_outputs_vs_numpy_oracle():
         mtot = cases.tocabi_model()["mass"].sum()
         Jc = e.dump_field(d, "J_com", (6, 39))[i]
         assert np.abs(-Jc[:3].T @ (mtot * np.array([0, 0, -9.81])) - e.dump_field(d, "G", (39,))[i]).max() < 1e-9
+
+
+COM_LINK = 34  # the synthetic "COM" link, id = link_num_ (reference src/dwbc.cpp:230-231)
+COM_TASKS = [[(3, COM_LINK, (0, 0, 0))], [(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))]]  # COM position, pelvis rotation, upper-body rotation
+
+
+def test_emulated_kernel_com_task_hierarchy():
+    """a task level on the COM link uses jac_com_ = SI_body^-1 CMM_ (reference src/dwbc.cpp:352-353, :708-780)"""
+    from oracle.dwbc_np import Cycle
+
+    B = 8
+    q, fl, _ = cases.synth_batch(B, seed=21, yaw=True)
+    fs = 1.5 * np.random.default_rng(2).uniform(-1, 1, size=(B, 9))
+    e = Emu(cases.URDF, cases.CONTACTS_2, COM_TASKS, cases.TAU_LIM)
+    r = e.run(q, fl, fs)
+    tau, wr, st, _ = _oracle(q, fl, fs, cases.CONTACTS_2, COM_TASKS, cases.TAU_LIM)
+    assert (r["status"] == st).all() and st.all()
+    assert np.abs(tau[:, 1]).max() > 5.0
+    assert np.abs(r["tau"] - tau).max() < 1e-6
+    # the numpy twin agrees with the C restatement on the COM Jacobian rows
+    c = Cycle(cases.tocabi_model())
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    for lv, links in enumerate(COM_TASKS):
+        for m_, l_, p_ in links:
+            c.add_task(lv, m_, l_, p_)
+    c.set_torque_limit(cases.TAU_LIM)
+    t = c.run(q[0], [1, 1], [fs[0, 0:3], fs[0, 3:6], fs[0, 6:9]])
+    assert np.abs(t - tau[0].sum(axis=0)).max() < 1e-8

@@ -116,6 +116,9 @@ HIERARCHIES = {
     # right hand (a later non-contact level: the null_force_ branch, dwbc.cpp:3311-3325)
     "pelvis_rot-upper-rhand": ([[(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(0, 33, (0, 0, 0))]], 12),
     "pelvis6d-upper-rhand-lhandpos": ([[(0, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(0, 33, (0, 0, 0))], [(3, 23, (0, 0, 0))]], 18),
+    # the reference harness itself (redu_dyn_test.cpp:98-103): COM position (a "cmm" level, task.cpp:106-114), pelvis rotation,
+    # upper-body rotation, right hand 6D
+    "com_pos-pelvis_rot-upper-rhand": ([[(3, 34, (0, 0, 0))], [(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(0, 33, (0, 0, 0))]], 15),
     # a contact-chain level after the non-contact one (Null_task_R_ is carried over it, dwbc.cpp:3247-3250)
     "pelvis_rot-upper-hiproll_pos": ([[(6, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))], [(3, 1, (0, 0, 0))]], 9),
 }
@@ -132,10 +135,11 @@ def test_emulated_reduced_kernel_task_hierarchies(name):
     e = Emu(cases.URDF, cases.CONTACTS_2, tasks, None)
     r = e.run(q, fl, fs, reduced=True)
     tau, wr, st = oracle_batch(q, fl, fs, tasks)
-    assert (r["status"] == st).all() and st.all()
+    assert (r["status"] == st).all() and st.mean() > 0.6
+    ok = st == 1
     assert np.abs(tau[:, 1]).max() > 1.0  # the hierarchy does something
-    assert np.abs(r["tau"] - tau).max() < TOL_TAU
-    assert np.abs(r["wrench"] - wr).max() < 1e-5
+    assert np.abs(r["tau"][ok] - tau[ok]).max() < TOL_TAU
+    assert np.abs(r["wrench"][ok] - wr[ok]).max() < 1e-5
 
 
 def test_emulated_reduced_kernel_rejects_out_of_scope():
@@ -180,6 +184,31 @@ def test_gpu_reduced_kernel_vs_oracle(cfg):
     wbc.set_torque_limit(np.array(cases.TAU_LIM))
     with pytest.raises(RuntimeError):
         wbc.solve(reduced=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(HIERARCHIES))
+def test_gpu_reduced_task_hierarchies(name):
+    import libdwbc_amd as D
+
+    tasks, nf = HIERARCHIES[name]
+    B = 16
+    q, fl, _ = cases.synth_batch(B, seed=12)
+    fs = 2.0 * np.random.default_rng(5).uniform(-1, 1, size=(B, nf))
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    for lv, links in enumerate(tasks):
+        for mode, link, pt in links:
+            wbc.add_task(lv, mode, link, pt)
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar_all(fs)
+    wbc.solve(reduced=True)
+    tau, wr, st = oracle_batch(q, fl, fs, tasks)
+    assert (wbc.get("status") == st).all() and st.mean() > 0.5
+    ok = st == 1
+    assert np.abs(wbc.get("tau")[ok] - tau[ok]).max() < TOL_TAU
 
 
 @pytest.mark.gpu
