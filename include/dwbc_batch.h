@@ -112,6 +112,10 @@ int dwbc_batch_add_contact(dwbc_batch *b, int link, int contact_type, const doub
 int dwbc_batch_clear_contacts(dwbc_batch *b);                               /* ClearContactConstraint */
 /* AddTaskSpace(level, mode, link, point) include/dwbc.h:319 (same level twice appends a link, src/dwbc.cpp:592-600) */
 int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const double point[3]);
+/* AddTaskSpace(heirarchy, TASK_CUSTOM, task_dof) include/dwbc.h:318 and SetTaskSpace(heirarchy, f*, J_task) include/dwbc.h:333:
+ * a level whose Jacobian the caller supplies, per instance (fstar: B x task_dof or NULL to keep, J: B x task_dof x ndof row-major) */
+int dwbc_batch_add_custom_task(dwbc_batch *b, int level, int task_dof);
+int dwbc_batch_set_custom_task(dwbc_batch *b, int level, const double *fstar, const double *J);
 int dwbc_batch_clear_tasks(dwbc_batch *b);                                  /* ClearTaskSpace */
 /* ---- on-device task reference (reference src/task.cpp:223-339, src/dwbc.cpp:708-780): a task link with a trajectory gets its
  * f* segment from the quintic / slerp trajectory + PD law on the device; link_index = position of the link inside its level.

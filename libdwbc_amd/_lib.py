@@ -30,6 +30,8 @@ SYMBOLS = [
     ("dwbc_batch_add_contact", _i, [_vp, _i, _i, _vp, _d, _d, _d, _d]),
     ("dwbc_batch_clear_contacts", _i, [_vp]),
     ("dwbc_batch_add_task", _i, [_vp, _i, _i, _i, _vp]),
+    ("dwbc_batch_add_custom_task", _i, [_vp, _i, _i]),
+    ("dwbc_batch_set_custom_task", _i, [_vp, _i, _vp, _vp]),
     ("dwbc_batch_clear_tasks", _i, [_vp]),
     ("dwbc_batch_set_task_gain", _i, [_vp, _i, _i] + [_vp] * 6),
     ("dwbc_batch_set_trajectory", _i, [_vp, _i, _i, _vp]),

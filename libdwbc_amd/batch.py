@@ -144,6 +144,21 @@ class Batch:
             assert qd.shape == (self.B, self.n), qd.shape
         _check(self._L.dwbc_batch_set_state(self._h, q.ctypes.data, qd.ctypes.data if qd is not None else None, None))
 
+    def add_custom_task(self, level, task_dof):
+        """AddTaskSpace(heirarchy, TASK_CUSTOM, task_dof) (reference include/dwbc.h:318)"""
+        _check(self._L.dwbc_batch_add_custom_task(self._h, int(level), int(task_dof)))
+
+    def set_custom_task(self, level, fstar, J):
+        """SetTaskSpace(heirarchy, f*, J_task) (reference include/dwbc.h:333): fstar (B, t), J (B, t, n)"""
+        J = np.ascontiguousarray(J, np.float64)
+        t = self.task_dof(level)
+        assert J.shape == (self.B, t, self.n), J.shape
+        f = None
+        if fstar is not None:
+            f = np.ascontiguousarray(fstar, np.float64)
+            assert f.shape == (self.B, t), f.shape
+        _check(self._L.dwbc_batch_set_custom_task(self._h, int(level), f.ctypes.data if f is not None else None, J.ctypes.data))
+
     def set_task_gain(self, level, link_index, pos_p, pos_d, pos_a, rot_p, rot_d, rot_a=(0, 0, 0)):
         """TaskLink::SetTaskGain (reference include/dwbc_task.h:108)"""
         arrs = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (3,))) for a in (pos_p, pos_d, pos_a, rot_p, rot_d, rot_a)]

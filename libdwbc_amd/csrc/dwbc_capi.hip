@@ -127,6 +127,9 @@ struct dwbc_batch {
     // device buffers (owned unless bound)
     double *d_qdot = nullptr;  // B x n, allocated when the caller passes a qdot
     double *d_traj = nullptr, *d_ctime = nullptr;  // on-device task reference inputs (dwbc_fstar.h)
+    double *d_custom = nullptr;  // B x n_custom x 6 x n: J_task of the TASK_CUSTOM levels
+    std::vector<double> h_custom;
+    bool dirty_custom = false;
     std::vector<double> h_traj, h_ctime;
     bool dirty_traj = false, dirty_ctime = false;
     std::vector<double> h_qdot;
@@ -270,6 +273,7 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     if (b->d_qdot) hipFree(b->d_qdot);
     if (b->d_traj) hipFree(b->d_traj);
     if (b->d_ctime) hipFree(b->d_ctime);
+    if (b->d_custom) hipFree(b->d_custom);
     if (b->own_fstar) hipFree(b->d_fstar);
     if (b->own_flags) hipFree(b->d_flags);
     if (b->own_tau) hipFree(b->d_tau);
@@ -308,9 +312,36 @@ int dwbc_batch_add_task(dwbc_batch *b, int level, int mode, int link, const doub
     return 1;
 }
 
+int dwbc_batch_add_custom_task(dwbc_batch *b, int level, int task_dof) {
+    std::string err;
+    if (!setup_add_custom_task(b->su, level, task_dof, err)) return fail(err);
+    b->h_fstar.assign((size_t)b->B * b->su.fstar_total, 0.0);
+    b->dirty_fstar = true;
+    b->h_custom.assign((size_t)b->B * b->su.n_custom * kMaxTaskDof * b->n, 0.0);
+    if (b->d_custom) { hipFree(b->d_custom); b->d_custom = nullptr; }
+    b->dirty_custom = true;
+    return 1;
+}
+
+int dwbc_batch_set_custom_task(dwbc_batch *b, int level, const double *fstar, const double *J) {
+    if (level < 0 || level >= b->su.n_levels) return fail("ERROR : task space size overflow");
+    const int slot = b->su.t_custom_slot[level];
+    if (slot < 0) return fail("not a TASK_CUSTOM level");
+    if (!J) return fail("J_task is NULL");
+    if (fstar && !dwbc_batch_set_fstar(b, level, fstar)) return 0;
+    const int t = b->su.t_dof[level], n = b->n, ns = b->su.n_custom;
+    const size_t stride = (size_t)kMaxTaskDof * n;
+    for (int i = 0; i < b->B; i++) memcpy(&b->h_custom[((size_t)i * ns + slot) * stride], J + (size_t)i * t * n, sizeof(double) * t * n);
+    b->dirty_custom = true;
+    return 1;
+}
+
 int dwbc_batch_clear_tasks(dwbc_batch *b) {
     b->su.n_levels = 0;
     b->su.has_com_task = 0;
+    b->su.n_custom = 0;
+    for (int l = 0; l < kMaxLevels; l++) b->su.t_custom_slot[l] = -1;
+    b->h_custom.clear();
     setup_fstar_layout(b->su);
     b->h_fstar.clear();
     b->su.n_traj = 0;
@@ -446,6 +477,11 @@ static int upload_inputs(dwbc_batch *b) {
         HIP_OK(hipMemcpyAsync(b->d_traj, b->h_traj.data(), b->h_traj.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
         b->dirty_traj = false;
     }
+    if (b->dirty_custom && b->su.n_custom > 0) {
+        if (!b->d_custom) HIP_OK(hipMalloc(&b->d_custom, b->h_custom.size() * sizeof(double)));
+        HIP_OK(hipMemcpyAsync(b->d_custom, b->h_custom.data(), b->h_custom.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        b->dirty_custom = false;
+    }
     if (b->dirty_ctime) {
         if (!b->d_ctime) HIP_OK(hipMalloc(&b->d_ctime, (size_t)b->B * sizeof(double)));
         HIP_OK(hipMemcpyAsync(b->d_ctime, b->h_ctime.data(), b->h_ctime.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -493,6 +529,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.qdot = b->d_qdot;
     io.traj = b->su.n_traj > 0 ? b->d_traj : nullptr;
     io.ctime = b->d_ctime;
+    io.custom_J = b->su.n_custom > 0 ? b->d_custom : nullptr;
     io.flags = b->d_flags;
     io.fstar = b->d_fstar;
     io.tau = b->d_tau;
@@ -523,6 +560,7 @@ int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
     if (b->su.n_contacts < 1) return fail("no contact constraint");
     const bool reduced = flags & DWBC_SOLVE_REDUCED;
     b->last_reduced = reduced;
+    if (reduced && b->su.n_custom > 0) return fail("TASK_CUSTOM levels are not built on the reduced dynamics path");
     if (reduced && b->su.has_tau_lim)
         return fail("reduced dynamics path with a torque limit is inconsistent in the reference (src/dwbc.cpp:3462-3467,3513; "
                     "its harness disables the limit, tests/sp_test/redu_dyn_test.cpp:63): call dwbc_batch_set_torque_limit(b, NULL)");

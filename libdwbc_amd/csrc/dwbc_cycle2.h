@@ -374,6 +374,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = 0.0;
         DWBC_SYNC();
         int row = 0;
+        if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
+            const double *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
+            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = cj[idx];
+        }
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
             double pl[3] = {0, 0, 0};

@@ -587,6 +587,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         }
         // 1 = contact-chain task, 2 = non-contact task, 3 = centroidal (COM) task: like 1 with the non-contact columns of the
         // Jacobian folded through J_I_nc_inv_T (task.cpp:106-114); mixed levels are undefined in the reference (task.cpp:134-141)
+        // (TASK_CUSTOM levels are classified by the norms of their Jacobian blocks in the reference, dwbc.cpp:3170-3185: not built)
         kind[lv] = (ncm && !nco && !nnc) ? 3 : ((nco && !nnc && !ncm) ? 1 : ((nnc && !nco && !ncm) ? 2 : 0));
         if (kind[lv] == 2 && first_nc < 0) first_nc = lv;
         if (kind[lv] == 0 || (lv == 0 && kind[lv] == 2)) st_task = 0;
@@ -598,6 +599,10 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = 0.0;
         DWBC_SYNC();
         int row = 0;
+        if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
+            const double *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
+            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = cj[idx];
+        }
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
             double pl[3] = {0, 0, 0};

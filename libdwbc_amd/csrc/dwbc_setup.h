@@ -17,6 +17,7 @@ inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
     su.qp_max_iter_contact = 300;  // reference src/dwbc.cpp:1546
     for (int l = 0; l < kMaxLevels; l++)
         for (int j = 0; j < kMaxTaskLinks; j++) su.t_traj_slot[l][j] = -1;
+    for (int l = 0; l < kMaxLevels; l++) su.t_custom_slot[l] = -1;
 }
 
 // parent body of every body (Model::topo_table()[0..nb)); must be installed before contacts / tasks are added
@@ -38,6 +39,7 @@ inline void setup_fstar_layout(Setup &su) {
     for (int l = 0; l < su.n_levels; l++) {
         int t = 0;
         for (int j = 0; j < su.t_nlinks[l]; j++) t += task_mode_dof(su.t_mode[l][j]);
+        if (su.t_custom_slot[l] >= 0) t = su.t_dof[l];  // TASK_CUSTOM: the dof given to AddTaskSpace(h, TASK_CUSTOM, dof)
         su.t_dof[l] = t;
         su.fstar_off[l] = off;
         off += t;
@@ -64,7 +66,21 @@ inline int setup_add_contact(Setup &su, int link, int contact_type, const double
     return i;
 }
 
+// AddTaskSpace(heirarchy, TASK_CUSTOM, task_dof) (reference src/dwbc.cpp:522-530): a level whose Jacobian the caller supplies
+inline bool setup_add_custom_task(Setup &su, int level, int task_dof, std::string &err) {
+    if (level != su.n_levels || level >= kMaxLevels) { err = "bad task level (levels must be added in order)"; return false; }
+    if (task_dof < 1 || task_dof > kMaxTaskDof) { err = "custom task dof must be 1..6 on the device path"; return false; }
+    su.n_levels++;
+    su.t_nlinks[level] = 0;
+    su.t_custom_slot[level] = su.n_custom++;
+    su.t_dof[level] = task_dof;
+    su.t_dofmask[level] = (1ull << su.ndof) - 1ull;
+    setup_fstar_layout(su);
+    return true;
+}
+
 inline bool setup_add_task(Setup &su, int level, int mode, int link, const double *point, std::string &err) {
+    if (level >= 0 && level < su.n_levels && su.t_custom_slot[level] >= 0) { err = "cannot add a link to a TASK_CUSTOM level"; return false; }
     if (level < 0 || level > su.n_levels || level >= kMaxLevels) { err = "bad task level (levels must be added in order)"; return false; }
     if (mode < 0 || mode > TASK_LINK_ROTATION_CUSTOM_FRAME) { err = "bad task mode"; return false; }
     if (link < 0 || link > su.nb) { err = "bad link id"; return false; }

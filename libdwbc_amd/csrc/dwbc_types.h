@@ -57,6 +57,9 @@ struct Setup {
     int t_traj_slot[kMaxLevels][kMaxTaskLinks];
     int n_traj;
     int has_com_task;  // some task level controls the synthetic COM link (link id = nb)
+    // TASK_CUSTOM levels (reference include/dwbc.h:318,333): the caller supplies J_task per instance; slot into BatchIO::custom_J or -1
+    int t_custom_slot[kMaxLevels];
+    int n_custom;
 };
 
 // per-instance diagnostics (int32)
@@ -123,6 +126,7 @@ struct BatchIO {
     const double *fstar;         // B x fstar_total
     const double *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
     const double *ctime;         // B control times (RobotData::control_time_) or nullptr
+    const double *custom_J;      // B x n_custom x (kMaxTaskDof x N) row-major J_task of the TASK_CUSTOM levels, or nullptr
     double *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
     double *wrench;              // B x 12    : getContactForce(tau_total), zero padded
     int *status;                 // B         : 1 ok / 0 fail (reference int returns ANDed)

@@ -394,6 +394,17 @@ class Cycle:
             self.tasks.append([])
         self.tasks[level].append((mode, link, np.asarray(point, float)))
 
+    def add_custom_task(self, level, dof):
+        """AddTaskSpace(heirarchy, TASK_CUSTOM, task_dof) (dwbc.cpp:522-530); the Jacobian comes from set_custom_J"""
+        while len(self.tasks) <= level:
+            self.tasks.append([])
+        self.tasks[level] = ("custom", dof)
+        self.custom_J = getattr(self, "custom_J", {})
+
+    def set_custom_J(self, level, J):
+        """SetTaskSpace(heirarchy, f*, J_task) (dwbc.cpp:664-681)"""
+        self.custom_J[level] = np.asarray(J, float)
+
     def set_torque_limit(self, lim):
         self.tau_lim = np.asarray(lim, float)
 
@@ -461,6 +472,8 @@ class Cycle:
 
     # -- UpdateTaskSpace (dwbc.cpp:685-793)
     def task_jacobian(self, level):
+        if isinstance(self.tasks[level], tuple) and self.tasks[level][0] == "custom":
+            return self.custom_J[level]
         rows = []
         for mode, link, pt in self.tasks[level]:
             if link == self.model["nb"]:  # the synthetic "COM" link: jac_ = jac_com_ = SI_body^-1 CMM_ (dwbc.cpp:230-231,352-353)

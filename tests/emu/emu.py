@@ -47,6 +47,9 @@ class Emu:
             pt = np.asarray(c["point"], dtype=np.float64)
             assert L.emu_add_contact(self.h, c["link"], pt.ctypes.data, c["lx"], c["ly"], c.get("mu", 0.2), c.get("muz", 0.2)) >= 0
         for lv, links in enumerate(tasks):
+            if isinstance(links, int):  # TASK_CUSTOM level of that many dof
+                assert L.emu_add_custom_task(C.c_void_p(self.h), lv, links) == 1, L.emu_error(self.h)
+                continue
             for mode, link, pt in links:
                 p = np.asarray(pt, dtype=np.float64)
                 assert L.emu_add_task(self.h, lv, mode, link, p.ctypes.data) == 1, L.emu_error(self.h)
@@ -68,7 +71,7 @@ class Emu:
         g = np.ascontiguousarray(gains15, np.float64)
         self.L.emu_set_traj(C.c_void_p(self.h), level, link_index, slot, C.c_void_p(g.ctypes.data))
 
-    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None):
+    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None, custom_J=None):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -81,6 +84,8 @@ class Emu:
         dmp = np.zeros((B, self.D)) if dump else None
         qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
         self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))
+        cj = None if custom_J is None else np.ascontiguousarray(custom_J, np.float64)  # (B, n_custom, 6, n)
+        self.L.emu_set_custom(C.c_void_p(cj.ctypes.data if cj is not None else None))
         tr = None if traj is None else np.ascontiguousarray(traj, np.float64)
         ct = None if ctime is None else np.ascontiguousarray(ctime, np.float64)
         self.L.emu_set_traj_data(C.c_void_p(tr.ctypes.data if tr is not None else None), C.c_void_p(ct.ctypes.data if ct is not None else None))

@@ -92,6 +92,9 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     return 1;
 }
 
+static const double *g_emu_custom = nullptr;
+int emu_add_custom_task(EmuCtx *c, int level, int dof) { return setup_add_custom_task(c->su, level, dof, c->err) ? 1 : 0; }
+void emu_set_custom(const double *J) { g_emu_custom = J; }
 static const double *g_emu_traj = nullptr, *g_emu_ctime = nullptr;
 void emu_set_traj(EmuCtx *c, int level, int link_index, int slot, const double *gains15) {
     c->su.t_traj_slot[level][link_index] = slot;
@@ -111,6 +114,7 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.qdot = g_emu_qdot;
     io.traj = c->su.n_traj > 0 ? g_emu_traj : nullptr;
     io.ctime = g_emu_ctime;
+    io.custom_J = c->su.n_custom > 0 ? g_emu_custom : nullptr;
     io.flags = flags;
     io.fstar = fstar;
     io.tau = tau;

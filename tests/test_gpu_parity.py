@@ -288,3 +288,28 @@ def test_gpu_com_task_hierarchy_vs_oracle():
     assert (wbc.get("status") == st).all() and st.mean() > 0.9
     ok = st == 1
     assert np.abs(wbc.get("tau")[ok] - tau[ok]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_custom_task_level_vs_oracle():
+    """AddTaskSpace(h, TASK_CUSTOM, dof) + SetTaskSpace(h, f*, J) (reference include/dwbc.h:318,333) through the C-ABI"""
+    import libdwbc_amd as D
+    from tests.test_kernel_emulation import _custom_case
+
+    B = 16
+    q, fl, fs, J, tau, st = _custom_case(B, 43)
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_custom_task(1, 3)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar(0, fs[:, :6])
+    wbc.set_custom_task(1, fs[:, 6:], J)
+    wbc.solve()
+    assert (wbc.get("status") == st).all() and st.all()
+    assert np.abs(wbc.get("tau") - tau).max() < 1e-6
+    with pytest.raises(RuntimeError):
+        wbc.solve(reduced=True)

@@ -114,3 +114,42 @@ def test_emulated_kernel_com_task_hierarchy():
     c.set_torque_limit(cases.TAU_LIM)
     t = c.run(q[0], [1, 1], [fs[0, 0:3], fs[0, 3:6], fs[0, 6:9]])
     assert np.abs(t - tau[0].sum(axis=0)).max() < 1e-8
+
+
+def _custom_case(B, seed):
+    """level 0 = pelvis 6D (link task), level 1 = TASK_CUSTOM of 3 dof with a caller-made Jacobian: the difference of the two
+    hands' linear Jacobians (a relative-position task no TASK_LINK mode can express)"""
+    from oracle import dwbc_np as Dn
+
+    m = cases.tocabi_model()
+    q, fl, _ = cases.synth_batch(B, seed=seed, yaw=True)
+    fs = 0.8 * np.random.default_rng(seed).uniform(-1, 1, size=(B, 9))
+    J = np.zeros((B, 3, 39))
+    tau = np.zeros((B, 3, 33))
+    st = np.zeros(B, np.int32)
+    for b in range(B):
+        R, p = Dn.forward_kinematics(m, q[b])
+        J[b] = Dn.point_jacobian(m, R, p, 23, np.zeros(3))[:3] - Dn.point_jacobian(m, R, p, 33, np.zeros(3))[:3]
+        c = Dn.Cycle(m)
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.add_task(0, 0, 0)
+        c.add_custom_task(1, 3)
+        c.set_custom_J(1, J[b])
+        c.set_torque_limit(cases.TAU_LIM)
+        c.run(q[b], [1, 1], [fs[b, :6], fs[b, 6:]])
+        st[b] = c.status
+        tau[b] = [c.tau_grav, c.tau_task, c.tau_contact]
+    return q, fl, fs, J, tau, st
+
+
+def test_emulated_kernel_custom_task_level():
+    """AddTaskSpace(h, TASK_CUSTOM, dof) + SetTaskSpace(h, f*, J) (reference include/dwbc.h:318,333)"""
+    B = 6
+    q, fl, fs, J, tau, st = _custom_case(B, 41)
+    e = Emu(cases.URDF, cases.CONTACTS_2, [cases.TASKS_2LEVEL[0], 3], cases.TAU_LIM)
+    Jpad = np.zeros((B, 1, 6, 39))
+    Jpad[:, 0, :3] = J
+    r = e.run(q, fl, fs, custom_J=Jpad)
+    assert (r["status"] == st).all() and st.all()
+    assert np.abs(tau[:, 1]).max() > 1.0 and np.abs(r["tau"] - tau).max() < 1e-6
