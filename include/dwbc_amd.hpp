@@ -81,6 +81,8 @@ struct LinkView {  // the kinematic fields of DWBC::Link callers read (include/d
 };
 struct ContactView {  // include/dwbc_contact_constraint.h:27-80
     int link_number_ = -1;
+    Vec3 xc_pos, zmp_pos;  // include/dwbc_contact_constraint.h: contact point (world) and the contact's ZMP
+    Mat rotm;
     bool contact = false;
     int contact_dof_ = 6;
 };
@@ -236,6 +238,21 @@ class RobotData {
     // back to the full model for the next CalcContactConstraint / CalcTaskControlTorque
     void UseFullDynamics() { if (reduced_) dirty_ = true; reduced_ = false; }
 
+    Vec3 getZMP(const Vec &contact_force) {  // dwbc.h:304, src/dwbc.cpp:898-939 (packed wrench of the active contacts)
+        double tot = 0.0, z[3] = {0, 0, 0};
+        unsigned a = 0;
+        for (auto &c : cc_) if (c.contact) { tot += contact_force[6 * a + 2]; a++; }
+        a = 0;
+        for (auto &c : cc_) {
+            if (!c.contact) continue;
+            const double fz = contact_force[6 * a + 2];
+            c.zmp_pos = c.xc_pos;
+            if (!(fz > -1.0e-3)) { c.zmp_pos.v[0] += -contact_force[6 * a + 4] / fz; c.zmp_pos.v[1] += contact_force[6 * a + 3] / fz; }
+            for (int x = 0; x < 3; x++) z[x] += c.zmp_pos.v[x] * fz / tot;
+            a++;
+        }
+        return Vec3(z[0], z[1], z[2]);
+    }
     int CalcAll(bool init = true) { int ok = refresh(init); torque_contact_ = tau_contact_final_; return ok && diag_[0] && diag_[1] && diag_[2]; }
     Vec getContactForce(const Vec &command_torque) {  // wbd.cpp:268-271: J_C_INV_T[:,6:] tau - P_C
         Vec f(contact_dof_, 0.0);
@@ -300,6 +317,17 @@ class RobotData {
         G_ = g.d; P_C = pc.d;
         CMM_ = fetch(DWBC_CMM, 6, n); J_com_ = fetch(DWBC_J_COM, 6, n); com_inertia_ = fetch(DWBC_COM_INERTIA, 3, 3);
         { Mat cp = fetch(DWBC_COM, 1, 3); com_pos = Vec3(cp.d[0], cp.d[1], cp.d[2]); }
+        {
+            Mat xp = fetch(DWBC_CONTACT_POS, 2, 3), xr = fetch(DWBC_CONTACT_ROT, 2, 9);
+            int a = 0;
+            for (auto &c : cc_) {
+                if (!c.contact || a >= 2) continue;
+                c.xc_pos = Vec3(xp(a, 0), xp(a, 1), xp(a, 2));
+                c.rotm = Mat(3, 3);
+                for (int x = 0; x < 9; x++) c.rotm.d[x] = xr(a, x);
+                a++;
+            }
+        }
         {
             Mat bb = fetch(DWBC_B, 1, n), lr = fetch(DWBC_LINK_R, 48, 9), lp = fetch(DWBC_LINK_P, 48, 3), lv = fetch(DWBC_LINK_V, 48, 3), lw = fetch(DWBC_LINK_W, 48, 3);
             B_ = bb.d;

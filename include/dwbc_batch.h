@@ -79,7 +79,10 @@ enum dwbc_field {
     /* velocity-dependent outputs of UpdateKinematics: need a qdot in dwbc_batch_set_state */
     DWBC_B = 54,          /* (n)      B_ = C qdot + g (RNEA)    (src/dwbc.cpp:343-344) */
     DWBC_LINK_V = 55,     /* (48, 3)  link_[i].v                (src/link.cpp:87) */
-    DWBC_LINK_W = 56      /* (48, 3)  link_[i].w                (src/link.cpp:88) */
+    DWBC_LINK_W = 56,     /* (48, 3)  link_[i].w                (src/link.cpp:88) */
+    DWBC_CONTACT_POS = 57,/* (2, 3)   cc_[i].xc_pos of the active contacts (src/contact_constraint.cpp:53) */
+    DWBC_CONTACT_ROT = 58,/* (2, 9)   cc_[i].rotm */
+    DWBC_ZMP = 59         /* (3, 3)   getZMP(getContactForce(tau_total)) then cc_[i].zmp_pos (src/dwbc.cpp:898-939) */
 };
 
 const char *dwbc_last_error(void);

@@ -623,6 +623,9 @@ size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
         case DWBC_COM: return B * 3 * 8;
         case DWBC_COM_INERTIA: return B * 9 * 8;
         case DWBC_B: return B * n * 8;
+        case DWBC_CONTACT_POS: return B * kMaxActiveContacts * 3 * 8;
+        case DWBC_CONTACT_ROT: return B * kMaxActiveContacts * 9 * 8;
+        case DWBC_ZMP: return B * (3 + kMaxActiveContacts * 3) * 8;
         case DWBC_LINK_V: case DWBC_LINK_W: return B * kMaxBodies * 3 * 8;
         default: return 0;
     }
@@ -679,6 +682,9 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
         case DWBC_COM: off = dl.com; len = 3; break;
         case DWBC_COM_INERTIA: off = dl.com_inertia; len = 9; break;
         case DWBC_B: off = dl.B; len = n; break;
+        case DWBC_CONTACT_POS: off = dl.contact_pos; len = kMaxActiveContacts * 3; break;
+        case DWBC_CONTACT_ROT: off = dl.contact_rot; len = kMaxActiveContacts * 9; break;
+        case DWBC_ZMP: off = dl.zmp; len = 3 + kMaxActiveContacts * 3; break;
         case DWBC_LINK_V: off = dl.link_v; len = kMaxBodies * 3; break;
         case DWBC_LINK_W: off = dl.link_w; len = kMaxBodies * 3; break;
         case DWBC_P_C: off = dl.P_C; len = 12; break;

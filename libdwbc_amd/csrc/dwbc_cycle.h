@@ -461,6 +461,30 @@ DWBC_DEV void dump_centroidal(Thr th, const double *A, int lda, const double *R0
     }
 }
 
+// RobotData::getZMP(getContactForce(tau_total)) (reference src/dwbc.cpp:898-939) + cc_[i].xc_pos / rotm / zmp_pos of the
+// active contacts, into the dump record.  The reference indexes the packed wrench by REGISTRATION index (i * 6), which is only
+// consistent when the active contacts are the first registered ones; the active order is used here.
+DWBC_DEV void dump_contacts_zmp(Thr th, const double *Pc, const double *Rc, const double *wr, int nc, double *dump, const DumpLayout &dl) {
+    if (th.tid != 0) return;
+    double tot = 0.0, z[3] = {0, 0, 0};
+    for (int a = 0; a < nc; a++) tot += wr[6 * a + 2];
+    for (int a = 0; a < kMaxActiveContacts; a++) {
+        double zp[3] = {0, 0, 0};
+        if (a < nc) {
+            const double fz = wr[6 * a + 2];
+            zp[0] = Pc[a * 3]; zp[1] = Pc[a * 3 + 1]; zp[2] = Pc[a * 3 + 2];
+            if (!(fz > -1.0e-3)) { zp[0] += -wr[6 * a + 4] / fz; zp[1] += wr[6 * a + 3] / fz; }
+            for (int x = 0; x < 3; x++) z[x] += zp[x] * fz / tot;
+        }
+        for (int x = 0; x < 3; x++) {
+            dump[dl.zmp + 3 + a * 3 + x] = zp[x];
+            dump[dl.contact_pos + a * 3 + x] = a < nc ? Pc[a * 3 + x] : 0.0;
+        }
+        for (int x = 0; x < 9; x++) dump[dl.contact_rot + a * 9 + x] = a < nc ? Rc[a * 9 + x] : 0.0;
+    }
+    for (int x = 0; x < 3; x++) dump[dl.zmp + x] = z[x];
+}
+
 // Jacobian of the synthetic "COM" link, jac_ = jac_com_ = SI_body^-1 CMM_ (reference src/dwbc.cpp:318-353), 6 x N row-major
 // [linear; angular], followed by com_pos (3).  Same arithmetic as dump_centroidal, kept in LDS for COM task levels.
 template <int N, int NT>

@@ -724,6 +724,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         wr[i] = acc;  // getContactForce(tau_total), wbd.cpp:268-271
     }
+    if (dump) { DWBC_SYNC(); dump_contacts_zmp(th, L + S::Pc, L + S::Rc, wr, nc, dump, dl); }
     if (th.tid == 0) {
         io.status[inst] = (st_contact && st_task && st_redis) ? 1 : 0;
         if (diag) {

@@ -1061,6 +1061,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             }
             wr[i] = acc;  // getContactForce(tau_total) on the full-model J_C_INV_T (dwbc.cpp:3104) and P_C = J̄^T G
         }
+        if (dump) { DWBC_SYNC(); dump_contacts_zmp(th, L + S::Pc, L + S::Rc, wr, nc, dump, dl); }
         if (th.tid == 0) {
             io.status[inst] = (st_contact && st_task && st_redis) ? 1 : 0;
             if (diag) {

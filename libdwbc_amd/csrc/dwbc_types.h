@@ -76,7 +76,7 @@ enum DiagField {
 struct DumpLayout {
     int N, M;
     int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
-    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, B, link_v, link_w, stamps, total;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, B, link_v, link_w, contact_pos, contact_rot, zmp, stamps, total;
     __host__ __device__ static DumpLayout make(int n) {
         DumpLayout d;
         d.N = n;
@@ -112,6 +112,9 @@ struct DumpLayout {
         d.B = o; o += n;                // B_ (dwbc.cpp:343-344), needs qdot
         d.link_v = o; o += kMaxBodies * 3;  // link_[i].v (link.cpp:87), needs qdot
         d.link_w = o; o += kMaxBodies * 3;  // link_[i].w (link.cpp:88)
+        d.contact_pos = o; o += kMaxActiveContacts * 3;  // cc_[i].xc_pos of the active contacts (contact_constraint.cpp:53)
+        d.contact_rot = o; o += kMaxActiveContacts * 9;  // cc_[i].rotm
+        d.zmp = o; o += 3 + kMaxActiveContacts * 3;      // getZMP(getContactForce(tau_total)), then cc_[i].zmp_pos (dwbc.cpp:898-939)
         d.stamps = o; o += 64;  // fine-grained stage stamps (diagnostic build only)
         d.total = o;
         return d;

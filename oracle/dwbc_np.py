@@ -609,6 +609,22 @@ class Cycle:
     def contact_force(self, tau):
         return self.J_C_INV_T[:, 6:] @ tau - self.P_C
 
+    def get_zmp(self, cf):
+        """RobotData::getZMP (dwbc.cpp:898-939) on the packed wrench of the active contacts -> (zmp, per-contact zmp_pos)"""
+        pts = [self.p[cc["link"]] + self.R[cc["link"]] @ cc["point"] for cc in self.act_contacts]
+        tot = sum(cf[6 * i + 2] for i in range(len(pts)))
+        z = np.zeros(3)
+        zs = []
+        for i, xc in enumerate(pts):
+            fz = cf[6 * i + 2]
+            zp = xc.copy()
+            if not fz > -1.0e-3:
+                zp[0] += -cf[6 * i + 4] / fz
+                zp[1] += cf[6 * i + 3] / fz
+            zs.append(zp)
+            z = z + zp * fz / tot
+        return z, zs
+
     def run(self, q, flags, fstars):
         self.update_kinematics(q)
         self.set_contact(flags)

@@ -64,7 +64,7 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
     std::string n(name);
 #define F(x) if (n == #x) return d.x;
     F(A) F(A_inv) F(J_C) F(Lambda_c) F(J_C_INV_T) F(A_inv_N_C) F(W_inv) F(NwJw) F(Vb) F(G) F(P_C) F(link_R) F(link_p)
-    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com) F(B) F(link_v) F(link_w)
+    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com) F(B) F(link_v) F(link_w) F(contact_pos) F(contact_rot) F(zmp)
 #undef F
     return -1;
 }

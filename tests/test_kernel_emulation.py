@@ -153,3 +153,26 @@ def test_emulated_kernel_custom_task_level():
     r = e.run(q, fl, fs, custom_J=Jpad)
     assert (r["status"] == st).all() and st.all()
     assert np.abs(tau[:, 1]).max() > 1.0 and np.abs(r["tau"] - tau).max() < 1e-6
+
+
+def test_emulated_zmp_and_contact_frames():
+    """getZMP(getContactForce(tau_total)) and cc_[i].xc_pos / rotm (reference src/dwbc.cpp:898-939) from the dump record"""
+    from oracle.dwbc_np import Cycle
+
+    B = 4
+    q, fl, fs = cases.synth_batch(B, seed=61, yaw=True)
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, dump=True)
+    z = e.dump_field(r["dump"], "zmp", (3, 3))
+    cp = e.dump_field(r["dump"], "contact_pos", (2, 3))
+    for b in range(B):
+        c = Cycle(cases.tocabi_model())
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.add_task(0, 0, 0)
+        c.add_task(1, 6, 15)
+        c.set_torque_limit(cases.TAU_LIM)
+        tau = c.run(q[b], [1, 1], [fs[b, :6], fs[b, 6:]])
+        zmp, zs = c.get_zmp(c.contact_force(tau))
+        assert np.abs(z[b, 0] - zmp).max() < 1e-7 and np.abs(z[b, 1] - zs[0]).max() < 1e-7 and np.abs(z[b, 2] - zs[1]).max() < 1e-7
+        assert np.abs(cp[b, 0] - (c.p[6] + c.R[6] @ np.array(cases.FOOT_POINT))).max() < 1e-12
