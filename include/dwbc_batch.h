@@ -143,6 +143,10 @@ int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags);
 /* SetTaskSpace(level, f*) include/dwbc.h:333 : fstar is B x task_dof(level) */
 int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar);
 
+/* CopyKinematicsData(target) include/dwbc.h:375, src/dwbc.cpp:1711-1762: state, contact flags, task spaces with their f*, torque
+ * limit and control time of `src` into `dst` (same model and batch size); the hand-off the reference uses between threads */
+int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src);
+
 /* zero-copy: use a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr) for an input or output field */
 int dwbc_batch_bind_device(dwbc_batch *b, int field, void *device_ptr);
 int dwbc_batch_set_stream(dwbc_batch *b, void *hip_stream);

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("dwbc_batch_set_state", _i, [_vp, _vp, _vp, _vp]),
     ("dwbc_batch_set_contact", _i, [_vp, _vp]),
     ("dwbc_batch_set_fstar", _i, [_vp, _i, _vp]),
+    ("dwbc_batch_copy_kinematics", _i, [_vp, _vp]),
     ("dwbc_batch_bind_device", _i, [_vp, _i, _vp]),
     ("dwbc_batch_set_stream", _i, [_vp, _vp]),
     ("dwbc_batch_enable_dump", _i, [_vp, _i]),

@@ -177,6 +177,11 @@ class Batch:
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, np.float64), (self.B,)))
         _check(self._L.dwbc_batch_set_control_time(self._h, t.ctypes.data))
 
+    def copy_kinematics_to(self, target):
+        """RobotData::CopyKinematicsData(target) (reference include/dwbc.h:375)"""
+        _check(self._L.dwbc_batch_copy_kinematics(target._h, self._h))
+        target.n_contacts = self.n_contacts
+
     def set_contact(self, flags):
         f = np.ascontiguousarray(flags, np.uint8)
         assert f.shape == (self.B, self.n_contacts), f.shape

@@ -569,6 +569,56 @@ int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
     return launch(b, reduced);
 }
 
+int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src) {
+    // RobotData::CopyKinematicsData (reference src/dwbc.cpp:1711-1762): state, contacts (with their flags), task spaces (with
+    // their f*), torque limit and control time go to the target object, which then runs its own Calc* sequence.  Everything
+    // derived (A_, A_inv_, link_, G_, CMM_, B_) is recomputed by the fused kernel from the copied state.
+    if (!dst || !src) return fail("NULL batch");
+    if (dst == src) return 1;
+    if (dst->B != src->B || dst->n != src->n || dst->su.nb != src->su.nb) return fail("CopyKinematicsData: batch size / model mismatch");
+    HIP_OK(hipSetDevice(dst->device));
+    dst->su = src->su;
+    auto clone = [&](double *&dd, bool &own, const double *sd, size_t count, std::vector<double> &hd, const std::vector<double> &hs, bool &dirty,
+                     bool src_own) -> int {
+        hd = hs;
+        if (count == 0) return 1;
+        if (!src_own || hs.size() != count) {  // the source reads a caller-owned device buffer: device-to-device copy
+            if (!own || !dd) { HIP_OK(hipMalloc(&dd, count * sizeof(double))); own = true; }
+            HIP_OK(hipMemcpy(dd, sd, count * sizeof(double), hipMemcpyDeviceToDevice));
+            hd.assign(count, 0.0);
+            HIP_OK(hipMemcpy(hd.data(), sd, count * sizeof(double), hipMemcpyDeviceToHost));
+            dirty = false;
+        } else {
+            dirty = true;
+        }
+        return 1;
+    };
+    if (!clone(dst->d_q, dst->own_q, src->d_q, (size_t)src->B * (src->n + 1), dst->h_q, src->h_q, dst->dirty_q, src->own_q)) return 0;
+    // f* and flags: (re)allocated by upload_inputs when the layout changed
+    dst->h_fstar = src->h_fstar;
+    dst->h_flags = src->h_flags;
+    if (dst->own_fstar && dst->d_fstar) { hipFree(dst->d_fstar); dst->d_fstar = nullptr; }
+    if (dst->own_flags && dst->d_flags) { hipFree(dst->d_flags); dst->d_flags = nullptr; }
+    dst->own_fstar = dst->own_flags = true;
+    dst->fstar_alloc = dst->flags_alloc = 0;
+    dst->dirty_fstar = dst->dirty_flags = true;
+    if (!src->own_fstar && src->d_fstar && src->su.fstar_total > 0) {
+        dst->h_fstar.assign((size_t)src->B * src->su.fstar_total, 0.0);
+        HIP_OK(hipMemcpy(dst->h_fstar.data(), src->d_fstar, dst->h_fstar.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (!src->own_flags && src->d_flags && src->su.n_contacts > 0) {
+        dst->h_flags.assign((size_t)src->B * src->su.n_contacts, 0);
+        HIP_OK(hipMemcpy(dst->h_flags.data(), src->d_flags, dst->h_flags.size(), hipMemcpyDeviceToHost));
+    }
+    dst->h_qdot = src->h_qdot; dst->dirty_qdot = !src->h_qdot.empty();
+    dst->h_ctime = src->h_ctime; dst->dirty_ctime = !src->h_ctime.empty();
+    dst->h_traj = src->h_traj; dst->dirty_traj = !src->h_traj.empty();
+    if (dst->d_traj) { hipFree(dst->d_traj); dst->d_traj = nullptr; }
+    dst->h_custom = src->h_custom; dst->dirty_custom = !src->h_custom.empty();
+    if (dst->d_custom) { hipFree(dst->d_custom); dst->d_custom = nullptr; }
+    return 1;
+}
+
 int dwbc_batch_sync(dwbc_batch *b) {
     HIP_OK(hipSetDevice(b->device));
     HIP_OK(hipStreamSynchronize(b->stream));

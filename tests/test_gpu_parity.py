@@ -313,3 +313,30 @@ def test_gpu_custom_task_level_vs_oracle():
     assert np.abs(wbc.get("tau") - tau).max() < 1e-6
     with pytest.raises(RuntimeError):
         wbc.solve(reduced=True)
+
+
+@pytest.mark.gpu
+def test_gpu_copy_kinematics_data():
+    """RobotData::CopyKinematicsData (reference src/dwbc.cpp:1711-1762, the cross-thread hand-off of tests/test_thread.cpp):
+    the target batch reproduces the source's torques from the copied state / contacts / task spaces"""
+    import libdwbc_amd as D
+
+    B = 32
+    q, fl, fs = cases.synth_batch(B, seed=88, contact_mode="mixed")
+    model = D.Model.from_urdf(cases.URDF)
+    src = D.Batch(model, B, device=0)
+    for c in cases.CONTACTS_2:
+        src.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    src.add_task(0, D.TASK_LINK_6D, 0)
+    src.add_task(1, D.TASK_LINK_ROTATION, 15)
+    src.set_torque_limit(np.array(cases.TAU_LIM))
+    src.set_state(q)
+    src.set_contact(fl)
+    src.set_fstar_all(fs)
+    src.solve()
+    dst = D.Batch(model, B, device=0)
+    src.copy_kinematics_to(dst)
+    dst.solve()
+    assert (dst.get("status") == src.get("status")).all()
+    assert np.abs(dst.get("tau") - src.get("tau")).max() == 0.0
+    assert np.abs(dst.get("wrench") - src.get("wrench")).max() == 0.0
