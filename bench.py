@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 
 F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit (SURVEY 8d / BASELINE.md 3)
 PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
+PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak (public spec), for --dtype f32 runs
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
 
 
@@ -49,6 +50,7 @@ def main():
     ap.add_argument("--workload", default="ds2", choices=["ds2", "ss3", "mixed", "reduced"],
                     help="ds2 = BASELINE configs[1] (the metric's config, default); ss3 / mixed / reduced = configs[2] / [3] / [4] "
                          "(parity-test cases; measured for DESIGN.md only)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="arithmetic type of the kernels (f32: measured for DESIGN.md only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -75,7 +77,7 @@ def main():
     B = args.batch
 
     model = D.Model.from_urdf(cases.URDF)
-    wbc = D.Batch(model, B, device=local_rank)
+    wbc = D.Batch(model, B, device=local_rank, dtype=args.dtype)
     for c in cases.CONTACTS_2:
         wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
     wbc.add_task(0, D.TASK_LINK_6D, 0)
@@ -161,7 +163,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": workload_name,
@@ -173,9 +175,9 @@ def main():
             "roofline": {
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": PEAK_FP64_TFLOPS,
+                "peak": PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_TFLOPS,
+                "frac": achieved / (PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS),
                 "traffic": hbm_traffic_per_launch(wbc.kernel_name(), B),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_final_pmc_summary.json)",
                 "kernel": wbc.kernel_name(),

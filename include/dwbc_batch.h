@@ -32,7 +32,9 @@ enum {
     DWBC_TASK_LINK_POSITION, DWBC_TASK_LINK_POSITION_COM_FRAME, DWBC_TASK_LINK_POSITION_CUSTOM_FRAME,
     DWBC_TASK_LINK_ROTATION, DWBC_TASK_LINK_ROTATION_CUSTOM_FRAME
 };
-enum { DWBC_F64 = 0 };
+/* arithmetic type of the kernels.  DWBC_F32 runs the same kernel source in single precision on float shadows of the
+ * buffers; every buffer at this boundary (host arrays, bound device buffers) stays double.  Accuracy envelope: DESIGN.md §8 */
+enum { DWBC_F64 = 0, DWBC_F32 = 1 };
 /* DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
  * ReducedCalcGravCompensation, ReducedCalcTaskSpace, ReducedCalcTaskControlTorque, ReducedCalcContactRedistribute --
  * reference include/dwbc.h:411-416, tests/sp_test/redu_dyn_test.cpp:263-298) instead of the full-model sequence */

@@ -94,13 +94,13 @@ class Model:
 
 
 class Batch:
-    def __init__(self, model, B, device=0):
+    def __init__(self, model, B, device=0, dtype="f64"):
         self._L = _lib.load()
         self.model = model
         self.B = int(B)
         self.n = model.ndof
         self.m = model.ndof - 6
-        self._h = self._L.dwbc_batch_create(model._h, self.B, int(device), 0)
+        self._h = self._L.dwbc_batch_create(model._h, self.B, int(device), {"f64": 0, "f32": 1}[dtype])
         if not self._h:
             raise DwbcError(_lib.last_error())
         self.n_contacts = 0

@@ -9,56 +9,22 @@
 #include <vector>
 
 #include "../../include/dwbc_batch.h"
-#include "dwbc_reduced.h"
+#include "dwbc_kernels.h"
 #include "dwbc_model.h"
 #include "dwbc_setup.h"
 
 using namespace dwbc;
 
-// ------------------------------------------------------------------------------------------------
-// kernel: one workgroup (one 64-lane wavefront) per robot instance, everything between q and tau in LDS
-// ------------------------------------------------------------------------------------------------
-template <int N, int NB, int NT>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const BatchIO io) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int inst = blockIdx.x;
-    if (inst >= io.B) return;
-    Thr th{(int)threadIdx.x};
-    int *iL = reinterpret_cast<int *>(lds + Lds<N, NB>::total);
-    cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
-}
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, const void **fn, const void **fn_wide, int *lds_bytes);
 
-// register-resident version (dwbc_cycle2.h): the default.  Two builds of the same body:
-//   _v2   amdgpu_waves_per_eu(2): VGPR + AGPR <= 256, so a fifth workgroup of a CU (the LDS map allows 5 at <= 31 KB) can
-//         share a SIMD -- the throughput build for batches larger than 4 instances per CU
-//   _v2w  no register cap (one wave per SIMD): ~7 % shorter single-instance latency -- used while B <= 4 x CUs
-#define DWBC_V2_BODY                                                                     \
-    static_assert(NT == 64, "one wavefront per instance");                               \
-    extern __shared__ __attribute__((aligned(16))) double lds[];                         \
-    const int inst = blockIdx.x;                                                         \
-    if (inst >= io.B) return;                                                            \
-    Thr th{(int)threadIdx.x};                                                            \
-    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
-    cycle_instance_v2<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
-template <int N, int NB, int NLV, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
-    DWBC_V2_BODY
+// DWBC_F32 batches keep the double buffers of the boundary and run the fp32 kernels on float shadows (dwbc_kernels_f32.hip)
+__global__ void dwbc_cvt_d2f(const double *__restrict__ in, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
 }
-template <int N, int NB, int NLV, int NT>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
-    DWBC_V2_BODY
-}
-
-// reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
-template <int N, int NB, int NLV, int NT>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
-    static_assert(NT == 64, "one wavefront per instance");
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int inst = blockIdx.x;
-    if (inst >= io.B) return;
-    Thr th{(int)threadIdx.x};
-    int *iL = reinterpret_cast<int *>(lds + LdsR<N, NB, NLV>::rtotal);
-    cycle_instance_reduced<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+__global__ void dwbc_cvt_f2d(const float *__restrict__ in, double *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
 }
 
 namespace {
@@ -73,45 +39,6 @@ int fail(const std::string &s) {
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-constexpr int kNT = 64;
-
-struct KernelEntry {
-    int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
-    void (*fn)(const Setup, const BatchIO);
-    int lds_bytes;
-    void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
-};
-// instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
-// index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
-#ifdef DWBC_EXPERIMENT
-// A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
-const KernelEntry kKernels[] = {
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
-};
-const KernelEntry kKernelsReduced[] = {
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
-};
-#else
-const KernelEntry kKernels[] = {
-    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT>},
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
-    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT>},
-    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT>},
-};
-const KernelEntry kKernelsReduced[] = {
-    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr},
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
-    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr},
-    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr},
-};
-#endif
-#ifdef DWBC_EXPERIMENT
-const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr}};
-#else
-const KernelEntry kKernelsV1[] = {
-    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
-};
-#endif
 }  // namespace
 
 struct dwbc_model {
@@ -140,6 +67,12 @@ struct dwbc_batch {
     bool own_q = false, own_fstar = false, own_flags = false, own_tau = false, own_wrench = false, own_status = false;
     int fstar_alloc = 0, flags_alloc = 0;
     bool dump_on = false;
+    int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
+    float *f_q = nullptr, *f_fstar = nullptr, *f_tau = nullptr, *f_wrench = nullptr, *f_body = nullptr, *f_qdot = nullptr, *f_traj = nullptr,
+          *f_ctime = nullptr, *f_custom = nullptr;
+    size_t f_fstar_n = 0, f_traj_n = 0, f_custom_n = 0;
+    const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
+    int f32_lds = 0, f32_key = -1;
     bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
     // host mirrors of the inputs
     std::vector<double> h_q, h_fstar;
@@ -215,7 +148,7 @@ int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, do
 
 dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype) {
     if (!m || B < 1) { g_err = "bad arguments"; return nullptr; }
-    if (dtype != DWBC_F64) { g_err = "only DWBC_F64 is implemented"; return nullptr; }
+    if (dtype != DWBC_F64 && dtype != DWBC_F32) { g_err = "dtype must be DWBC_F64 or DWBC_F32"; return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return nullptr; }
@@ -230,6 +163,7 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     b->model = m;
     b->B = B;
     b->device = device;
+    b->dtype = dtype;
     b->n = m->m.ndof;
     b->m = b->n - 6;
     b->kern = ke;
@@ -271,6 +205,8 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     hipSetDevice(b->device);
     if (b->own_q) hipFree(b->d_q);
     if (b->d_qdot) hipFree(b->d_qdot);
+    for (float *p : {b->f_q, b->f_fstar, b->f_tau, b->f_wrench, b->f_body, b->f_qdot, b->f_traj, b->f_ctime, b->f_custom})
+        if (p) hipFree(p);
     if (b->d_traj) hipFree(b->d_traj);
     if (b->d_ctime) hipFree(b->d_ctime);
     if (b->d_custom) hipFree(b->d_custom);
@@ -500,23 +436,96 @@ static int upload_inputs(dwbc_batch *b) {
 }
 
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
-    if (reduced) {
-        for (const auto &k : kKernelsReduced)
-            if (k.n == b->n && k.nb == b->su.nb && k.nlv == b->su.n_levels) return &k;
-        return nullptr;
-    }
     const char *kv = getenv("DWBC_KERNEL");
-    if (kv && std::string(kv) == "v1") {
-        for (const auto &k : kKernelsV1)
-            if (k.n == b->n && k.nb == b->su.nb) return &k;
-        return nullptr;
+    const int which = reduced ? 2 : ((kv && std::string(kv) == "v1") ? 1 : 0);
+    return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which);
+}
+
+// fp32 launch: float shadows of the double boundary buffers, converted on the batch's stream around the kernel
+static int launch_f32(dwbc_batch *b, bool reduced) {
+    const int which = reduced ? 2 : 0;
+    const int key = which * 16 + b->su.n_levels;
+    if (key != b->f32_key) {
+        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds))
+            return fail("no fp32 kernel for this model / number of task levels");
+        HIP_OK(hipFuncSetAttribute(b->f32_fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
+        if (b->f32_fn_wide) HIP_OK(hipFuncSetAttribute(b->f32_fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, b->device));
+        b->n_cu = prop.multiProcessorCount;
+        b->f32_key = key;
     }
-    for (const auto &k : kKernels)
-        if (k.n == b->n && k.nb == b->su.nb && k.nlv == b->su.n_levels) return &k;
-    return nullptr;
+    if (b->dump_on) return fail("the dump record is not available on DWBC_F32 batches");
+    const size_t B = b->B, n = b->n, m = b->m;
+    auto need = [&](float *&p, size_t count, size_t *have) -> int {
+        if (p && (!have || *have == count)) return 1;
+        if (p) hipFree(p);
+        p = nullptr;
+        HIP_OK(hipMalloc(&p, count * sizeof(float)));
+        if (have) *have = count;
+        return 1;
+    };
+    auto d2f = [&](const double *src, float *dst, size_t count) {
+        hipLaunchKernelGGL(dwbc_cvt_d2f, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, src, dst, count);
+    };
+    if (!b->f_body) {
+        std::vector<double> body;
+        b->model->m.body_table(body);
+        if (!need(b->f_body, body.size(), nullptr)) return 0;
+        d2f(b->d_body, b->f_body, body.size());
+    }
+    if (!need(b->f_q, B * (n + 1), nullptr) || !need(b->f_tau, B * 3 * m, nullptr) || !need(b->f_wrench, B * 12, nullptr)) return 0;
+    if (!need(b->f_fstar, B * b->su.fstar_total, &b->f_fstar_n)) return 0;
+    d2f(b->d_q, b->f_q, B * (n + 1));
+    d2f(b->d_fstar, b->f_fstar, B * b->su.fstar_total);
+    struct IoF32 {  // BatchIO of the fp32 namespace: same layout, float pointers
+        int B;
+        const float *q, *qdot;
+        const unsigned char *flags;
+        const float *fstar, *traj, *ctime, *custom_J;
+        float *tau, *wrench;
+        int *status, *diag;
+        float *dump;
+        const float *body;
+        const int *topo;
+    } io{};
+    static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
+    io.B = b->B;
+    io.q = b->f_q;
+    if (b->d_qdot) { if (!need(b->f_qdot, B * n, nullptr)) return 0; d2f(b->d_qdot, b->f_qdot, B * n); io.qdot = b->f_qdot; }
+    if (b->su.n_traj > 0 && b->d_traj) {
+        const size_t c = B * b->su.n_traj * kTrajStride;
+        if (!need(b->f_traj, c, &b->f_traj_n)) return 0;
+        d2f(b->d_traj, b->f_traj, c);
+        io.traj = b->f_traj;
+    }
+    if (b->d_ctime) { if (!need(b->f_ctime, B, nullptr)) return 0; d2f(b->d_ctime, b->f_ctime, B); io.ctime = b->f_ctime; }
+    if (b->su.n_custom > 0 && b->d_custom) {
+        const size_t c = B * b->su.n_custom * kMaxTaskDof * n;
+        if (!need(b->f_custom, c, &b->f_custom_n)) return 0;
+        d2f(b->d_custom, b->f_custom, c);
+        io.custom_J = b->f_custom;
+    }
+    io.flags = b->d_flags;
+    io.fstar = b->f_fstar;
+    io.tau = b->f_tau;
+    io.wrench = b->f_wrench;
+    io.status = b->d_status;
+    io.diag = b->d_diag;
+    io.dump = nullptr;
+    io.body = b->f_body;
+    io.topo = b->d_topo;
+    const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
+    void *args[] = {(void *)&b->su, (void *)&io};
+    HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, b->f32_lds, b->stream));
+    hipLaunchKernelGGL(dwbc_cvt_f2d, dim3((unsigned)((B * 3 * m + 255) / 256)), dim3(256), 0, b->stream, b->f_tau, b->d_tau, B * 3 * m);
+    hipLaunchKernelGGL(dwbc_cvt_f2d, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, b->stream, b->f_wrench, b->d_wrench, B * 12);
+    HIP_OK(hipGetLastError());
+    return 1;
 }
 
 static int launch(dwbc_batch *b, bool reduced = false) {
+    if (b->dtype == DWBC_F32) return launch_f32(b, reduced);
     const KernelEntry *ke = pick_kernel(b, reduced);
     if (!ke) return fail("no kernel for this model / number of task levels");
     if (ke != b->kern) {
@@ -757,9 +766,10 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     static thread_local std::string name;
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
+    const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "";
     if (!ke) return "";
     if (b->last_reduced) {
-        name = "dwbc_cycle_kernel_reduced<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+        name = pre + "dwbc_cycle_kernel_reduced<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
         return name.c_str();
     }
     int n_cu = b->n_cu;
@@ -772,13 +782,14 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     name = v1 ? "dwbc_cycle_kernel<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", 64>"
               : std::string(wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + std::to_string(ke->n) + ", " +
                     std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+    name = pre + name;  // rocprofv3 prints the fp32 instantiations as dwbc_f32::dwbc_cycle_kernel_v2<...>
     return name.c_str();
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     if (threads) *threads = kNT;
-    if (lds) *lds = ke ? ke->lds_bytes : 0;
+    if (lds) *lds = b->dtype == DWBC_F32 && b->f32_lds ? b->f32_lds : (ke ? ke->lds_bytes : 0);
     return 1;
 }
 

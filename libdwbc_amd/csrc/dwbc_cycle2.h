@@ -91,32 +91,32 @@ struct Lds2 {
     static constexpr bool jcm_in_U = NLV * M * T >= 6 * N + 4;
     static constexpr int Jcm = jcm_in_U ? U : ev(total0);
     static constexpr int total = jcm_in_U ? total0 : ev(total0) + 6 * N + 4;
-    static constexpr int total_bytes = total * 8 + 64;
+    static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
 };
 
 // symmetric Gauss-Jordan sweep on a column-per-lane register matrix: on exit s / dg hold the inverse (see
 // spd_inverse_wave in dwbc_cycle.h for the derivation of the single-FMA update).  Returns 0 on a non-positive pivot.
 template <int NN>
-DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), double *colbuf) {
+DWBC_WDEV int sweep_inverse_regs(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
     DWBC_LANE_DECL;
     int ok = 1;
     for (int k = 0; k < NN; k++) {
-        double d = BCAST(dg, k);
-        if (!(d > 0.0)) { ok = 0; d = 1.0; }
-        const double rp = fast_rcp(d);
+        real_t d = BCAST(dg, k);
+        if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
+        const real_t rp = fast_rcp(d);
         // lane k publishes its column; its own slot k gets c_k - 1 (LDS ops of one wave execute in order, so the second
         // store to colbuf[k] needs no barrier; reads of the previous step were consumed by the FMAs that precede these stores)
         LANES {
             if (lane == k) {
 #pragma unroll
                 for (int i = 0; i < NN; i++) colbuf[i] = LV(s)[i];
-                colbuf[k] = d - 1.0;
+                colbuf[k] = d - real_t(1.0);
             }
         }
         DWBC_SYNC();
         LANES {
-            const double cj = colbuf[lane < NN ? lane : 0];
-            const double h = (lane == k) ? (1.0 - rp) : cj * rp;
+            const real_t cj = colbuf[lane < NN ? lane : 0];
+            const real_t h = (lane == k) ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll
             for (int i = 0; i < NN; i++) LV(s)[i] -= colbuf[i] * h;
             LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
@@ -138,40 +138,40 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(double, s, NN), PL_REF(double, dg), dou
 // s[kr], s[8+kr], ... by the uniform kb.  The "- delta_ik" of the multiplier is absorbed by storing the diagonal
 // shifted by one (s[j][j] = S[j][j] - 1), so that readlane(s[k], k) is already c_k - 1; the true diagonal lives in dg.
 template <int NN>
-DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg), int npiv = NN) {
+DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int npiv = NN) {
     DWBC_LANE_DECL;
     static_assert(NN <= 40, "five candidate registers per kr");
     int ok = 1;
     LANES {
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - 1.0 : LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - real_t(1.0) : LV(s)[i];
     }
     for (int kb = 0; kb < (NN + 7) / 8; kb++) {
 #pragma unroll
         for (int kr = 0; kr < 8; kr++) {
             const int k = 8 * kb + kr;
             if (k < NN && k < npiv) {
-                double d = BCAST(dg, k);
-                if (!(d > 0.0)) { ok = 0; d = 1.0; }
-                const double rp = fast_rcp(d);
+                real_t d = BCAST(dg, k);
+                if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
+                const real_t rp = fast_rcp(d);
 #ifdef DWBC_HOST_EMU
-                double snap_[NN];
+                real_t snap_[NN];
                 for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[k][i_];
 #endif
                 LANES {
                     // own element k = 8*kb + kr: static candidates, uniform selector
-                    double cj = LV(s)[kr];
+                    real_t cj = LV(s)[kr];
                     if (8 + kr < NN) cj = (kb == 1) ? LV(s)[(8 + kr) < NN ? 8 + kr : 0] : cj;
                     if (16 + kr < NN) cj = (kb == 2) ? LV(s)[(16 + kr) < NN ? 16 + kr : 0] : cj;
                     if (24 + kr < NN) cj = (kb == 3) ? LV(s)[(24 + kr) < NN ? 24 + kr : 0] : cj;
                     if (32 + kr < NN) cj = (kb == 4) ? LV(s)[(32 + kr) < NN ? 32 + kr : 0] : cj;
-                    const double h = (lane == k) ? (1.0 - rp) : cj * rp;
+                    const real_t h = (lane == k) ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll
                     for (int i = 0; i < NN; i++) {
 #ifdef DWBC_HOST_EMU
-                        const double ci = snap_[i];
+                        const real_t ci = snap_[i];
 #else
-                        const double ci = readlane_f64(LV(s)[i], k);
+                        const real_t ci = readlane_f64(LV(s)[i], k);
 #endif
                         LV(s)[i] -= ci * h;
                     }
@@ -196,24 +196,24 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(double, s, NN), PL_REF(double, dg), int n
 // cross-lane traffic -- and lane c < n then solves L L^T x = e_c for column c of the inverse with 30 FMAs.  About half
 // the fp64 instructions of the 12-wide register sweep, which matters because one wave issues an fp64 VALU op only
 // every ~12 cycles (tools/ubench).
-DWBC_WDEV int spd_inverse_chol6(const double *Ain, int lda, int n, double *Out, int ldo) {
+DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, int ldo) {
     DWBC_LANE_DECL;
-    double Lc[6][6], ri[6];
+    real_t Lc[6][6], ri[6];
     int ok = 1;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) Lc[i][j] = (i < n) ? Ain[i * lda + j] : (i == j ? 1.0 : 0.0);
+        for (int j = 0; j <= i; j++) Lc[i][j] = (i < n) ? Ain[i * lda + j] : (i == j ? real_t(1.0) : real_t(0.0));
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        double d = Lc[j][j];
+        real_t d = Lc[j][j];
 #pragma unroll
         for (int k = 0; k < j; k++) d -= Lc[j][k] * Lc[j][k];
-        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
         ri[j] = fast_rsqrt(d);
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
-            double v = Lc[i][j];
+            real_t v = Lc[i][j];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= Lc[i][k] * Lc[j][k];
             Lc[i][j] = v * ri[j];
@@ -221,17 +221,17 @@ DWBC_WDEV int spd_inverse_chol6(const double *Ain, int lda, int n, double *Out, 
     }
     DWBC_SYNC();  // Out may alias Ain
     LANES {
-        double y[6];
+        real_t y[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            double v = (lane == i) ? 1.0 : 0.0;
+            real_t v = (lane == i) ? real_t(1.0) : real_t(0.0);
 #pragma unroll
             for (int k = 0; k < i; k++) v -= Lc[i][k] * y[k];
             y[i] = v * ri[i];
         }
 #pragma unroll
         for (int i = 5; i >= 0; i--) {
-            double v = y[i];
+            real_t v = y[i];
 #pragma unroll
             for (int k = i + 1; k < 6; k++) v -= Lc[k][i] * y[k];
             y[i] = v * ri[i];
@@ -246,18 +246,18 @@ DWBC_WDEV int spd_inverse_chol6(const double *Ain, int lda, int n, double *Out, 
     return ok;
 }
 
-DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, int ldo, double *colbuf) {
+DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *colbuf) {
     DWBC_LANE_DECL;
     (void)colbuf;
     DWBC_SYNC();
     if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo);
-    PLA(double, s, 12);
-    PL(double, dg);
+    PLA(real_t, s, 12);
+    PL(real_t, dg);
     LANES {
         const int col = lane < n ? lane : 0;
 #pragma unroll
-        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] : 0.0;
-        LV(dg) = (lane < n) ? Ain[col * lda + col] : 1.0;
+        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] : real_t(0.0);
+        LV(dg) = (lane < n) ? Ain[col * lda + col] : real_t(1.0);
     }
     const int ok = sweep_inverse_rl<12>(s, dg, n);
     DWBC_SYNC();
@@ -273,43 +273,43 @@ DWBC_DEVN int spd_inverse_small(const double *Ain, int lda, int n, double *Out, 
 }
 
 template <int N, int NB, int NLV, int NT>
-DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, double *L, int *iL) {
+DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
     using S = Lds2<N, NB, NLV>;
     constexpr int M = S::M, C = S::C, T = S::T;
     DWBC_LANE_DECL;
     (void)iL;
     const int nb = su.nb;
-    const double *body = io.body;
+    const real_t *body = io.body;
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
-    const double *qin = io.q + (size_t)inst * (N + 1);
+    const real_t *qin = io.q + (size_t)inst * (N + 1);
     const DumpLayout dl = DumpLayout::make(N);
-    double *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
+    real_t *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
     DWBC_STAMP_INIT();
 
-    PLA(double, s, N);  // column `lane` of A -> A^-1 -> A^-1 N_c
-    PL(double, dg);     // its diagonal element
+    PLA(real_t, s, N);  // column `lane` of A -> A^-1 -> A^-1 N_c
+    PL(real_t, dg);     // its diagonal element
 
 #include "dwbc_cycle2_stage0.inc"
 
 #include "dwbc_cycle2_stage1.inc"
     // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
-    double *Vb = L + S::c_Vb, *VG = L + S::c_VG;
+    real_t *Vb = L + S::c_Vb, *VG = L + S::c_VG;
     if (k > 0) {
-        const double *Pc = L + S::Pc;
+        const real_t *Pc = L + S::Pc;
         for (int idx = th.tid; idx < M * k; idx += NT) {
             const int r = idx / 6, a = idx - r * 6;  // k == 6 here
             const int ci = 1 + a / 6, e = a % 6;
-            double f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-            if (e < 3) f2[e] = 1.0; else m2[e - 3] = 1.0;
-            const double d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
-            const double m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
-            const double m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
-            const double m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
+            real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+            if (e < 3) f2[e] = real_t(1.0); else m2[e - 3] = real_t(1.0);
+            const real_t d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
+            const real_t m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
+            const real_t m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
+            const real_t m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
             const int col = 6 + r;
-            const double *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
+            const real_t *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
             const int o1 = 6 * ci;
-            double acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
+            real_t acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
             acc += m1x * Jc[3] + m1y * Jc[4] + m1z * Jc[5];
             acc += f2[0] * Jc[o1 + 0] + f2[1] * Jc[o1 + 1] + f2[2] * Jc[o1 + 2];
             acc += m2[0] * Jc[o1 + 3] + m2[1] * Jc[o1 + 4] + m2[2] * Jc[o1 + 5];
@@ -319,7 +319,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_FSTAMP(7);  // Vb
         for (int idx = th.tid; idx < k * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
-            double acc = 0.0;
+            real_t acc = real_t(0.0);
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
             L[S::c_s2 + idx] = acc;
@@ -329,7 +329,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // JV = J̄[0:k,6:] Vb:  NwJw = VG JV^T (JV G^-1 JV^T)^-1  (same matrix: both satisfy J̄1 NwJw = I on span(Vb))
         DWBC_FSTAMP(8);
         {
-            double *JV = L + S::c_s2, *Gi = L + S::c_s2 + 36, *Bm = L + S::c_s2 + 72, *Sm6 = L + S::c_s2 + 108;  // 4 x (6x6) in C*C = 144
+            real_t *JV = L + S::c_s2, *Gi = L + S::c_s2 + 36, *Bm = L + S::c_s2 + 72, *Sm6 = L + S::c_s2 + 108;  // 4 x (6x6) in C*C = 144
             mm_tn<NT>(th, Gi, k, Vb, k, Vb, k, k, M, k);                      // G
             DWBC_SYNC();
             spd_inverse_small(Gi, k, k, Gi, k, L + S::c_s1);                   // G^-1
@@ -348,7 +348,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
         for (int idx = th.tid; idx < cd * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
-            double acc = 0.0;
+            real_t acc = real_t(0.0);
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
             L[S::c_s1 + idx] = acc;
@@ -357,8 +357,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < cd * k; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
-            const double *R = L + S::Rc + a * 9;
-            const double *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
+            const real_t *R = L + S::Rc + a * 9;
+            const real_t *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
             L[S::FNl + idx] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[k] + R[2 * 3 + x] * src[2 * k];
         }
         DWBC_SYNC();
@@ -368,19 +368,19 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
-        double *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
+        real_t *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
         const unsigned long long tm = su.t_dofmask[lv];
         DWBC_SYNC();
-        for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = 0.0;
+        for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = real_t(0.0);
         DWBC_SYNC();
         int row = 0;
         if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
-            const double *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
+            const real_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
             for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = cj[idx];
         }
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
-            double pl[3] = {0, 0, 0};
+            real_t pl[3] = {0, 0, 0};
             if ((mode == TASK_LINK_6D_COM_FRAME || mode == TASK_LINK_POSITION_COM_FRAME) && link < nb)
                 for (int a = 0; a < 3; a++) pl[a] = body[link * kBodyStride + BF_COM + a];
             else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
@@ -389,8 +389,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
                 com_task_rows<N, NT>(th, L + S::Jcm, Jtt, row, rsel, T);
             } else {
-                const double *R = L + S::Rw + link * 9;
-                double P[3];
+                const real_t *R = L + S::Rw + link * 9;
+                real_t P[3];
                 for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
                 point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
             }
@@ -399,9 +399,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // T1[:, lane] = J_t * (lane's column of A^-1 N_c): all task rows in one pass, zero columns of J_t skipped
         LANES {
-            double tc_[T];
+            real_t tc_[T];
 #pragma unroll
-            for (int r = 0; r < T; r++) tc_[r] = 0.0;
+            for (int r = 0; r < T; r++) tc_[r] = real_t(0.0);
 #pragma unroll
             for (int ib = 0; ib < N; ib += 3) {
                 if ((tm >> ib) & 7) {
@@ -421,7 +421,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (lv == 0) DWBC_FSTAMP(14);  // level 0: Jt + T1
         for (int idx = th.tid; idx < t * t; idx += NT) {  // J_t A^-1 N_c J_t^T
             const int i = idx / t, j = idx - i * t;
-            double acc = 0.0;
+            real_t acc = real_t(0.0);
 #pragma unroll
             for (int c = 0; c < N; c++)
                 if ((tm >> c) & 1) acc += T1[i * N + c] * Jtt[c * T + j];
@@ -443,8 +443,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
     DWBC_FSTAMP(17);  // all task levels
     // ---- W^+ = (W + alpha P)^-1 - P / alpha, column c of W held by lane c (moved down from lane 6 + c)
-    PLA(double, w, M);
-    PL(double, dw);
+    PLA(real_t, w, M);
+    PL(real_t, dw);
     LANES {
         const int src = lane < M ? lane + 6 : lane;
 #pragma unroll
@@ -455,20 +455,20 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (lane < M) L[S::c_col + lane] = LV(dw);
     }
     DWBC_SYNC();
-    double alpha = 0.0;
+    real_t alpha = real_t(0.0);
     for (int i = 0; i < M; i++) alpha += L[S::c_col + i];
     alpha /= M;
-    const double ialpha = alpha != 0.0 ? 1.0 / alpha : 0.0;
+    const real_t ialpha = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
     DWBC_SYNC();
-    PLA(double, vbr, 6);  // row `lane` of Vb
+    PLA(real_t, vbr, 6);  // row `lane` of Vb
     LANES {
 #pragma unroll
-        for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * k + a] : 0.0;
+        for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * k + a] : real_t(0.0);
         if (k > 0) {
-            double dp = 0.0;
+            real_t dp = real_t(0.0);
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                double pij = 0.0;
+                real_t pij = real_t(0.0);
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
                 LV(w)[i] += alpha * pij;
@@ -478,8 +478,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         if (lane >= M) {
 #pragma unroll
-            for (int i = 0; i < M; i++) LV(w)[i] = 0.0;
-            LV(dw) = 1.0;
+            for (int i = 0; i < M; i++) LV(w)[i] = real_t(0.0);
+            LV(dw) = real_t(1.0);
         }
     }
     DWBC_FSTAMP(18);  // W + alpha P assembled
@@ -489,14 +489,14 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (k > 0) {
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                double pij = 0.0;
+                real_t pij = real_t(0.0);
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
                 LV(w)[i] -= ialpha * pij;
             }
         }
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
-        double acc = 0.0;
+        real_t acc = real_t(0.0);
 #pragma unroll
         for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
         if (lane < M) L[S::tg + lane] = acc;
@@ -519,14 +519,14 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     int rankbad = 0;
     for (int lv = 0; lv < su.n_levels; lv++) {
         const int t = su.t_dof[lv];
-        const double *Lt = L + S::c_Lt + lv * T * T;
+        const real_t *Lt = L + S::c_Lt + lv * T * T;
         const FastDiv fdt(t);
-        const double *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
-        double *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
+        const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
+        real_t *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
         DWBC_SYNC();
         for (int idx = th.tid; idx < T * M; idx += NT) {  // Q = Lambda T1[:,6:]  (zero padded to T rows)
             const int i = idx / M, j = idx - i * M;
-            double acc = 0.0;
+            real_t acc = real_t(0.0);
             if (i < t)
                 _Pragma("unroll 8")
                 for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * M + j];
@@ -535,10 +535,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int r = 0; r < T; r++) {
             LANES {
-                double a4[4] = {0.0, 0.0, 0.0, 0.0};
+                real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
                 for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
-                const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
             }
         }
@@ -549,25 +549,25 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
         // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
-        double *Ul = L + S::U + lv * M * T;
-        double *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;
+        real_t *Ul = L + S::U + lv * M * T;
+        real_t *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;
         LANES {
-            double jk[T], qw[T];
+            real_t jk[T], qw[T];
 #pragma unroll
             for (int r = 0; r < T; r++) qw[r] = QW[r * M + (lane < M ? lane : 0)];
 #pragma unroll
             for (int r2 = 0; r2 < T; r2++) {
-                double acc = 0.0;
+                real_t acc = real_t(0.0);
 #pragma unroll
-                for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : 0.0;
+                for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : real_t(0.0);
                 jk[r2] = acc;
                 if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
             }
 #pragma unroll
             for (int r3 = 0; r3 < T; r3++) {
-                double acc = 0.0;
+                real_t acc = real_t(0.0);
 #pragma unroll
-                for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : 0.0;
+                for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : real_t(0.0);
                 if (lane < M) {
                     Xs[lane * T + r3] = acc;
                     Ul[lane * T + r3] = acc;
@@ -577,10 +577,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
             const int tp = su.t_dof[pl];
-            const double *Xp = L + S::Xl + pl * M * T, *Yp = L + S::T1r + pl * T * M;
+            const real_t *Xp = L + S::Xl + pl * M * T, *Yp = L + S::T1r + pl * T * M;
             for (int idx = th.tid; idx < tp * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
-                double acc = 0.0;
+                real_t acc = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
                 L[S::c_Z + idx] = acc;
@@ -588,7 +588,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             for (int idx = th.tid; idx < M * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
-                double acc = Ul[i * T + j];
+                real_t acc = Ul[i * T + j];
                 _Pragma("unroll 8")
                 for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * L[S::c_Z + p * t + j];
                 Ul[i * T + j] = acc;
@@ -606,20 +606,20 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
     int st_task = 1, fail_level = -1, st_redis = 1;
-    const double *fs_in = L + S::fs;  // filled by task_reference() after stage 0
-    double *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
+    const real_t *fs_in = L + S::fs;  // filled by task_reference() after stage 0
+    real_t *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
         if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
         const int t = is_task ? su.t_dof[qi] : 0;
         const FastDiv fdt1(t + 1);
-        const double *Ul = L + S::U + (is_task ? qi : 0) * M * T;
-        const double *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
+        const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
+        const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
         DWBC_SYNC();
         for (int i = th.tid; i < M; i += NT) {
-            double acc = L[S::tg + i] + L[S::tt + i];
+            real_t acc = L[S::tg + i] + L[S::tt + i];
             if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
             else acc += L[S::tc + i];
             base[i] = acc;
@@ -628,7 +628,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // contact wrench map in the contact frame: F = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
             const int i = fdt1.div(idx), j = idx - i * (t + 1);
-            double acc = 0.0;
+            real_t acc = real_t(0.0);
             if (j < t) {
                 _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Ul[c * T + j];
@@ -643,9 +643,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
             const int i = fdt1.div(idx), j = idx - i * (t + 1);
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
-            const double *R = L + S::Rc + a * 9;
-            const double *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
-            const double v = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[T + 1] + R[2 * 3 + x] * src[2 * (T + 1)];
+            const real_t *R = L + S::Rc + a * 9;
+            const real_t *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
+            const real_t v = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[T + 1] + R[2 * 3 + x] * src[2 * (T + 1)];
             if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
         }
         DWBC_SYNC();
@@ -653,12 +653,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         QpResult qres;
         {
             // task level: x = [f*_qp (t) ; contact_qp (k)], rows [U | s NwJw];  redistribution: x = c (k), rows [NwJw]
-            const double *P1 = is_task ? Ul : L + S::NwJw;
+            const real_t *P1 = is_task ? Ul : L + S::NwJw;
             const int ld1 = is_task ? T : k, n1 = is_task ? t : k, n2 = is_task ? k : 0;
-            const double *W1 = is_task ? F : L + S::FNl;
+            const real_t *W1 = is_task ? F : L + S::FNl;
             const int ldw1 = is_task ? kQpLd : k;
             qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], P1, ld1, n1, L + S::NwJw, k, n2,
-                                     is_task ? kQpScaleGI : 1.0, W1, ldw1, L + S::FNl, k, fv, base, n1,
+                                     is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, k, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
         }
         const int slot = is_task ? qi : kMaxLevels;
@@ -670,18 +670,18 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
         if (dump && th.tid == 0 && qi == 0)
-            for (int i_ = 0; i_ < 8; i_++) dump[dl.stamps + 23 + i_] = (double)qres.tm[i_];
+            for (int i_ = 0; i_ < 8; i_++) dump[dl.stamps + 23 + i_] = (real_t)qres.tm[i_];
 #endif
         if (is_task) DWBC_STAMP(8 + 3 * qi);
-        const double *x = L + S::qp_x;
+        const real_t *x = L + S::qp_x;
         if (is_task) {
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }  // cascade aborts (dwbc.cpp:836,1119)
             for (int i = th.tid; i < M; i += NT) {
-                double acc = 0.0;
+                real_t acc = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
                 L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
-                double c = 0.0;
+                real_t c = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
                 L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
@@ -692,7 +692,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
         } else if (qres.status) {
             for (int i = th.tid; i < M; i += NT) {
-                double c = 0.0;
+                real_t c = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
                 L[S::tc + i] += c;    // torque_contact_ += NwJw c   (dwbc.cpp:1549)
@@ -701,22 +701,22 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 for (int j = th.tid; j < k; j += NT) dump[dl.cf_redis + j] = x[j];
         } else {
             st_redis = 0;
-            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1553-1559
+            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);  // dwbc.cpp:1553-1559
         }
         DWBC_SYNC();
     }
     if (k == 0) {
-        for (int i = th.tid; i < M; i += NT) L[S::tc + i] = 0.0;  // dwbc.cpp:1562-1567
+        for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);  // dwbc.cpp:1562-1567
     }
     DWBC_SYNC();
     DWBC_STAMP(15);
 
     // ================= outputs =================
-    double *tau = io.tau + (size_t)inst * 3 * M;
+    real_t *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
-    double *wr = io.wrench + (size_t)inst * 12;
+    real_t *wr = io.wrench + (size_t)inst * 12;
     for (int i = th.tid; i < 12; i += NT) {
-        double acc = 0.0;
+        real_t acc = real_t(0.0);
         if (i < cd) {
             acc = -L[S::PC + i];
             _Pragma("unroll 8")

@@ -1,0 +1,114 @@
+// dwbc_kernels.h -- __global__ entry points of the fused cycle and the table of instantiations.  Included by dwbc_capi.hip
+// (DWBC_REAL = double, the product path) and by dwbc_kernels_f32.hip (DWBC_REAL = float with the namespace renamed to
+// dwbc_f32): the same source in both arithmetic types, looked up at run time through KernelEntry.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dwbc_reduced.h"
+
+namespace dwbc {
+
+// ------------------------------------------------------------------------------------------------
+// kernel: one workgroup (one 64-lane wavefront) per robot instance, everything between q and tau in LDS
+// ------------------------------------------------------------------------------------------------
+template <int N, int NB, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const BatchIO io) {
+    extern __shared__ __attribute__((aligned(16))) real_t lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    int *iL = reinterpret_cast<int *>(lds + Lds<N, NB>::total);
+    cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
+}
+
+// register-resident version (dwbc_cycle2.h): the default.  Two builds of the same body:
+//   _v2   amdgpu_waves_per_eu(2): VGPR + AGPR <= 256, so a fifth workgroup of a CU (the LDS map allows 5 at <= 31 KB) can
+//         share a SIMD -- the throughput build for batches larger than 4 instances per CU
+//   _v2w  no register cap (one wave per SIMD): ~7 % shorter single-instance latency -- used while B <= 4 x CUs
+#define DWBC_V2_BODY                                                                     \
+    static_assert(NT == 64, "one wavefront per instance");                               \
+    extern __shared__ __attribute__((aligned(16))) real_t lds[];                         \
+    const int inst = blockIdx.x;                                                         \
+    if (inst >= io.B) return;                                                            \
+    Thr th{(int)threadIdx.x};                                                            \
+    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
+    cycle_instance_v2<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
+    DWBC_V2_BODY
+}
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
+    DWBC_V2_BODY
+}
+
+// reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
+template <int N, int NB, int NLV, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
+    static_assert(NT == 64, "one wavefront per instance");
+    extern __shared__ __attribute__((aligned(16))) real_t lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    int *iL = reinterpret_cast<int *>(lds + LdsR<N, NB, NLV>::rtotal);
+    cycle_instance_reduced<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+}
+
+constexpr int kNT = 64;
+
+struct KernelEntry {
+    int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
+    void (*fn)(const Setup, const BatchIO);
+    int lds_bytes;
+    void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
+};
+// instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
+// index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
+#ifdef DWBC_EXPERIMENT
+// A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
+const KernelEntry kKernels[] = {
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
+};
+const KernelEntry kKernelsReduced[] = {
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
+};
+#else
+const KernelEntry kKernels[] = {
+    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT>},
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
+    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT>},
+    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT>},
+};
+const KernelEntry kKernelsReduced[] = {
+    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr},
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
+    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr},
+    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr},
+};
+#endif
+#ifdef DWBC_EXPERIMENT
+const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr}};
+#else
+const KernelEntry kKernelsV1[] = {
+    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
+};
+#endif
+
+// which: 0 = register-resident kernel (default), 1 = LDS-resident reference kernel (DWBC_KERNEL=v1), 2 = reduced dynamics
+inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which) {
+    if (which == 2) {
+        for (const auto &k : kKernelsReduced)
+            if (k.n == n && k.nb == nb && k.nlv == nlv) return &k;
+        return nullptr;
+    }
+    if (which == 1) {
+        for (const auto &k : kKernelsV1)
+            if (k.n == n && k.nb == nb) return &k;
+        return nullptr;
+    }
+    for (const auto &k : kKernels)
+        if (k.n == n && k.nb == nb && k.nlv == nlv) return &k;
+    return nullptr;
+}
+
+}  // namespace dwbc

@@ -1,0 +1,16 @@
+// dwbc_kernels_f32.hip -- the fp32 build of the fused cycle kernels (BASELINE config 5 names an fp32 path).  Same source as the
+// fp64 product kernels (dwbc_kernels.h) with DWBC_REAL = float; the namespace is renamed so that both builds link into
+// libdwbc_hip.so.  dwbc_capi.hip looks the entry points up through dwbc_f32_lookup() and launches them with hipLaunchKernel.
+#define DWBC_REAL float
+#define dwbc dwbc_f32
+#include "dwbc_kernels.h"
+#undef dwbc
+
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, const void **fn, const void **fn_wide, int *lds_bytes) {
+    const dwbc_f32::KernelEntry *k = dwbc_f32::lookup_kernel(n, nb, nlv, which);
+    if (!k || !k->fn) return 0;
+    *fn = reinterpret_cast<const void *>(k->fn);
+    *fn_wide = reinterpret_cast<const void *>(k->fn_wide);
+    *lds_bytes = k->lds_bytes;
+    return 1;
+}

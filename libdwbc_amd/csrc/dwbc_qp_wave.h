@@ -23,17 +23,17 @@ namespace dwbc {
 constexpr int kQpN = 12;  // max variables (6 task + 6 contact-null)
 
 struct QpRows {
-    PLA(double, g, kQpN);  // row coefficients, contact columns already scaled by kQpScaleGI, zero padded
-    PL(double, hi);        // g.x <= hi
-    PL(double, lo);        // -g.x <= lo   (lo = +inf: one-sided row)
+    PLA(real_t, g, kQpN);  // row coefficients, contact columns already scaled by kQpScaleGI, zero padded
+    PL(real_t, hi);        // g.x <= hi
+    PL(real_t, lo);        // -g.x <= lo   (lo = +inf: one-sided row)
     PL(int, id_hi);        // reference row index of the hi side (for diagnostics)
     PL(int, id_lo);
 };
 
 struct QpResult {
     int status, iters, nact;
-    double viol;
-    double x[kQpN];   // uniform, unscaled [delta (t); c (k)]
+    real_t viol;
+    real_t x[kQpN];   // uniform, unscaled [delta (t); c (k)]
     int act[kQpN];    // reference row indices of the working set
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
     long long tm[8];  // diagnostic build: cycles per solver section
@@ -48,11 +48,11 @@ struct QpResult {
 #define DWBC_QPT(i) ((void)0)
 #endif
 
-#define DWBC_QP_INF 1.0e300
+#define DWBC_QP_INF (dwbc::kF32 ? dwbc::real_t(1.0e30) : dwbc::real_t(1.0e300))
 
 // uniform 12-array element with a uniform dynamic index
-DWBC_WDEV double upick12(const double *a, int idx) {
-    double v = 0.0;
+DWBC_WDEV real_t upick12(const real_t *a, int idx) {
+    real_t v = real_t(0.0);
 #pragma unroll
     for (int i = 0; i < kQpN; i++) v = (i == idx) ? a[i] : v;
     return v;
@@ -64,65 +64,65 @@ DWBC_WDEV double upick12(const double *a, int idx) {
 #define DWBC_QP_PERM_CASE(TT, KK)                                                                         \
     _Pragma("unroll") for (int i = 0; i < kQpN; i++)                                                      \
         LV(c)[i] = (i < (KK)) ? sgw * wsc * LV(R.g)[((TT) + i) < kQpN ? (TT) + i : 0]                     \
-                              : ((i < (KK) + (TT)) ? sgw * LV(R.g)[(i - (KK)) >= 0 ? i - (KK) : 0] : 0.0);
+                              : ((i < (KK) + (TT)) ? sgw * LV(R.g)[(i - (KK)) >= 0 ? i - (KK) : 0] : real_t(0.0));
 
 template <int DUMMY>
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, double *V /* LDS, 176 doubles */) {
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */) {
     DWBC_LANE_DECL;
     const int k = nv - t;
-    PLA(double, Mx, kQpN);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
-    PL(double, d);          // g . x of the own row (normalised row, scaled variables)
-    PL(double, fs);         // |g| / |a|: factor from the normalised slack to slack / (norm of the unscaled row)
-    PL(double, u);          // slot lanes: multiplier
+    PLA(real_t, Mx, kQpN);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
+    PL(real_t, d);          // g . x of the own row (normalised row, scaled variables)
+    PL(real_t, fs);         // |g| / |a|: factor from the normalised slack to slack / (norm of the unscaled row)
+    PL(real_t, u);          // slot lanes: multiplier
     PL(int, akey);          // slot lanes: (owner lane << 1) | side
     PL(int, actf);          // bit0: hi side in the working set, bit1: lo side
     PL(int, slotbit);       // 1 << slot for lanes 16..27, else 0
-    PL(double, val);
+    PL(real_t, val);
     PL(int, key);
-    PL(double, m);
-    PL(double, dz);
-    double xu[kQpN];
+    PL(real_t, m);
+    PL(real_t, dz);
+    real_t xu[kQpN];
     DWBC_QPT_INIT();
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) xu[i] = 0.0;
+    for (int i = 0; i < kQpN; i++) xu[i] = real_t(0.0);
     LANES {
-        double s2 = 0.0, a2 = 0.0;
+        real_t s2 = real_t(0.0), a2 = real_t(0.0);
 #pragma unroll
         for (int j = 0; j < kQpN; j++) {
-            const double g2 = LV(R.g)[j] * LV(R.g)[j];
+            const real_t g2 = LV(R.g)[j] * LV(R.g)[j];
             s2 += g2;
-            a2 += (j < t) ? g2 : g2 * (1.0 / (kQpScaleGI * kQpScaleGI));
+            a2 += (j < t) ? g2 : g2 * (real_t(1.0) / (kQpScaleGI * kQpScaleGI));
         }
         // a numerically zero row (|g| < kQpZeroRow) is the constraint 0 <= hi: its coefficients are dropped and its
         // slack is taken unnormalised, so noise never becomes a unit normal (oracle: QP_ZERO_ROW)
         const bool zrow = s2 < kQpZeroRow * kQpZeroRow;
-        const double gn = zrow ? 1.0 : sqrt(s2);
-        const double rg = zrow ? 0.0 : 1.0 / gn;
-        LV(fs) = zrow ? 1.0 : gn / sqrt(a2);
+        const real_t gn = zrow ? real_t(1.0) : sqrt(s2);
+        const real_t rg = zrow ? real_t(0.0) : real_t(1.0) / gn;
+        LV(fs) = zrow ? real_t(1.0) : gn / sqrt(a2);
 #pragma unroll
         for (int j = 0; j < kQpN; j++) {
             LV(R.g)[j] *= rg;
-            LV(Mx)[j] = (lane == j) ? 1.0 : 0.0;
+            LV(Mx)[j] = (lane == j) ? real_t(1.0) : real_t(0.0);
         }
         if (LV(R.hi) < DWBC_QP_INF && !zrow) LV(R.hi) *= rg;
         if (LV(R.lo) < DWBC_QP_INF && !zrow) LV(R.lo) *= rg;
-        LV(d) = 0.0;
-        LV(u) = 0.0;
+        LV(d) = real_t(0.0);
+        LV(u) = real_t(0.0);
         LV(akey) = 0;
         LV(actf) = 0;
         LV(slotbit) = (lane >= 16 && lane < 16 + kQpN) ? (1 << (lane - 16)) : 0;
-        LV(m) = 0.0;
-        LV(dz) = 0.0;
+        LV(m) = real_t(0.0);
+        LV(dz) = real_t(0.0);
     }
     // ---- Goldfarb-Idnani dual active set on min 1/2 |x|^2 (scaled variables), x = 0 start
     int used = 0, q = 0, it = 0, status = 1, p = 0, side = 0, kmin = 0;
     bool pick = true;
-    double up = 0.0, worst = 0.0;
+    real_t up = real_t(0.0), worst = real_t(0.0);
     for (;;) {
         if (pick) {
             LANES {
-                const double sh = ((LV(actf) & 1) || LV(R.hi) >= DWBC_QP_INF) ? DWBC_QP_INF : LV(R.hi) - LV(d);
-                const double sl = ((LV(actf) & 2) || LV(R.lo) >= DWBC_QP_INF) ? DWBC_QP_INF : LV(R.lo) + LV(d);
+                const real_t sh = ((LV(actf) & 1) || LV(R.hi) >= DWBC_QP_INF) ? DWBC_QP_INF : LV(R.hi) - LV(d);
+                const real_t sl = ((LV(actf) & 2) || LV(R.lo) >= DWBC_QP_INF) ? DWBC_QP_INF : LV(R.lo) + LV(d);
                 const bool lo_side = sl < sh;
                 LV(val) = lo_side ? sl : sh;
                 LV(key) = (lane << 1) | (lo_side ? 1 : 0);
@@ -135,45 +135,45 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             if (!(worst < -kQpTol)) break;
             p = kmin >> 1;
             side = kmin & 1;
-            up = 0.0;
+            up = real_t(0.0);
             pick = false;
         }
         if (++it > max_iter) { status = 0; break; }
         // normal of the violated side (GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g)
-        double gp[kQpN];
+        real_t gp[kQpN];
 #pragma unroll
         for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
-        const double sgn = side ? 1.0 : -1.0;
+        const real_t sgn = side ? real_t(1.0) : -real_t(1.0);
         LANES {
-            double s_ = 0.0;
+            real_t s_ = real_t(0.0);
 #pragma unroll
             for (int j = 0; j < kQpN; j++) s_ += LV(Mx)[j] * gp[j];
             LV(m) = sgn * s_;  // lanes 0..11: z = H n;  slot lanes: r = N^+ n
         }
-        double zu[kQpN];
+        real_t zu[kQpN];
 #pragma unroll
         for (int i = 0; i < kQpN; i++) zu[i] = BCAST(m, i);
         LANES {
-            double s_ = 0.0;
+            real_t s_ = real_t(0.0);
 #pragma unroll
             for (int j = 0; j < kQpN; j++) s_ += LV(R.g)[j] * zu[j];
             LV(dz) = s_;  // change of g.x per unit step along z
             LV(val) = side ? LV(R.lo) + LV(d) : LV(R.hi) - LV(d);
         }
-        const double zg = sgn * BCAST(dz, p);  // n.z = |z|^2
-        const double sp = BCAST(val, p);       // slack of the violated side (negative)
-        const bool zok = zg > 1e-20 && q < nv;
+        const real_t zg = sgn * BCAST(dz, p);  // n.z = |z|^2
+        const real_t sp = BCAST(val, p);       // slack of the violated side (negative)
+        const bool zok = zg > (kF32 ? real_t(1e-10) : real_t(1e-20)) && q < nv;
         DWBC_QPT(2);
         LANES {
-            const bool ok = (LV(slotbit) & used) && LV(m) > 1e-12;
+            const bool ok = (LV(slotbit) & used) && LV(m) > (kF32 ? real_t(1e-6) : real_t(1e-12));
             LV(val) = ok ? LV(u) * fast_rcp(LV(m)) : DWBC_QP_INF;
             LV(key) = lane;
         }
-        double t1;
+        real_t t1;
         int l;
         WAVE_ARGMIN_ROW1(val, key, t1, l);
-        const double t2 = zok ? -sp * fast_rcp(zg) : DWBC_QP_INF;
-        const double tstep = t1 < t2 ? t1 : t2;
+        const real_t t2 = zok ? -sp * fast_rcp(zg) : DWBC_QP_INF;
+        const real_t tstep = t1 < t2 ? t1 : t2;
         if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
         const bool full = zok && t2 <= t1;
         if (zok) {
@@ -189,9 +189,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             int slot = 0;
 #pragma unroll
             for (int a = kQpN - 1; a >= 0; a--) slot = ((used >> a) & 1) ? slot : a;
-            const double inv_ = fast_rcp(zg);
+            const real_t inv_ = fast_rcp(zg);
             LANES {
-                double coef = LV(m) * inv_;
+                real_t coef = LV(m) * inv_;
                 if (lane == 16 + slot) { coef = -inv_; LV(u) = up; LV(akey) = kmin; }
 #pragma unroll
                 for (int j = 0; j < kQpN; j++) LV(Mx)[j] -= coef * zu[j];
@@ -211,19 +211,19 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                 }
             }
             WSYNC();
-            double rho[kQpN], rr = 0.0;
+            real_t rho[kQpN], rr = real_t(0.0);
 #pragma unroll
             for (int j = 0; j < kQpN; j++) { rho[j] = V[j]; rr += rho[j] * rho[j]; }
-            const double inv_ = fast_rcp(rr);
+            const real_t inv_ = fast_rcp(rr);
             LANES {
-                double dd = 0.0;
+                real_t dd = real_t(0.0);
 #pragma unroll
                 for (int j = 0; j < kQpN; j++) dd += LV(Mx)[j] * rho[j];
-                double coef = dd * inv_;
+                real_t coef = dd * inv_;
                 if (lane < kQpN) coef = -V[lane] * inv_;
 #pragma unroll
-                for (int j = 0; j < kQpN; j++) LV(Mx)[j] = (lane == l) ? 0.0 : LV(Mx)[j] - coef * rho[j];
-                if (lane == l) LV(u) = 0.0;
+                for (int j = 0; j < kQpN; j++) LV(Mx)[j] = (lane == l) ? real_t(0.0) : LV(Mx)[j] - coef * rho[j];
+                if (lane == l) LV(u) = real_t(0.0);
                 if (lane == (kl >> 1)) LV(actf) &= ~((kl & 1) ? 2 : 1);
             }
             WSYNC();
@@ -236,7 +236,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     out.iters = it;
     out.nact = q;
     out.status = status;
-    out.viol = worst >= DWBC_QP_INF ? 0.0 : worst;
+    out.viol = worst >= DWBC_QP_INF ? real_t(0.0) : worst;
 #pragma unroll
     for (int a = 0; a < kQpN; a++) {
         const int ka = BCASTI(akey, 16 + a);
@@ -245,12 +245,12 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         out.act[a] = ((used >> a) & 1) ? ((ka & 1) ? idl : idh) : -1;
     }
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) out.x[i] = 0.0;
+    for (int i = 0; i < kQpN; i++) out.x[i] = real_t(0.0);
     if (!status || q == 0) return;  // x = 0: failure (caller zeroes the correction) or no active constraint
     // Tikhonov point on the working set = the GI iterate (the fallback of the canon, and the answer when one of the two
     // variable blocks is empty)
 #pragma unroll
-    for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j] * ((j >= t) ? kQpScaleGI : 1.0) : 0.0;
+    for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
     if (!(k > 0 && t > 0)) return;
     // ---- lexicographic least-norm point on the working set: contact block weighted by kQpScalePolish.  The weighted
     //      normal of an active row stays in its owner lane, entries in POSITION order (contact variables first = row
@@ -258,56 +258,56 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     //      norm, pivot column broadcast with v_readlane, reflector applied by every pending lane; the forward
     //      substitution R^T y = b is folded into the same step (acc = b - sum_j R[j] y_j per lane).
     {
-        const double wsc = kQpScalePolish / kQpScaleGI;
-        PLA(double, c, kQpN);
-        PL(double, acc);
+        const real_t wsc = kQpScalePolish / kQpScaleGI;
+        PLA(real_t, c, kQpN);
+        PL(real_t, acc);
         PL(int, pend);
         LANES {
-            const double sgw = LV(actf) ? ((LV(actf) & 2) ? -1.0 : 1.0) : 0.0;  // row as (sg g).x = b
+            const real_t sgw = LV(actf) ? ((LV(actf) & 2) ? -real_t(1.0) : real_t(1.0)) : real_t(0.0);  // row as (sg g).x = b
             if (t == 6 && k == 6) { DWBC_QP_PERM_CASE(6, 6) }
             else if (t == 3 && k == 6) { DWBC_QP_PERM_CASE(3, 6) }
             else {
 #pragma unroll
                 for (int i = 0; i < kQpN; i++) {
                     const int var = (i < k) ? t + i : i - k;
-                    double gv = 0.0;
+                    real_t gv = real_t(0.0);
 #pragma unroll
                     for (int j = 0; j < kQpN; j++) gv = (j == var) ? LV(R.g)[j] : gv;
-                    LV(c)[i] = (i < nv) ? sgw * gv * ((i < k) ? wsc : 1.0) : 0.0;
+                    LV(c)[i] = (i < nv) ? sgw * gv * ((i < k) ? wsc : real_t(1.0)) : real_t(0.0);
                 }
             }
-            LV(acc) = LV(actf) ? ((LV(actf) & 2) ? LV(R.lo) : LV(R.hi)) : 0.0;
+            LV(acc) = LV(actf) ? ((LV(actf) & 2) ? LV(R.lo) : LV(R.hi)) : real_t(0.0);
             LV(pend) = LV(actf) ? 1 : 0;
         }
-        double y[kQpN];
+        real_t y[kQpN];
 #pragma unroll
-        for (int i = 0; i < kQpN; i++) y[i] = 0.0;
+        for (int i = 0; i < kQpN; i++) y[i] = real_t(0.0);
         WSYNC();
 #pragma unroll
         for (int s = 0; s < kQpN; s++) {
             if (s < q) {
                 LANES {
-                    double c2 = 0.0;
+                    real_t c2 = real_t(0.0);
 #pragma unroll
                     for (int j = s; j < kQpN; j++) c2 += LV(c)[j] * LV(c)[j];
                     LV(val) = LV(pend) ? -c2 : DWBC_QP_INF;
                 }
                 int jp;
                 WAVE_ARGMIN_F32(val, jp);
-                double v[kQpN];
+                real_t v[kQpN];
 #pragma unroll
                 for (int j = s; j < kQpN; j++) v[j] = BCASTA(c, j, jp);
-                const double nrm2 = -BCAST(val, jp);
-                const double a0 = v[s];
-                const double nrm = sqrt(nrm2);
-                const double alpha = a0 > 0 ? -nrm : nrm;
-                const double vs0 = a0 - alpha;
-                const double vn2 = nrm2 - a0 * a0 + vs0 * vs0;
-                const double bt = vn2 > 0.0 ? 2.0 * fast_rcp(vn2) : 0.0;
+                const real_t nrm2 = -BCAST(val, jp);
+                const real_t a0 = v[s];
+                const real_t nrm = sqrt(nrm2);
+                const real_t alpha = a0 > 0 ? -nrm : nrm;
+                const real_t vs0 = a0 - alpha;
+                const real_t vn2 = nrm2 - a0 * a0 + vs0 * vs0;
+                const real_t bt = vn2 > real_t(0.0) ? real_t(2.0) * fast_rcp(vn2) : real_t(0.0);
                 v[s] = vs0;
                 LANES {
                     if (LV(pend)) {
-                        double dd = 0.0;
+                        real_t dd = real_t(0.0);
 #pragma unroll
                         for (int j = s; j < kQpN; j++) dd += v[j] * LV(c)[j];
                         dd *= bt;
@@ -320,7 +320,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                         V[kQpN * kQpN + s] = bt;
                     }
                 }
-                const double ys = BCAST(acc, jp) * fast_rcp(alpha);
+                const real_t ys = BCAST(acc, jp) * fast_rcp(alpha);
                 y[s] = ys;
                 LANES {
                     if (lane == jp) LV(pend) = 0;
@@ -334,8 +334,8 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
         for (int s = kQpN - 1; s >= 0; s--) {
             if (s < q) {
-                double dd = 0.0;
-                double v[kQpN];
+                real_t dd = real_t(0.0);
+                real_t v[kQpN];
 #pragma unroll
                 for (int j = s; j < kQpN; j++) { v[j] = V[s * kQpN + j]; dd += v[j] * y[j]; }
                 dd *= V[kQpN * kQpN + s];
@@ -345,40 +345,40 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         }
         DWBC_QPT(6);
         // back to variable order, in the GI scaling (for the slack test) and unscaled (result)
-        double xs[kQpN];
+        real_t xs[kQpN];
         if (t == 6 && k == 6) {
 #pragma unroll
             for (int j = 0; j < kQpN; j++) xs[j] = (j < 6) ? y[6 + j] : y[j - 6] * wsc;
         } else if (t == 3 && k == 6) {
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) xs[j] = (j < 3) ? y[6 + j] : (j < 9 ? y[j - 3] * wsc : 0.0);
+            for (int j = 0; j < kQpN; j++) xs[j] = (j < 3) ? y[6 + j] : (j < 9 ? y[j - 3] * wsc : real_t(0.0));
         } else {
 #pragma unroll
             for (int j = 0; j < kQpN; j++) {
                 const int pos = (j >= t) ? j - t : k + j;
-                double yv = 0.0;
+                real_t yv = real_t(0.0);
 #pragma unroll
                 for (int i = 0; i < kQpN; i++) yv = (i == pos) ? y[i] : yv;
-                xs[j] = (j < nv) ? yv * ((j >= t) ? wsc : 1.0) : 0.0;
+                xs[j] = (j < nv) ? yv * ((j >= t) ? wsc : real_t(1.0)) : real_t(0.0);
             }
         }
         // worst slack of the lexicographic point, normalised by the unscaled row norm
         LANES {
-            double dd = 0.0;
+            real_t dd = real_t(0.0);
 #pragma unroll
             for (int j = 0; j < kQpN; j++) dd += LV(R.g)[j] * xs[j];
-            const double sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - dd) * LV(fs);
-            const double sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + dd) * LV(fs);
+            const real_t sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - dd) * LV(fs);
+            const real_t sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + dd) * LV(fs);
             LV(val) = sl < sh ? sl : sh;
         }
         int wi;
         WAVE_ARGMIN_F32(val, wi);
-        const double wv = BCAST(val, wi);
+        const real_t wv = BCAST(val, wi);
         DWBC_QPT(7);
         if (!(wv < -kQpFeasTol)) {
-            out.viol = wv >= DWBC_QP_INF ? 0.0 : wv;
+            out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j] * ((j >= t) ? kQpScaleGI : 1.0) : 0.0;
+            for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
         }
     }
 }

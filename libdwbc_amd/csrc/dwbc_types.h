@@ -7,7 +7,16 @@
 #define __device__
 #endif
 
+// arithmetic type of the device path.  The product library is built for double; DWBC_REAL=float (with the namespace renamed
+// by -Ddwbc=dwbc_f32) builds the fp32 variant of the same kernels in a second translation unit (dwbc_kernels_f32.hip).
+#ifndef DWBC_REAL
+#define DWBC_REAL double
+#endif
+
 namespace dwbc {
+
+typedef DWBC_REAL real_t;
+constexpr bool kF32 = sizeof(real_t) == 4;
 
 constexpr int kMaxBodies = 48;
 constexpr int kMaxContacts = 4;       // registered contacts (reference tests register 4: tests/dwbc_test.cpp:66-69)
@@ -121,21 +130,21 @@ struct DumpLayout {
     }
 };
 
-struct BatchIO {
+struct BatchIO {  // device pointers; floating-point buffers are real_t
     int B;
-    const double *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
-    const double *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
+    const real_t *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
+    const real_t *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
     const unsigned char *flags;  // B x n_contacts
-    const double *fstar;         // B x fstar_total
-    const double *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
-    const double *ctime;         // B control times (RobotData::control_time_) or nullptr
-    const double *custom_J;      // B x n_custom x (kMaxTaskDof x N) row-major J_task of the TASK_CUSTOM levels, or nullptr
-    double *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
-    double *wrench;              // B x 12    : getContactForce(tau_total), zero padded
+    const real_t *fstar;         // B x fstar_total
+    const real_t *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
+    const real_t *ctime;         // B control times (RobotData::control_time_) or nullptr
+    const real_t *custom_J;      // B x n_custom x (kMaxTaskDof x N) row-major J_task of the TASK_CUSTOM levels, or nullptr
+    real_t *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
+    real_t *wrench;              // B x 12    : getContactForce(tau_total), zero padded
     int *status;                 // B         : 1 ok / 0 fail (reference int returns ANDed)
     int *diag;                   // B x DG_COUNT
-    double *dump;                // B x DumpLayout::total or nullptr
-    const double *body;          // nb x kBodyStride
+    real_t *dump;                // B x DumpLayout::total or nullptr
+    const real_t *body;          // nb x kBodyStride
     const int *topo;             // parent[nb], depth[nb], subtree[nb]
 };
 

@@ -9,6 +9,8 @@
 #pragma once
 #include <math.h>
 
+#include "dwbc_types.h"
+
 #ifdef DWBC_HOST_EMU
 #define PL(type, x) type x[64]
 #define PLA(type, x, n) type x[64][n]
@@ -48,6 +50,9 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ float readlane_f64(float v, int srclane) {  // fp32 build: one v_readlane
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
 __device__ __forceinline__ int readlane_i32(int v, int srclane) { return __builtin_amdgcn_readlane(v, srclane); }
 #define BCASTI(x, src) dwbc::readlane_i32((x), (src))
 #else
@@ -67,6 +72,15 @@ DWBC_WDEV double fast_rcp(double d) {
     return __builtin_fma(r, e, r);
 #endif
 }
+DWBC_WDEV float fast_rcp(float d) {
+#ifdef DWBC_HOST_EMU
+    return 1.0f / d;
+#else
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(r, e, r);
+#endif
+}
 
 // 1/sqrt(d) for positive normal d: hardware estimate + two Newton steps
 DWBC_WDEV double fast_rsqrt(double d) {
@@ -80,16 +94,28 @@ DWBC_WDEV double fast_rsqrt(double d) {
     return r;
 #endif
 }
+DWBC_WDEV float fast_rsqrt(float d) {
+#ifdef DWBC_HOST_EMU
+    return 1.0f / sqrtf(d);
+#else
+    float r = __builtin_amdgcn_rsqf(d);
+    const float h = 0.5f * d;
+    return __builtin_fmaf(r, __builtin_fmaf(-h * r, r, 0.5f), r);
+#endif
+}
+// sin and cos of one angle in the arithmetic type of the build
+DWBC_WDEV void sincos_r(double x, double *s, double *c) { sincos(x, s, c); }
+DWBC_WDEV void sincos_r(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // element `lane` of a uniform 12-array (avoids dynamic register indexing on the device)
-DWBC_WDEV double pick12(const double *a, int lane) {
-    double v = 0.0;
+DWBC_WDEV real_t pick12(const real_t *a, int lane) {
+    real_t v = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) v = (lane == i) ? a[i] : v;
     return v;
 }
 // arr[q] = v for a per-lane 12-array with a (uniform or per-lane) dynamic index
-DWBC_WDEV void setidx12(double *arr, int q, double v) {
+DWBC_WDEV void setidx12(real_t *arr, int q, real_t v) {
 #pragma unroll
     for (int i = 0; i < 12; i++) arr[i] = (i == q) ? v : arr[i];
 }
@@ -165,7 +191,7 @@ __device__ __forceinline__ unsigned long long row1_min_u64(unsigned long long x)
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 // lane of the wave minimum of a value rounded to float: six single-register DPP steps and a ballot
-__device__ __forceinline__ int wave_argmin_f32(double v) {
+__device__ __forceinline__ int wave_argmin_f32(real_t v) {
     const float f = (float)v;
     float m = f;
 #define DWBC_DPP_STEP(ctrl, rmask)                                                                         \
@@ -185,8 +211,8 @@ __device__ __forceinline__ int wave_argmin_f32(double v) {
     return b ? (int)__builtin_ctzll(b) : 0;
 }
 // order-preserving map double -> u64, low 7 bits replaced by the lane so that keys are unique
-__device__ __forceinline__ unsigned long long argmin_key(double v, int lane) {
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+__device__ __forceinline__ unsigned long long argmin_key(real_t v, int lane) {
+    unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
     b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
     return (b & ~127ull) | (unsigned)lane;
 }

@@ -6,14 +6,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(f32=False):
+    if f32 not in _libs:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = C.CDLL(os.path.join(_HERE, "libdwbc_emu.so"))
+        L = C.CDLL(os.path.join(_HERE, "libdwbc_emu_f32.so" if f32 else "libdwbc_emu.so"))
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.c_char_p]
         L.emu_error.restype = C.c_char_p
@@ -28,13 +27,13 @@ def lib():
         L.emu_dump_offset.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.emu_run_reduced.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
-        _lib = L
-    return _lib
+        _libs[f32] = L
+    return _libs[f32]
 
 
 class Emu:
-    def __init__(self, urdf, contacts, tasks, tau_lim=None):
-        L = lib()
+    def __init__(self, urdf, contacts, tasks, tau_lim=None, f32=False):
+        L = lib(f32)
         self.L = L
         self.h = L.emu_create(urdf.encode())
         err = L.emu_error(self.h).decode()
