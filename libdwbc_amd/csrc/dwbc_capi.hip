@@ -766,7 +766,7 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     static thread_local std::string name;
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
-    const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "";
+    const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "dwbc::";  // as rocprofv3 prints the instantiations
     if (!ke) return "";
     if (b->last_reduced) {
         name = pre + "dwbc_cycle_kernel_reduced<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
@@ -782,7 +782,7 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     name = v1 ? "dwbc_cycle_kernel<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", 64>"
               : std::string(wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + std::to_string(ke->n) + ", " +
                     std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
-    name = pre + name;  // rocprofv3 prints the fp32 instantiations as dwbc_f32::dwbc_cycle_kernel_v2<...>
+    name = pre + name;
     return name.c_str();
 }
 

@@ -39,10 +39,11 @@ def mujoco_to_rbdl_q(qpos):
 
 
 class RlWBCBridge:
-    def __init__(self, n_envs, urdf, device=0, torque_limit=300.0):
+    def __init__(self, n_envs, urdf, device=0, torque_limit=300.0, dtype="f64"):
+        """dtype="f32": the fp32 kernels -- the bridge returns float32 torques either way"""
         self.n_envs = int(n_envs)
         self.model = Model.from_urdf(urdf)
-        self.wbc = Batch(self.model, self.n_envs, device=device)
+        self.wbc = Batch(self.model, self.n_envs, device=device, dtype=dtype)
         self.model_dof = self.wbc.m
         self.wbc.add_contact(LEFT_FOOT, FOOT_POINT, 0.15, 0.075, contact_type=CONTACT_6D)
         self.wbc.add_contact(RIGHT_FOOT, FOOT_POINT, 0.15, 0.075, contact_type=CONTACT_6D)

@@ -84,7 +84,7 @@ def test_gpu_f32_kernel_within_envelope(cfg):
         wbc.solve()
         out[dt] = (wbc.get("tau"), wbc.get("wrench"), wbc.get("status"))
         if dt == "f32":
-            assert "f32" in wbc.kernel_name()
+            assert wbc.kernel_name().startswith("dwbc_f32::")
     t32, w32, s32 = out["f32"]
     assert (s32 == st).mean() >= 0.99
     ok = (st == 1) & (s32 == 1)
