@@ -32,8 +32,8 @@ enum {
     DWBC_TASK_LINK_POSITION, DWBC_TASK_LINK_POSITION_COM_FRAME, DWBC_TASK_LINK_POSITION_CUSTOM_FRAME,
     DWBC_TASK_LINK_ROTATION, DWBC_TASK_LINK_ROTATION_CUSTOM_FRAME
 };
-/* arithmetic type of the kernels.  DWBC_F32 runs the same kernel source in single precision on float shadows of the
- * buffers; every buffer at this boundary (host arrays, bound device buffers) stays double.  Accuracy envelope: DESIGN.md §8 */
+/* arithmetic type of the kernels.  DWBC_F32 runs the same kernel source in single precision; every buffer at this boundary
+ * (host arrays, bound device buffers) stays double and is converted inside the kernel.  Accuracy envelope: DESIGN.md §8 */
 enum { DWBC_F64 = 0, DWBC_F32 = 1 };
 /* DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
  * ReducedCalcGravCompensation, ReducedCalcTaskSpace, ReducedCalcTaskControlTorque, ReducedCalcContactRedistribute --

@@ -17,14 +17,11 @@ using namespace dwbc;
 
 extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, const void **fn, const void **fn_wide, int *lds_bytes);
 
-// DWBC_F32 batches keep the double buffers of the boundary and run the fp32 kernels on float shadows (dwbc_kernels_f32.hip)
+// DWBC_F32 batches: the fp32 kernels (dwbc_kernels_f32.hip) work on the double buffers of the boundary; the model table is
+// converted to float once
 __global__ void dwbc_cvt_d2f(const double *__restrict__ in, float *__restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
-}
-__global__ void dwbc_cvt_f2d(const float *__restrict__ in, double *__restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
 }
 
 namespace {
@@ -68,9 +65,7 @@ struct dwbc_batch {
     int fstar_alloc = 0, flags_alloc = 0;
     bool dump_on = false;
     int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
-    float *f_q = nullptr, *f_fstar = nullptr, *f_tau = nullptr, *f_wrench = nullptr, *f_body = nullptr, *f_qdot = nullptr, *f_traj = nullptr,
-          *f_ctime = nullptr, *f_custom = nullptr;
-    size_t f_fstar_n = 0, f_traj_n = 0, f_custom_n = 0;
+    float *f_body = nullptr;
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
     int f32_lds = 0, f32_key = -1;
     bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
@@ -205,8 +200,7 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     hipSetDevice(b->device);
     if (b->own_q) hipFree(b->d_q);
     if (b->d_qdot) hipFree(b->d_qdot);
-    for (float *p : {b->f_q, b->f_fstar, b->f_tau, b->f_wrench, b->f_body, b->f_qdot, b->f_traj, b->f_ctime, b->f_custom})
-        if (p) hipFree(p);
+    if (b->f_body) hipFree(b->f_body);
     if (b->d_traj) hipFree(b->d_traj);
     if (b->d_ctime) hipFree(b->d_ctime);
     if (b->d_custom) hipFree(b->d_custom);
@@ -441,7 +435,8 @@ static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which);
 }
 
-// fp32 launch: float shadows of the double boundary buffers, converted on the batch's stream around the kernel
+// fp32 launch: the fp32 kernels read and write the double buffers of the boundary themselves (io_t); only the model table is
+// kept in float
 static int launch_f32(dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
     const int key = which * 16 + b->su.n_levels;
@@ -456,34 +451,18 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
         b->f32_key = key;
     }
     if (b->dump_on) return fail("the dump record is not available on DWBC_F32 batches");
-    const size_t B = b->B, n = b->n, m = b->m;
-    auto need = [&](float *&p, size_t count, size_t *have) -> int {
-        if (p && (!have || *have == count)) return 1;
-        if (p) hipFree(p);
-        p = nullptr;
-        HIP_OK(hipMalloc(&p, count * sizeof(float)));
-        if (have) *have = count;
-        return 1;
-    };
-    auto d2f = [&](const double *src, float *dst, size_t count) {
-        hipLaunchKernelGGL(dwbc_cvt_d2f, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, src, dst, count);
-    };
     if (!b->f_body) {
         std::vector<double> body;
         b->model->m.body_table(body);
-        if (!need(b->f_body, body.size(), nullptr)) return 0;
-        d2f(b->d_body, b->f_body, body.size());
+        HIP_OK(hipMalloc(&b->f_body, body.size() * sizeof(float)));
+        hipLaunchKernelGGL(dwbc_cvt_d2f, dim3((unsigned)((body.size() + 255) / 256)), dim3(256), 0, b->stream, b->d_body, b->f_body, body.size());
     }
-    if (!need(b->f_q, B * (n + 1), nullptr) || !need(b->f_tau, B * 3 * m, nullptr) || !need(b->f_wrench, B * 12, nullptr)) return 0;
-    if (!need(b->f_fstar, B * b->su.fstar_total, &b->f_fstar_n)) return 0;
-    d2f(b->d_q, b->f_q, B * (n + 1));
-    d2f(b->d_fstar, b->f_fstar, B * b->su.fstar_total);
-    struct IoF32 {  // BatchIO of the fp32 namespace: same layout, float pointers
+    struct IoF32 {  // BatchIO of the fp32 namespace: same members, real_t = float
         int B;
-        const float *q, *qdot;
+        const double *q, *qdot;
         const unsigned char *flags;
-        const float *fstar, *traj, *ctime, *custom_J;
-        float *tau, *wrench;
+        const double *fstar, *traj, *ctime, *custom_J;
+        double *tau, *wrench;
         int *status, *diag;
         float *dump;
         const float *body;
@@ -491,25 +470,15 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     } io{};
     static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
     io.B = b->B;
-    io.q = b->f_q;
-    if (b->d_qdot) { if (!need(b->f_qdot, B * n, nullptr)) return 0; d2f(b->d_qdot, b->f_qdot, B * n); io.qdot = b->f_qdot; }
-    if (b->su.n_traj > 0 && b->d_traj) {
-        const size_t c = B * b->su.n_traj * kTrajStride;
-        if (!need(b->f_traj, c, &b->f_traj_n)) return 0;
-        d2f(b->d_traj, b->f_traj, c);
-        io.traj = b->f_traj;
-    }
-    if (b->d_ctime) { if (!need(b->f_ctime, B, nullptr)) return 0; d2f(b->d_ctime, b->f_ctime, B); io.ctime = b->f_ctime; }
-    if (b->su.n_custom > 0 && b->d_custom) {
-        const size_t c = B * b->su.n_custom * kMaxTaskDof * n;
-        if (!need(b->f_custom, c, &b->f_custom_n)) return 0;
-        d2f(b->d_custom, b->f_custom, c);
-        io.custom_J = b->f_custom;
-    }
+    io.q = b->d_q;
+    io.qdot = b->d_qdot;
+    io.traj = b->su.n_traj > 0 ? b->d_traj : nullptr;
+    io.ctime = b->d_ctime;
+    io.custom_J = b->su.n_custom > 0 ? b->d_custom : nullptr;
     io.flags = b->d_flags;
-    io.fstar = b->f_fstar;
-    io.tau = b->f_tau;
-    io.wrench = b->f_wrench;
+    io.fstar = b->d_fstar;
+    io.tau = b->d_tau;
+    io.wrench = b->d_wrench;
     io.status = b->d_status;
     io.diag = b->d_diag;
     io.dump = nullptr;
@@ -518,9 +487,6 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     void *args[] = {(void *)&b->su, (void *)&io};
     HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, b->f32_lds, b->stream));
-    hipLaunchKernelGGL(dwbc_cvt_f2d, dim3((unsigned)((B * 3 * m + 255) / 256)), dim3(256), 0, b->stream, b->f_tau, b->d_tau, B * 3 * m);
-    hipLaunchKernelGGL(dwbc_cvt_f2d, dim3((unsigned)((B * 12 + 255) / 256)), dim3(256), 0, b->stream, b->f_wrench, b->d_wrench, B * 12);
-    HIP_OK(hipGetLastError());
     return 1;
 }
 

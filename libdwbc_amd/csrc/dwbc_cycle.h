@@ -471,16 +471,16 @@ DWBC_DEV void dump_centroidal(Thr th, const real_t *A, int lda, const real_t *R0
 // RobotData::getZMP(getContactForce(tau_total)) (reference src/dwbc.cpp:898-939) + cc_[i].xc_pos / rotm / zmp_pos of the
 // active contacts, into the dump record.  The reference indexes the packed wrench by REGISTRATION index (i * 6), which is only
 // consistent when the active contacts are the first registered ones; the active order is used here.
-DWBC_DEV void dump_contacts_zmp(Thr th, const real_t *Pc, const real_t *Rc, const real_t *wr, int nc, real_t *dump, const DumpLayout &dl) {
+DWBC_DEV void dump_contacts_zmp(Thr th, const real_t *Pc, const real_t *Rc, const io_t *wr, int nc, real_t *dump, const DumpLayout &dl) {
     if (th.tid != 0) return;
     real_t tot = real_t(0.0), z[3] = {0, 0, 0};
-    for (int a = 0; a < nc; a++) tot += wr[6 * a + 2];
+    for (int a = 0; a < nc; a++) tot += (real_t)wr[6 * a + 2];
     for (int a = 0; a < kMaxActiveContacts; a++) {
         real_t zp[3] = {0, 0, 0};
         if (a < nc) {
-            const real_t fz = wr[6 * a + 2];
+            const real_t fz = (real_t)wr[6 * a + 2];
             zp[0] = Pc[a * 3]; zp[1] = Pc[a * 3 + 1]; zp[2] = Pc[a * 3 + 2];
-            if (!(fz > -real_t(1.0e-3))) { zp[0] += -wr[6 * a + 4] / fz; zp[1] += wr[6 * a + 3] / fz; }
+            if (!(fz > -real_t(1.0e-3))) { zp[0] += -(real_t)wr[6 * a + 4] / fz; zp[1] += (real_t)wr[6 * a + 3] / fz; }
             for (int x = 0; x < 3; x++) z[x] += zp[x] * fz / tot;
         }
         for (int x = 0; x < 3; x++) {
@@ -623,14 +623,14 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     const int nb = su.nb;
     const real_t *body = io.body;
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
-    const real_t *qin = io.q + (size_t)inst * (N + 1);
+    const io_t *qin = io.q + (size_t)inst * (N + 1);
     const DumpLayout dl = DumpLayout::make(N);
     real_t *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
 
     DWBC_STAMP_INIT();
     // ================= stage 0: kinematics, A, A_inv, G  (src/dwbc.cpp:279-371) =================
-    for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = qin[i];
+    for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = (real_t)qin[i];
     for (int i = th.tid; i < 3 * M; i += NT) L[S::tg + i] = real_t(0.0);
     DWBC_SYNC();
     {
@@ -946,7 +946,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
     int st_task = 1, fail_level = -1;
-    const real_t *fs_in = io.fstar + (size_t)inst * su.fstar_total;
+    const io_t *fs_in = io.fstar + (size_t)inst * su.fstar_total;
     {
         real_t *Winv = L + S::bufA, *AiNc = L + S::bufN, *JbT = L + S::JbT;
         for (int lv = 0; lv < su.n_levels && st_task; lv++) {
@@ -1041,7 +1041,7 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
             DWBC_SYNC();
             DWBC_STAMP(6 + 3 * lv);  // level lv: J_kt, Lambda, null-space chain done
             // --- QP rows (dwbc.cpp:988-1053)
-            const real_t *fs = fs_in + su.fstar_off[lv];
+            const io_t *fs = fs_in + su.fstar_off[lv];
             real_t *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
             for (int i = th.tid; i < M; i += NT) {
                 real_t s = L[S::tg + i] + L[S::tt + i];
@@ -1156,9 +1156,9 @@ DWBC_DEV void cycle_instance(Thr th, const Setup &su, const BatchIO &io, int ins
 
     DWBC_STAMP(15);  // contact redistribution done
     // ================= outputs =================
-    real_t *tau = io.tau + (size_t)inst * 3 * M;
+    io_t *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
-    real_t *wr = io.wrench + (size_t)inst * 12;
+    io_t *wr = io.wrench + (size_t)inst * 12;
     for (int i = th.tid; i < 12; i += NT) {
         real_t s = real_t(0.0);
         if (i < cd) {

@@ -281,7 +281,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const int nb = su.nb;
     const real_t *body = io.body;
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
-    const real_t *qin = io.q + (size_t)inst * (N + 1);
+    const io_t *qin = io.q + (size_t)inst * (N + 1);
     const DumpLayout dl = DumpLayout::make(N);
     real_t *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
@@ -375,8 +375,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         int row = 0;
         if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
-            const real_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
-            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = cj[idx];
+            const io_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
+            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = (real_t)cj[idx];
         }
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
@@ -712,9 +712,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(15);
 
     // ================= outputs =================
-    real_t *tau = io.tau + (size_t)inst * 3 * M;
+    io_t *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
-    real_t *wr = io.wrench + (size_t)inst * 12;
+    io_t *wr = io.wrench + (size_t)inst * 12;
     for (int i = th.tid; i < 12; i += NT) {
         real_t acc = real_t(0.0);
         if (i < cd) {

@@ -145,12 +145,12 @@ DWBC_DEV void link_fstar(int mode, real_t t, const real_t *tr, const real_t *g, 
 template <class S, int N, int NB, int NT>
 DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int inst, const real_t *body, real_t *L, const real_t *Vb) {
     real_t *fs = L + S::fs;
-    const real_t *qd = io.qdot ? io.qdot + (size_t)inst * N : nullptr;
-    const real_t *fin = io.fstar + (size_t)inst * su.fstar_total;
-    for (int i = th.tid; i < su.fstar_total; i += NT) fs[i] = fin[i];
+    const io_t *qd = io.qdot ? io.qdot + (size_t)inst * N : nullptr;
+    const io_t *fin = io.fstar + (size_t)inst * su.fstar_total;
+    for (int i = th.tid; i < su.fstar_total; i += NT) fs[i] = (real_t)fin[i];
     DWBC_SYNC();
     if (!io.traj || su.n_traj == 0) return;
-    const real_t tnow = io.ctime ? io.ctime[inst] : real_t(0.0);
+    const real_t tnow = io.ctime ? (real_t)io.ctime[inst] : real_t(0.0);
     for (int idx = th.tid; idx < kMaxLevels * kMaxTaskLinks; idx += NT) {
         const int lv = idx / kMaxTaskLinks, li = idx - lv * kMaxTaskLinks;
         if (lv >= su.n_levels || li >= su.t_nlinks[lv]) continue;
@@ -165,7 +165,7 @@ DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int ins
         if (is_com) {
             if (qd)
                 for (int j = 0; j < N; j++)
-                    for (int a = 0; a < 3; a++) { v[a] += L[S::Jcm + a * N + j] * qd[j]; w[a] += L[S::Jcm + (3 + a) * N + j] * qd[j]; }
+                    for (int a = 0; a < 3; a++) { v[a] += L[S::Jcm + a * N + j] * (real_t)qd[j]; w[a] += L[S::Jcm + (3 + a) * N + j] * (real_t)qd[j]; }
         } else if (Vb) {
             const real_t *V = Vb + link * 6;
             const real_t d0 = p[0] - O[0], d1 = p[1] - O[1], d2 = p[2] - O[2];
@@ -177,7 +177,9 @@ DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int ins
         real_t gl[15], tp[3];  // Setup keeps host doubles
         for (int a = 0; a < 15; a++) gl[a] = (real_t)su.t_gain[lv][li][a];
         for (int a = 0; a < 3; a++) tp[a] = (real_t)su.t_point[lv][li][a];
-        link_fstar(su.t_mode[lv][li], tnow, io.traj + ((size_t)inst * su.n_traj + slot) * kTrajStride, gl, R, p, w, v,
+        real_t trl[kTrajStride];
+        for (int a = 0; a < kTrajStride; a++) trl[a] = (real_t)io.traj[((size_t)inst * su.n_traj + slot) * kTrajStride + a];
+        link_fstar(su.t_mode[lv][li], tnow, trl, gl, R, p, w, v,
                    body + (is_com ? 0 : link) * kBodyStride + BF_COM, tp, fs + off);
     }
     DWBC_SYNC();

@@ -267,7 +267,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     const int nb = su.nb;
     const real_t *body = io.body;
     const int *topo = io.topo;
-    const real_t *qin = io.q + (size_t)inst * (N + 1);
+    const io_t *qin = io.q + (size_t)inst * (N + 1);
     const DumpLayout dl = DumpLayout::make(N);
     real_t *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
@@ -286,7 +286,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     for (int j = 0; j < N; j++) vcd += (int)((comask >> j) & 1ull);
     int scope_ok = (nact >= 1) && (comask == ((1ull << vcd) - 1ull)) && (vcd == 12 || vcd == 18) && !su.has_tau_lim;
     if (!scope_ok) {  // outside the reduced path's scope: report failure, emit zeros
-        real_t *tau = io.tau + (size_t)inst * 3 * M;
+        io_t *tau = io.tau + (size_t)inst * 3 * M;
         for (int i = th.tid; i < 3 * M; i += NT) tau[i] = real_t(0.0);
         for (int i = th.tid; i < 12; i += NT) io.wrench[(size_t)inst * 12 + i] = real_t(0.0);
         if (th.tid == 0) io.status[inst] = 0;
@@ -600,8 +600,8 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         DWBC_SYNC();
         int row = 0;
         if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
-            const real_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
-            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = cj[idx];
+            const io_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
+            for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = (real_t)cj[idx];
         }
         for (int li = 0; li < su.t_nlinks[lv]; li++) {
             const int mode = su.t_mode[lv][li], link = su.t_link[lv][li];
@@ -1031,7 +1031,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             z6[r] = acc;
         }
         DWBC_SYNC();
-        real_t *tau = io.tau + (size_t)inst * 3 * M;
+        io_t *tau = io.tau + (size_t)inst * 3 * M;
         for (int i = th.tid; i < M; i += NT) {
             real_t g_, t_, c_;
             if (i < cod) {
@@ -1052,7 +1052,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             L[S::tg + i] = g_ + t_ + c_;
         }
         DWBC_SYNC();
-        real_t *wr = io.wrench + (size_t)inst * 12;
+        io_t *wr = io.wrench + (size_t)inst * 12;
         for (int i = th.tid; i < 12; i += NT) {
             real_t acc = real_t(0.0);
             if (i < cd) {

@@ -16,6 +16,7 @@
 namespace dwbc {
 
 typedef DWBC_REAL real_t;
+typedef double io_t;  // element type of every state / command / torque buffer at the boundary, whatever real_t is
 constexpr bool kF32 = sizeof(real_t) == 4;
 
 constexpr int kMaxBodies = 48;
@@ -130,17 +131,17 @@ struct DumpLayout {
     }
 };
 
-struct BatchIO {  // device pointers; floating-point buffers are real_t
+struct BatchIO {  // device pointers.  Inputs and outputs are io_t (double) in both builds; the model table and the dump are real_t
     int B;
-    const real_t *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
-    const real_t *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
+    const io_t *q;             // B x (N+1)   [x y z qx qy qz joints... qw]  (reference include/dwbc.h:251)
+    const io_t *qdot;          // B x N or nullptr: [v_world(3) w_body(3) joint rates]; only B_, link velocities and the task reference use it
     const unsigned char *flags;  // B x n_contacts
-    const real_t *fstar;         // B x fstar_total
-    const real_t *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
-    const real_t *ctime;         // B control times (RobotData::control_time_) or nullptr
-    const real_t *custom_J;      // B x n_custom x (kMaxTaskDof x N) row-major J_task of the TASK_CUSTOM levels, or nullptr
-    real_t *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
-    real_t *wrench;              // B x 12    : getContactForce(tau_total), zero padded
+    const io_t *fstar;         // B x fstar_total
+    const io_t *traj;          // B x n_traj x 34 trajectory records (dwbc_fstar.h) or nullptr
+    const io_t *ctime;         // B control times (RobotData::control_time_) or nullptr
+    const io_t *custom_J;      // B x n_custom x (kMaxTaskDof x N) row-major J_task of the TASK_CUSTOM levels, or nullptr
+    io_t *tau;                 // B x 3 x M : torque_grav_, torque_task_, torque_contact_
+    io_t *wrench;              // B x 12    : getContactForce(tau_total), zero padded
     int *status;                 // B         : 1 ok / 0 fail (reference int returns ANDed)
     int *diag;                   // B x DG_COUNT
     real_t *dump;                // B x DumpLayout::total or nullptr

@@ -26,7 +26,7 @@ DWBC_DEV void spatial_inertia_apply(real_t m, const real_t *c, const real_t *Ic,
 
 // Vout (nb x 6, [w; v_O]) stays in L + S::k_Rl for the caller (task-reference front end).
 template <class S, int N, int NB, int NT>
-DWBC_DEV void velocity_rnea(Thr th, const Setup &su, const real_t *qd, const real_t *body, const int *topo, real_t *L, real_t *Bout,
+DWBC_DEV void velocity_rnea(Thr th, const Setup &su, const io_t *qd, const real_t *body, const int *topo, real_t *L, real_t *Bout,
                             real_t *link_v, real_t *link_w) {
     const int nb = su.nb;
     const real_t *Sm = L + S::k_S, *Rw = L + S::Rw, *pw = L + S::pw;
@@ -35,9 +35,9 @@ DWBC_DEV void velocity_rnea(Thr th, const Setup &su, const real_t *qd, const rea
     for (int b = th.tid; b < nb; b += NT) {
         real_t v[6] = {0, 0, 0, 0, 0, 0};
         for (int j = 0; j < 6; j++)
-            for (int a = 0; a < 6; a++) v[a] += Sm[j * 6 + a] * qd[j];
+            for (int a = 0; a < 6; a++) v[a] += Sm[j * 6 + a] * (real_t)qd[j];
         for (int c = b; c > 0; c = su.parent[c])
-            for (int a = 0; a < 6; a++) v[a] += Sm[(c + 5) * 6 + a] * qd[c + 5];
+            for (int a = 0; a < 6; a++) v[a] += Sm[(c + 5) * 6 + a] * (real_t)qd[c + 5];
         for (int a = 0; a < 6; a++) V[b * 6 + a] = v[a];
         if (link_w) {
             const real_t d0 = pw[b * 3] - pw[0], d1 = pw[b * 3 + 1] - pw[1], d2 = pw[b * 3 + 2] - pw[2];
@@ -54,7 +54,7 @@ DWBC_DEV void velocity_rnea(Thr th, const Setup &su, const real_t *qd, const rea
         real_t c[6] = {0, 0, 0, 0, 0, 0};
         if (j >= 3) {
             const real_t *Vb = V + (j < 6 ? 0 : j - 5) * 6, *s = Sm + j * 6;
-            const real_t qj = qd[j];
+            const real_t qj = (real_t)qd[j];
             const real_t *w = Vb, *v = Vb + 3, *a = s, *bb = s + 3;
             c[0] = (w[1] * a[2] - w[2] * a[1]) * qj;
             c[1] = (w[2] * a[0] - w[0] * a[2]) * qj;

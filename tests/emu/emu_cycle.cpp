@@ -15,7 +15,7 @@
 
 using namespace dwbc;
 
-// inputs arrive as double; the kernel source runs in real_t (double, or float in libdwbc_emu_f32.so)
+// the boundary buffers are double (io_t) in both builds; the model table and the dump record are real_t (float in libdwbc_emu_f32.so)
 template <class T>
 static std::vector<real_t> to_real(const T *p, size_t n) {
     std::vector<real_t> v(p ? n : 0);
@@ -91,10 +91,11 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
     const int n = 39, m = 33;
     const size_t D = DumpLayout::make(n).total;
-    auto rq = to_real(q, (size_t)B * (n + 1)), rf = to_real(fstar, (size_t)B * c->su.fstar_total), rb = to_real(c->body.data(), c->body.size());
-    std::vector<real_t> rtau((size_t)B * 3 * m), rwr((size_t)B * 12), rdump(dump ? (size_t)B * D : 0);
+    (void)m;
+    auto rb = to_real(c->body.data(), c->body.size());
+    std::vector<real_t> rdump(dump ? (size_t)B * D : 0);
     BatchIO io{};
-    io.B = B; io.q = rq.data(); io.flags = flags; io.fstar = rf.data(); io.tau = rtau.data(); io.wrench = rwr.data(); io.status = status;
+    io.B = B; io.q = q; io.flags = flags; io.fstar = fstar; io.tau = tau; io.wrench = wrench; io.status = status;
     io.diag = diag; io.dump = dump ? rdump.data() : nullptr; io.body = rb.data(); io.topo = c->topo.data();
     std::vector<real_t> lds(LdsR<39, 34, 4>::rtotal + 64);
     std::vector<int> ilds(64);
@@ -105,7 +106,7 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
         else if (c->su.n_levels == 3) cycle_instance_reduced<39, 34, 3, 1>(th, c->su, io, b, lds.data(), ilds.data());
         else cycle_instance_reduced<39, 34, 4, 1>(th, c->su, io, b, lds.data(), ilds.data());
     }
-    from_real(rtau, tau); from_real(rwr, wrench); from_real(rdump, dump);
+    from_real(rdump, dump);
     return 1;
 }
 
@@ -127,21 +128,20 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
     const int n = 39, m = 33;
     const size_t D = DumpLayout::make(n).total;
-    auto rq = to_real(q, (size_t)B * (n + 1)), rf = to_real(fstar, (size_t)B * c->su.fstar_total), rb = to_real(c->body.data(), c->body.size());
-    auto rqd = to_real(g_emu_qdot, (size_t)B * n), rtr = to_real(g_emu_traj, (size_t)B * c->su.n_traj * kTrajStride);
-    auto rct = to_real(g_emu_ctime, (size_t)B), rcj = to_real(g_emu_custom, (size_t)B * c->su.n_custom * kMaxTaskDof * n);
-    std::vector<real_t> rtau((size_t)B * 3 * m), rwr((size_t)B * 12), rdump(dump ? (size_t)B * D : 0);
+    (void)m;
+    auto rb = to_real(c->body.data(), c->body.size());
+    std::vector<real_t> rdump(dump ? (size_t)B * D : 0);
     BatchIO io{};
     io.B = B;
-    io.q = rq.data();
-    io.qdot = g_emu_qdot ? rqd.data() : nullptr;
-    io.traj = (c->su.n_traj > 0 && g_emu_traj) ? rtr.data() : nullptr;
-    io.ctime = g_emu_ctime ? rct.data() : nullptr;
-    io.custom_J = (c->su.n_custom > 0 && g_emu_custom) ? rcj.data() : nullptr;
+    io.q = q;
+    io.qdot = g_emu_qdot;
+    io.traj = c->su.n_traj > 0 ? g_emu_traj : nullptr;
+    io.ctime = g_emu_ctime;
+    io.custom_J = c->su.n_custom > 0 ? g_emu_custom : nullptr;
     io.flags = flags;
-    io.fstar = rf.data();
-    io.tau = rtau.data();
-    io.wrench = rwr.data();
+    io.fstar = fstar;
+    io.tau = tau;
+    io.wrench = wrench;
     io.status = status;
     io.diag = diag;
     io.dump = dump ? rdump.data() : nullptr;
@@ -159,7 +159,7 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
         else if (c->su.n_levels == 3) cycle_instance_v2<39, 34, 3, 1>(th, c->su, io, b, lds.data(), ilds.data());
         else cycle_instance_v2<39, 34, 4, 1>(th, c->su, io, b, lds.data(), ilds.data());
     }
-    from_real(rtau, tau); from_real(rwr, wrench); from_real(rdump, dump);
+    from_real(rdump, dump);
     return 1;
 }
 }
