@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--workload", default="ds2", choices=["ds2", "ss3", "mixed", "reduced"],
                     help="ds2 = BASELINE configs[1] (the metric's config, default); ss3 / mixed / reduced = configs[2] / [3] / [4] "
                          "(parity-test cases; measured for DESIGN.md only)")
+    ap.add_argument("--no-hqp", action="store_true", help="hqp = false: plain hierarchy + closed-form redistribution (DESIGN.md only)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="arithmetic type of the kernels (f32: measured for DESIGN.md only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -118,7 +119,7 @@ def main():
         return out
 
     for _ in range(args.warmup):
-        wbc.solve(reduced=reduced)
+        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
     gather_final()
     torch.cuda.synchronize()
     if world > 1:
@@ -126,7 +127,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wbc.solve(reduced=reduced)
+        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
     gather_final()
     torch.cuda.synchronize()
     if world > 1:
@@ -143,7 +144,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream)
     for _ in range(args.steps):
-        wbc.solve(reduced=reduced)
+        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
     ev1.record(stream)
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
@@ -166,7 +167,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": workload_name,
+                "workload": workload_name + (" [hqp = false]" if args.no_hqp else ""),
                 "batch_per_gpu": B,
                 "threads_per_instance": nt,
                 "lds_bytes_per_instance": lds,

@@ -8,7 +8,7 @@
 //   * every Calc* call launches the fused kernel (CalcContactConstraint .. CalcContactRedistribute are one launch on the
 //     device) and refreshes all public fields, so the reference's call order yields the reference's values; a loop that
 //     only needs the final torque should call CalcAll() once per tick;
-//   * only what the device path implements: floating base, CONTACT_6D, link tasks (TASK_LINK_*), hqp = true.
+//   * only what the device path implements: floating base, CONTACT_6D, link / COM tasks (TASK_LINK_*), hqp = true or false.
 //
 // Reference API mirrored: include/dwbc.h:59-430 (method names, argument order, int 1/0 returns, std::cout messages).
 #pragma once
@@ -196,8 +196,9 @@ class RobotData {
     int CalcContactConstraint() { return refresh() ? diag_[0] : 0; }
     Vec CalcGravCompensation() { refresh(); return torque_grav_; }
     int CalcTaskControlTorque(bool hqp = true, bool init = true, bool = true) {
-        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        if (hqp != hqp_) { hqp_ = hqp; dirty_ = true; }  // hqp = false: plain hierarchy, no QP (dwbc.cpp:856-873)
         if (!refresh(init)) return 0;
+        if (!hqp) { torque_contact_.assign(model_dof_, 0.0); redistributed_ = false; return diag_[1]; }
         // torque_contact_ = NwJw * contact_qp_(last level) at this point of the reference sequence (dwbc.cpp:851)
         const int k = contact_dof_ > 6 ? (int)contact_dof_ - 6 : 0;
         torque_contact_.assign(model_dof_, 0.0);
@@ -208,7 +209,7 @@ class RobotData {
         return diag_[1];
     }
     int CalcContactRedistribute(bool hqp = true, bool init = true) {
-        if (!hqp) { std::cout << "libdwbc_amd : hqp=false is not on the device path" << std::endl; return 0; }
+        if (hqp != hqp_) { hqp_ = hqp; dirty_ = true; }  // hqp = false: closed-form ContactRedistributetwomod (dwbc.cpp:1570-1619)
         if (!refresh(init)) return 0;
         torque_contact_ = tau_contact_final_;
         redistributed_ = true;
@@ -268,7 +269,7 @@ class RobotData {
     dwbc_model *model_ = nullptr;
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
-    bool dirty_ = true, redistributed_ = false, reduced_ = false;
+    bool dirty_ = true, redistributed_ = false, reduced_ = false, hqp_ = true;
     double sent_time_ = -1.0e300;
     void reduced_on() { if (!reduced_) { reduced_ = true; dirty_ = true; } }
     int diag_[96] = {0};
@@ -301,7 +302,7 @@ class RobotData {
             }
         if (control_time_ != sent_time_) { dwbc_batch_set_control_time(batch_, &control_time_); sent_time_ = control_time_; dirty_ = true; }
         if (!dirty_) return 1;
-        if (!dwbc_batch_solve(batch_, DWBC_SOLVE_HQP | (init ? DWBC_SOLVE_INIT : 0) | (reduced_ ? DWBC_SOLVE_REDUCED : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        if (!dwbc_batch_solve(batch_, (hqp_ ? DWBC_SOLVE_HQP : 0) | (init ? DWBC_SOLVE_INIT : 0) | (reduced_ ? DWBC_SOLVE_REDUCED : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         const int n = system_dof_, m = model_dof_, cd = contact_dof_, k = cd > 6 ? cd - 6 : 0;
         std::vector<double> tau(3 * m);
         dwbc_batch_get(batch_, DWBC_TAU, tau.data(), tau.size() * 8);

@@ -35,7 +35,9 @@ enum {
 /* arithmetic type of the kernels.  DWBC_F32 runs the same kernel source in single precision; every buffer at this boundary
  * (host arrays, bound device buffers) stays double and is converted inside the kernel.  Accuracy envelope: DESIGN.md §8 */
 enum { DWBC_F64 = 0, DWBC_F32 = 1 };
-/* DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
+/* DWBC_SOLVE_HQP: CalcTaskControlTorque(hqp) / CalcContactRedistribute(hqp) with hqp = true (the QP cascade); without the bit the
+ * plain hierarchy and the closed-form two-contact redistribution run (src/dwbc.cpp:856-873, 1570-1619), full model only.
+ * DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
  * ReducedCalcGravCompensation, ReducedCalcTaskSpace, ReducedCalcTaskControlTorque, ReducedCalcContactRedistribute --
  * reference include/dwbc.h:411-416, tests/sp_test/redu_dyn_test.cpp:263-298) instead of the full-model sequence */
 enum { DWBC_SOLVE_HQP = 1, DWBC_SOLVE_INIT = 2, DWBC_SOLVE_REDUCED = 4 };

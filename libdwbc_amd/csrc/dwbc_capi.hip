@@ -68,6 +68,7 @@ struct dwbc_batch {
     float *f_body = nullptr;
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
     int f32_lds = 0, f32_key = -1;
+    int hqp = 1;
     bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
     // host mirrors of the inputs
     std::vector<double> h_q, h_fstar;
@@ -467,6 +468,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
         float *dump;
         const float *body;
         const int *topo;
+        int hqp;
     } io{};
     static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
     io.B = b->B;
@@ -484,6 +486,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     io.dump = nullptr;
     io.body = b->f_body;
     io.topo = b->d_topo;
+    io.hqp = b->hqp;
     const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     void *args[] = {(void *)&b->su, (void *)&io};
     HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, b->f32_lds, b->stream));
@@ -514,6 +517,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.dump = b->dump_on ? b->d_dump : nullptr;
     io.body = b->d_body;
     io.topo = b->d_topo;
+    io.hqp = b->hqp;
     if (!b->attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
         if (b->kern->fn_wide)
@@ -530,7 +534,9 @@ static int launch(dwbc_batch *b, bool reduced = false) {
 }
 
 int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
-    if (!(flags & DWBC_SOLVE_HQP)) return fail("hqp=false (closed-form ContactRedistributetwomod) is not on the device path");
+    b->hqp = (flags & DWBC_SOLVE_HQP) ? 1 : 0;
+    if (!b->hqp && (flags & DWBC_SOLVE_REDUCED)) return fail("hqp=false is not built on the reduced dynamics path");
+    if (!b->hqp && getenv("DWBC_KERNEL") && std::string(getenv("DWBC_KERNEL")) == "v1") return fail("hqp=false needs the default kernel");
     if (b->su.n_levels < 1) return fail("no task space");
     if (b->su.n_contacts < 1) return fail("no contact constraint");
     const bool reduced = flags & DWBC_SOLVE_REDUCED;

@@ -12,6 +12,7 @@
 #include "dwbc_cycle.h"
 #include "dwbc_velocity.h"
 #include "dwbc_fstar.h"
+#include "dwbc_nohqp.h"
 
 namespace dwbc {
 
@@ -33,7 +34,8 @@ struct Lds2 {
     static constexpr int Rc = PC + C;
     static constexpr int Pc = Rc + kMaxActiveContacts * 9;
     static constexpr int fs = Pc + kMaxActiveContacts * 3;    // f* of every level (SetTaskSpace values or the on-device task reference)
-    static constexpr int JbT = fs + kMaxLevels * kMaxTaskDof;  // C x N            (written from stage 1 on)
+    static constexpr int comp = fs + kMaxLevels * kMaxTaskDof; // com_pos (3 + pad), written for hqp = false only
+    static constexpr int JbT = comp + 4;  // C x N            (written from stage 1 on)
     static constexpr int NwJw = JbT + C * N;                   // M x K
     static constexpr int FNl = NwJw + M * K;                   // C x K
     static constexpr int U = FNl + C * K;                      // levels x (M x T)
@@ -611,12 +613,26 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
+        if (!is_task && !io.hqp) {          // CalcContactRedistribute(hqp = false): closed form (dwbc.cpp:1570-1619)
+            st_redis = redistribute_closed_form<S, N, NB, NT>(th, L, JbT, cd, k);
+            break;
+        }
         if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
         const int t = is_task ? su.t_dof[qi] : 0;
         const FastDiv fdt1(t + 1);
         const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
+        if (is_task && !io.hqp) {  // CalcTaskControlTorque(hqp = false): torque_task_ += Null_{i-1} J_kt Lambda f* (dwbc.cpp:856-873)
+            DWBC_SYNC();
+            for (int i = th.tid; i < M; i += NT) {
+                real_t acc = real_t(0.0);
+                for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j];
+                L[S::tt + i] += acc;
+            }
+            DWBC_SYNC();
+            continue;
+        }
         DWBC_SYNC();
         for (int i = th.tid; i < M; i += NT) {
             real_t acc = L[S::tg + i] + L[S::tt + i];

@@ -147,6 +147,8 @@ struct BatchIO {  // device pointers.  Inputs and outputs are io_t (double) in b
     real_t *dump;                // B x DumpLayout::total or nullptr
     const real_t *body;          // nb x kBodyStride
     const int *topo;             // parent[nb], depth[nb], subtree[nb]
+    int hqp;                     // 1: CalcTaskControlTorque / CalcContactRedistribute with hqp = true (QPs); 0: plain hierarchy +
+                                 // closed-form redistribution (dwbc_nohqp.h)
 };
 
 }  // namespace dwbc

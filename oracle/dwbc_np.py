@@ -691,3 +691,108 @@ def link_velocities(model, R, p, qd):
         w[i] = J[3:] @ qd
         vi[i] = v[i] + np.cross(w[i], R[i] @ model["com"][i])
     return v, w, vi
+
+
+# ----------------------------------------------------------------------------------------------
+# hqp = false: plain hierarchy + closed-form two-contact redistribution (reference src/dwbc.cpp:856-873, 1570-1619,
+# src/wbd.cpp:273-404).  PARITY UNPINNED (no fixture; link_[0].rpy comes from Eigen's eulerAngles [ext]).
+# ----------------------------------------------------------------------------------------------
+def euler_angles_zyx(m):
+    """Eigen MatrixBase::eulerAngles(2, 1, 0) (Eigen >= 3.3 [ext]): (a0 about Z in [0, pi], a1 about Y, a2 about X)"""
+    r0 = np.arctan2(m[1, 0], m[0, 0])
+    c2 = np.hypot(m[2, 2], m[2, 1])
+    if r0 < 0.0:
+        r0 += np.pi
+        r1 = np.arctan2(-m[2, 0], -c2)
+    else:
+        r1 = np.arctan2(-m[2, 0], c2)
+    s1, c1 = np.sin(r0), np.cos(r0)
+    r2 = np.arctan2(s1 * m[0, 2] - c1 * m[1, 2], c1 * m[1, 1] - s1 * m[0, 1])
+    return np.array([r0, r1, r2])
+
+
+def rotate_with_z(a):
+    return np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+
+
+def contact_redistribute_two_mod(eta_cust, footlength, footwidth, mu_s, ratio_x, ratio_y, P1, P2, F12):
+    """ContactRedistributetwomod (src/wbd.cpp:273-404) -> (ForceRedistribution (12), eta)"""
+    W = np.zeros((6, 12))
+    W[:, :6] = np.eye(6)
+    W[:, 6:] = np.eye(6)
+    W[3:, 0:3] = skew(P1)
+    W[3:, 6:9] = skew(P2)
+    Rf = W @ F12
+    lb, ub = 1.0 - eta_cust, eta_cust
+
+    def bound(A, B, C, lb, ub):
+        a, b, c = A * A, 2.0 * A * B, B * B - C * C
+        with np.errstate(all="ignore"):
+            disc = np.sqrt(b * b - 4.0 * a * c)
+            s1, s2 = (-b + disc) / 2.0 / a, (-b - disc) / 2.0 / a
+        hi, lo = (s1, s2) if s1 > s2 else (s2, s1)
+        if hi < ub:
+            ub = hi
+        if lo > lb:
+            lb = lo
+        return lb, ub
+
+    d = P1 - P2
+    lb, ub = bound(d[2] * Rf[1] - d[1] * Rf[2], Rf[3] + P2[2] * Rf[1] - P2[1] * Rf[2], ratio_y * footwidth / 2.0 * abs(Rf[2]), lb, ub)
+    lb, ub = bound(-d[2] * Rf[0] + d[0] * Rf[2], Rf[4] - P2[2] * Rf[0] + P2[0] * Rf[2], ratio_x * footlength / 2.0 * abs(Rf[2]), lb, ub)
+    lb, ub = bound(-d[0] * Rf[1] + d[1] * Rf[0], Rf[5] + P2[1] * Rf[0] - P2[0] * Rf[1], mu_s * abs(Rf[2]), lb, ub)
+    with np.errstate(all="ignore"):
+        eta_s = (-Rf[3] - P2[2] * Rf[1] + P2[1] * Rf[2]) / (d[2] * Rf[1] - d[1] * Rf[2])
+    eta = eta_s
+    if eta_s > ub:
+        eta = ub
+    elif eta_s < lb:
+        eta = lb
+    if (eta > eta_cust) or (eta < 1.0 - eta_cust) or not np.isfinite(eta):
+        eta = 0.5
+    A3, B3 = d[2] * Rf[1] - d[1] * Rf[2], Rf[3] + P2[2] * Rf[1] - P2[1] * Rf[2]
+    A4, B4 = -d[2] * Rf[0] + d[0] * Rf[2], Rf[4] - P2[2] * Rf[0] + P2[0] * Rf[2]
+    A5, B5 = -d[0] * Rf[1] + d[1] * Rf[0], Rf[5] + P2[1] * Rf[0] - P2[0] * Rf[1]
+    out = np.zeros(12)
+    out[0:3] = eta * Rf[0:3]
+    out[3], out[4], out[5] = A3 * eta * eta + B3 * eta, A4 * eta * eta + B4 * eta, A5 * eta * eta + B5 * eta
+    out[6:9] = (1.0 - eta) * Rf[0:3]
+    out[9], out[10], out[11] = (1.0 - eta) * (A3 * eta + B3), (1.0 - eta) * (A4 * eta + B4), (1.0 - eta) * (A5 * eta + B5)
+    return out, eta
+
+
+def run_no_hqp(cyc, q, flags, fstars):
+    """UpdateKinematics .. CalcTaskControlTorque(false) .. CalcContactRedistribute(false) on a Cycle object"""
+    cyc.update_kinematics(q)
+    cyc.set_contact(flags)
+    ok = cyc.calc_contact_constraint()
+    cyc.calc_grav()
+    m = cyc.m
+    L = len(cyc.tasks)
+    AiNc = cyc.A_inv @ cyc.N_C
+    cyc.tau_task = np.zeros(m)
+    null_prev = np.eye(m)
+    for i in range(L):  # CalcTaskSpace + the hqp = false branch of CalcTaskControlTorque (dwbc.cpp:856-873)
+        Jt = cyc.task_jacobian(i)
+        lam = np.linalg.inv(Jt @ AiNc @ Jt.T)
+        Q = (lam @ Jt @ AiNc)[:, 6:]
+        Jkt = cyc.W_inv @ Q.T @ pinv_cod(Q @ cyc.W_inv @ Q.T)
+        cyc.tau_task = cyc.tau_task + null_prev @ (Jkt @ lam @ np.asarray(fstars[i], float))
+        null_prev = null_prev @ (np.eye(m) - Jkt @ lam @ Jt @ cyc.A_inv_N_C[:, 6:])
+    cyc.tau_contact = np.zeros(m)
+    if cyc.cdof != 12:  # dwbc.cpp:1612-1617
+        cyc.status = 0
+        return cyc.tau_grav + cyc.tau_task
+    tau_in = cyc.tau_grav + cyc.tau_task
+    cf = cyc.J_C_INV_T[:, 6:] @ tau_in - cyc.P_C
+    xc = [cyc.p[cc["link"]] + cyc.R[cc["link"]] @ cc["point"] for cc in cyc.act_contacts]
+    Ry = rotate_with_z(-euler_angles_zyx(cyc.R[0])[2])  # sic: rpy(2) of eulerAngles(2,1,0) is the angle about X (dwbc.cpp:1580)
+    F12 = np.concatenate([Ry @ cf[0:3], Ry @ cf[3:6], Ry @ cf[6:9], Ry @ cf[9:12]])
+    red, eta = contact_redistribute_two_mod(0.99, 0.26, 0.1, 1.0, 0.9, 0.9, Ry @ (xc[0] - cyc.com), Ry @ (xc[1] - cyc.com), F12)
+    fc = np.concatenate([Ry.T @ red[0:3], Ry.T @ red[3:6], Ry.T @ red[6:9], Ry.T @ red[9:12]])
+    desired = -cf[6:12] + fc[6:12]
+    V2t = cyc.V2.T
+    cyc.tau_contact = V2t @ np.linalg.solve(cyc.J_C_INV_T[6:12, 6:] @ V2t, desired)
+    cyc.eta = eta
+    cyc.status = int(ok)
+    return cyc.tau_grav + cyc.tau_task + cyc.tau_contact

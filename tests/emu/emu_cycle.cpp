@@ -96,7 +96,7 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     std::vector<real_t> rdump(dump ? (size_t)B * D : 0);
     BatchIO io{};
     io.B = B; io.q = q; io.flags = flags; io.fstar = fstar; io.tau = tau; io.wrench = wrench; io.status = status;
-    io.diag = diag; io.dump = dump ? rdump.data() : nullptr; io.body = rb.data(); io.topo = c->topo.data();
+    io.diag = diag; io.dump = dump ? rdump.data() : nullptr; io.body = rb.data(); io.topo = c->topo.data(); io.hqp = 1;
     std::vector<real_t> lds(LdsR<39, 34, 4>::rtotal + 64);
     std::vector<int> ilds(64);
     for (int b = 0; b < B; b++) {
@@ -110,6 +110,8 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     return 1;
 }
 
+static int g_emu_hqp = 1;
+void emu_set_hqp(int hqp) { g_emu_hqp = hqp; }
 static const double *g_emu_custom = nullptr;
 int emu_add_custom_task(EmuCtx *c, int level, int dof) { return setup_add_custom_task(c->su, level, dof, c->err) ? 1 : 0; }
 void emu_set_custom(const double *J) { g_emu_custom = J; }
@@ -147,6 +149,7 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.dump = dump ? rdump.data() : nullptr;
     io.body = rb.data();
     io.topo = c->topo.data();
+    io.hqp = g_emu_hqp;
     std::vector<real_t> lds(Lds<39, 34>::total + Lds2<39, 34, 4>::total + 64);
     std::vector<int> ilds(64);
     const char *kv = getenv("DWBC_KERNEL");

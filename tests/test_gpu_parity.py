@@ -340,3 +340,27 @@ def test_gpu_copy_kinematics_data():
     assert (dst.get("status") == src.get("status")).all()
     assert np.abs(dst.get("tau") - src.get("tau")).max() == 0.0
     assert np.abs(dst.get("wrench") - src.get("wrench")).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_hqp_false_vs_oracle():
+    """hqp = false: plain hierarchy + closed-form redistribution (reference src/dwbc.cpp:856-873, 1570-1619)"""
+    import libdwbc_amd as D
+    from tests.test_kernel_emulation import _no_hqp_oracle
+
+    B = 32
+    q, fl, fs = cases.synth_batch(B, seed=72, yaw=True)
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar_all(fs)
+    wbc.solve(hqp=False)
+    tau, st = _no_hqp_oracle(q, fl, fs)
+    assert (wbc.get("status") == st).all()
+    assert np.abs(wbc.get("tau") - tau).max() < 1e-6
+    wbc.solve(hqp=True)  # and back
+    assert wbc.get("status").mean() > 0.9

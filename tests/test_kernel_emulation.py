@@ -176,3 +176,40 @@ def test_emulated_zmp_and_contact_frames():
         zmp, zs = c.get_zmp(c.contact_force(tau))
         assert np.abs(z[b, 0] - zmp).max() < 1e-7 and np.abs(z[b, 1] - zs[0]).max() < 1e-7 and np.abs(z[b, 2] - zs[1]).max() < 1e-7
         assert np.abs(cp[b, 0] - (c.p[6] + c.R[6] @ np.array(cases.FOOT_POINT))).max() < 1e-12
+
+
+def _no_hqp_oracle(q, fl, fs):
+    from oracle import dwbc_np as Dn
+
+    B = q.shape[0]
+    tau, st = np.zeros((B, 3, 33)), np.zeros(B, np.int32)
+    for b in range(B):
+        c = Dn.Cycle(cases.tocabi_model())
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.add_task(0, 0, 0)
+        c.add_task(1, 6, 15)
+        Dn.run_no_hqp(c, q[b], list(fl[b]), [fs[b, :6], fs[b, 6:]])
+        tau[b] = [c.tau_grav, c.tau_task, c.tau_contact]
+        st[b] = c.status
+    return tau, st
+
+
+@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "mixed"])
+def test_emulated_kernel_hqp_false(cfg):
+    """CalcTaskControlTorque(false) + CalcContactRedistribute(false): plain hierarchy and the closed-form two-contact
+    redistribution (reference src/dwbc.cpp:856-873, 1570-1619, src/wbd.cpp:273-404); PARITY UNPINNED in the reference"""
+    B = 16
+    kw = dict(seed=71)
+    if cfg == "ds_yaw":
+        kw["yaw"] = True
+    elif cfg == "mixed":
+        kw["contact_mode"] = "mixed"
+    q, fl, fs = cases.synth_batch(B, **kw)
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, None)
+    r = e.run(q, fl, fs, hqp=False)
+    tau, st = _no_hqp_oracle(q, fl, fs)
+    assert (r["status"] == st).all()  # single support returns 0 from CalcContactRedistribute(false) (dwbc.cpp:1612-1617)
+    assert np.abs(r["tau"] - tau).max() < 1e-6
+    if cfg != "mixed":
+        assert np.abs(tau[:, 2]).max() > 1.0
