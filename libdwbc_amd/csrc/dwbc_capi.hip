@@ -15,7 +15,7 @@
 
 using namespace dwbc;
 
-extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, const void **fn, const void **fn_wide, int *lds_bytes);
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, const void **fn, const void **fn_wide, int *lds_bytes);
 
 // DWBC_F32 batches: the fp32 kernels (dwbc_kernels_f32.hip) work on the double buffers of the boundary; the model table is
 // converted to float once
@@ -430,6 +430,11 @@ static int upload_inputs(dwbc_batch *b) {
     return 1;
 }
 
+// the lean instantiation (EXTRAS = false) serves every launch that uses none of the optional paths
+static bool lean_ok(const dwbc_batch *b) {
+    return b->hqp && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !(b->dump_on && b->d_qdot) && !getenv("DWBC_NO_LEAN");
+}
+
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const char *kv = getenv("DWBC_KERNEL");
     const int which = reduced ? 2 : ((kv && std::string(kv) == "v1") ? 1 : 0);
@@ -440,9 +445,10 @@ static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
 // kept in float
 static int launch_f32(dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
-    const int key = which * 16 + b->su.n_levels;
+    const int lean = lean_ok(b) ? 1 : 0;
+    const int key = (which * 16 + b->su.n_levels) * 2 + lean;
     if (key != b->f32_key) {
-        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds))
+        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, lean, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds))
             return fail("no fp32 kernel for this model / number of task levels");
         HIP_OK(hipFuncSetAttribute(b->f32_fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
         if (b->f32_fn_wide) HIP_OK(hipFuncSetAttribute(b->f32_fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
@@ -519,16 +525,17 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.topo = b->d_topo;
     io.hqp = b->hqp;
     if (!b->attr_set) {
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
-        if (b->kern->fn_wide)
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn_wide), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
+        for (auto fn : {b->kern->fn, b->kern->fn_wide, b->kern->fn_lean, b->kern->fn_wide_lean})
+            if (fn) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, b->device));
         b->n_cu = prop.multiProcessorCount;
         b->attr_set = true;
     }
     const bool wide = b->kern->fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
-    hipLaunchKernelGGL(wide ? b->kern->fn_wide : b->kern->fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
+    const bool lean = b->kern->fn_lean && lean_ok(b);
+    auto fn = wide ? (lean ? b->kern->fn_wide_lean : b->kern->fn_wide) : (lean ? b->kern->fn_lean : b->kern->fn);
+    hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -753,7 +760,7 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     const bool wide = !v1 && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
     name = v1 ? "dwbc_cycle_kernel<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", 64>"
               : std::string(wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + std::to_string(ke->n) + ", " +
-                    std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+                    std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64" + (v1 ? "" : (ke->fn_lean && lean_ok(b) ? ", false" : ", true")) + ">";
     name = pre + name;
     return name.c_str();
 }

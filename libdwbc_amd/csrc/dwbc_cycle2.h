@@ -274,9 +274,13 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     return ok;
 }
 
-template <int N, int NB, int NLV, int NT>
+// EXTRAS = false compiles the optional paths out (task-link trajectories, qdot outputs, COM / TASK_CUSTOM levels, hqp = false):
+// merely having them inlined costs the common cycle 2 % (register allocation around the 39-column register matrix), so the
+// launcher picks the lean instantiation whenever none of them is in use.
+template <int N, int NB, int NLV, int NT, bool EXTRAS = true>
 DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
     using S = Lds2<N, NB, NLV>;
+    constexpr bool kExtras = EXTRAS;
     constexpr int M = S::M, C = S::C, T = S::T;
     DWBC_LANE_DECL;
     (void)iL;
@@ -376,7 +380,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = real_t(0.0);
         DWBC_SYNC();
         int row = 0;
-        if (su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
+        if (kExtras && su.t_custom_slot[lv] >= 0 && io.custom_J) {  // TASK_CUSTOM: J_task handed over by SetTaskSpace(h, f*, J) (dwbc.cpp:664-681)
             const io_t *cj = io.custom_J + ((size_t)inst * su.n_custom + su.t_custom_slot[lv]) * (T * N);
             for (int idx = th.tid; idx < t * N; idx += NT) Jtt[(idx % N) * T + idx / N] = (real_t)cj[idx];
         }
@@ -388,7 +392,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             else if (mode == TASK_LINK_6D_CUSTOM_FRAME || mode == TASK_LINK_POSITION_CUSTOM_FRAME)
                 for (int a = 0; a < 3; a++) pl[a] = su.t_point[lv][li][a];
             const int rsel = mode <= TASK_LINK_6D_CUSTOM_FRAME ? 0 : (mode <= TASK_LINK_POSITION_CUSTOM_FRAME ? 1 : 2);
-            if (link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
+            if (kExtras && link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
                 com_task_rows<N, NT>(th, L + S::Jcm, Jtt, row, rsel, T);
             } else {
                 const real_t *R = L + S::Rw + link * 9;
@@ -613,7 +617,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
-        if (!is_task && !io.hqp) {          // CalcContactRedistribute(hqp = false): closed form (dwbc.cpp:1570-1619)
+        if (kExtras && !is_task && !io.hqp) {          // CalcContactRedistribute(hqp = false): closed form (dwbc.cpp:1570-1619)
             st_redis = redistribute_closed_form<S, N, NB, NT>(th, L, JbT, cd, k);
             break;
         }
@@ -623,7 +627,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
-        if (is_task && !io.hqp) {  // CalcTaskControlTorque(hqp = false): torque_task_ += Null_{i-1} J_kt Lambda f* (dwbc.cpp:856-873)
+        if (kExtras && is_task && !io.hqp) {  // CalcTaskControlTorque(hqp = false): torque_task_ += Null_{i-1} J_kt Lambda f* (dwbc.cpp:856-873)
             DWBC_SYNC();
             for (int i = th.tid; i < M; i += NT) {
                 real_t acc = real_t(0.0);

@@ -142,14 +142,14 @@ DWBC_DEV void link_fstar(int mode, real_t t, const real_t *tr, const real_t *g, 
 
 // fills L[S::fs ..) with this instance's f* (SetTaskSpace values, overridden per link by the trajectories).  Vb: the
 // (nb x 6) body velocities [w; v_O] of velocity_rnea(), or nullptr for zero velocity.
-template <class S, int N, int NB, int NT>
+template <class S, int N, int NB, int NT, bool kExtras = true>
 DWBC_DEV void task_reference(Thr th, const Setup &su, const BatchIO &io, int inst, const real_t *body, real_t *L, const real_t *Vb) {
     real_t *fs = L + S::fs;
     const io_t *qd = io.qdot ? io.qdot + (size_t)inst * N : nullptr;
     const io_t *fin = io.fstar + (size_t)inst * su.fstar_total;
     for (int i = th.tid; i < su.fstar_total; i += NT) fs[i] = (real_t)fin[i];
     DWBC_SYNC();
-    if (!io.traj || su.n_traj == 0) return;
+    if (!kExtras || !io.traj || su.n_traj == 0) return;
     const real_t tnow = io.ctime ? (real_t)io.ctime[inst] : real_t(0.0);
     for (int idx = th.tid; idx < kMaxLevels * kMaxTaskLinks; idx += NT) {
         const int lv = idx / kMaxTaskLinks, li = idx - lv * kMaxTaskLinks;

@@ -32,12 +32,13 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const Ba
     if (inst >= io.B) return;                                                            \
     Thr th{(int)threadIdx.x};                                                            \
     int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
-    cycle_instance_v2<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
-template <int N, int NB, int NLV, int NT>
+    cycle_instance_v2<N, NB, NLV, NT, EXTRAS>(th, su, io, inst, lds, iL);
+// EXTRAS: see cycle_instance_v2 -- false = the lean build the launcher uses when no optional path is requested
+template <int N, int NB, int NLV, int NT, bool EXTRAS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
-template <int N, int NB, int NLV, int NT>
+template <int N, int NB, int NLV, int NT, bool EXTRAS>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
@@ -61,36 +62,43 @@ struct KernelEntry {
     void (*fn)(const Setup, const BatchIO);
     int lds_bytes;
     void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
+    void (*fn_lean)(const Setup, const BatchIO);       // the same two without the optional paths (EXTRAS = false), or nullptr
+    void (*fn_wide_lean)(const Setup, const BatchIO);
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
 // index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 #ifdef DWBC_EXPERIMENT
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true>,
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false>},
 };
 const KernelEntry kKernelsReduced[] = {
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
 };
 #else
 const KernelEntry kKernels[] = {
-    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT>},
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT>},
-    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT>},
-    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT>},
+    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, true>,
+     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false>},
+    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true>,
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false>},
+    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, true>,
+     dwbc_cycle_kernel_v2<39, 34, 3, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false>},
+    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, true>,
+     dwbc_cycle_kernel_v2<39, 34, 4, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, false>},
 };
 const KernelEntry kKernelsReduced[] = {
-    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr},
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr},
-    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr},
-    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr},
+    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
 #ifdef DWBC_EXPERIMENT
-const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr}};
+const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr}};
 #else
 const KernelEntry kKernelsV1[] = {
-    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr},
+    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
 

@@ -6,11 +6,12 @@
 #include "dwbc_kernels.h"
 #undef dwbc
 
-extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, const void **fn, const void **fn_wide, int *lds_bytes) {
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, const void **fn, const void **fn_wide, int *lds_bytes) {
     const dwbc_f32::KernelEntry *k = dwbc_f32::lookup_kernel(n, nb, nlv, which);
     if (!k || !k->fn) return 0;
-    *fn = reinterpret_cast<const void *>(k->fn);
-    *fn_wide = reinterpret_cast<const void *>(k->fn_wide);
+    const bool ln = lean && k->fn_lean;
+    *fn = reinterpret_cast<const void *>(ln ? k->fn_lean : k->fn);
+    *fn_wide = reinterpret_cast<const void *>(ln ? k->fn_wide_lean : k->fn_wide);
     *lds_bytes = k->lds_bytes;
     return 1;
 }

@@ -262,6 +262,7 @@ template <int N, int NB, int NLV, int NT>
 DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
     using S = LdsR<N, NB, NLV>;
     constexpr int M = S::M, C = S::C, T = S::T, RSX = S::RSX, RMX = S::RMX, NCX = S::NCX;
+    constexpr bool kExtras = true;
     DWBC_LANE_DECL;
     (void)iL;
     const int nb = su.nb;
