@@ -432,7 +432,7 @@ static int upload_inputs(dwbc_batch *b) {
 
 // the lean instantiation (EXTRAS = false) serves every launch that uses none of the optional paths
 static bool lean_ok(const dwbc_batch *b) {
-    return b->hqp && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !(b->dump_on && b->d_qdot) && !getenv("DWBC_NO_LEAN");
+    return b->hqp && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !b->dump_on && !getenv("DWBC_NO_LEAN");
 }
 
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {

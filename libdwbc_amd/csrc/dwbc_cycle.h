@@ -50,7 +50,13 @@
 #define DWBC_SYNC() ((void)0)
 #else
 #define DWBC_DEV __device__ __forceinline__
-#define DWBC_DEVN __device__ __noinline__  /* shared helpers: keep the kernel inside the instruction cache */
+#ifdef DWBC_OUTLINE_HELPERS
+#define DWBC_DEVN __device__ __noinline__
+#else
+// shared helpers are inlined too: a call forces the live register-resident matrix columns through the callee-saved / spill
+// machinery, which costs more than the code growth (138.5 vs 142.2 us per launch at B = 1024; +4 % at B >= 8192)
+#define DWBC_DEVN __device__ __forceinline__
+#endif
 #define DWBC_SYNC() __syncthreads()
 #endif
 
@@ -555,7 +561,7 @@ DWBC_DEV void com_task_rows(Thr th, const real_t *Jcm, real_t *Jtt, int row0, in
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053)
 // W1/W2/fv are the contact wrench maps already rotated into the contact frames (A_rot applied).
 // ----------------------------------------------------------------------------------------------
-template <int N, int NB>
+template <int N, int NB, int WS = 1>
 DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone, int ci0, int ci1, const real_t *P1, int ld1,
                                 int t1, const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1,
                                 const real_t *W2, int ldw2, const real_t *fv, const real_t *base, int tvars, int max_iter,
@@ -606,7 +612,7 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
             LV(R.id_hi) = nlim + rr;
         }
     }
-    qp_solve_wave<0>(R, nv, tvars, max_iter, res, Vlds);
+    qp_solve_wave<WS>(R, nv, tvars, max_iter, res, Vlds);
     LANES {
         if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }

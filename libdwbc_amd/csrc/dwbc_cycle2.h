@@ -289,7 +289,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
     const io_t *qin = io.q + (size_t)inst * (N + 1);
     const DumpLayout dl = DumpLayout::make(N);
-    real_t *dump = io.dump ? io.dump + (size_t)inst * dl.total : nullptr;
+    real_t *dump = (EXTRAS && io.dump) ? io.dump + (size_t)inst * dl.total : nullptr;  // the lean build has no dump record
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
     DWBC_STAMP_INIT();
 
@@ -677,7 +677,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const int ld1 = is_task ? T : k, n1 = is_task ? t : k, n2 = is_task ? k : 0;
             const real_t *W1 = is_task ? F : L + S::FNl;
             const int ldw1 = is_task ? kQpLd : k;
-            qp_rows_and_solve<N, NB>(su, L, nlim, ncone, act_c[0], act_c[1], P1, ld1, n1, L + S::NwJw, k, n2,
+            qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, ld1, n1, L + S::NwJw, k, n2,
                                      is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, k, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
         }
@@ -685,7 +685,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (diag && th.tid == 0) {
             diag[DG_QP_ITER + slot] = qres.iters;
             diag[DG_QP_NACT + slot] = qres.nact;
-            for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + slot * kQpLd + a] = qres.act[a];
+            if (EXTRAS)  // working sets: diagnostics of the full build only
+                for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + slot * kQpLd + a] = qres.act[a];
         }
         if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)

@@ -66,7 +66,8 @@ DWBC_WDEV real_t upick12(const real_t *a, int idx) {
         LV(c)[i] = (i < (KK)) ? sgw * wsc * LV(R.g)[((TT) + i) < kQpN ? (TT) + i : 0]                     \
                               : ((i < (KK) + (TT)) ? sgw * LV(R.g)[(i - (KK)) >= 0 ? i - (KK) : 0] : real_t(0.0));
 
-template <int DUMMY>
+// WS != 0: report the working set (reference row indices) in out.act -- diagnostics the lean kernel build leaves out
+template <int WS>
 DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */) {
     DWBC_LANE_DECL;
     const int k = nv - t;
@@ -239,10 +240,14 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     out.viol = worst >= DWBC_QP_INF ? real_t(0.0) : worst;
 #pragma unroll
     for (int a = 0; a < kQpN; a++) {
-        const int ka = BCASTI(akey, 16 + a);
-        const int ow = ka >> 1;
-        const int idh = BCASTI(R.id_hi, ow), idl = BCASTI(R.id_lo, ow);
-        out.act[a] = ((used >> a) & 1) ? ((ka & 1) ? idl : idh) : -1;
+        if (WS) {
+            const int ka = BCASTI(akey, 16 + a);
+            const int ow = ka >> 1;
+            const int idh = BCASTI(R.id_hi, ow), idl = BCASTI(R.id_lo, ow);
+            out.act[a] = ((used >> a) & 1) ? ((ka & 1) ? idl : idh) : -1;
+        } else {
+            out.act[a] = -1;
+        }
     }
 #pragma unroll
     for (int i = 0; i < kQpN; i++) out.x[i] = real_t(0.0);
