@@ -612,7 +612,10 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
             LV(R.id_hi) = nlim + rr;
         }
     }
-    qp_solve_wave<WS>(R, nv, tvars, max_iter, res, Vlds);
+    // the solver is instantiated for 12, 9 and 6 variables (6 + 6, 3 + 6 and the 6 contact-null variables of the redistribution)
+    if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds);
+    else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds);
+    else qp_solve_wave<WS, 12>(R, nv, tvars, max_iter, res, Vlds);
     LANES {
         if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }

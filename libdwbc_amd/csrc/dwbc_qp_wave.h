@@ -62,16 +62,18 @@ DWBC_WDEV real_t upick12(const real_t *a, int idx) {
 // scaled-variable iterate -> position order of the final solve: contact variables first (the heavy rows of the
 // row-sorted weighted QR), then the task variables
 #define DWBC_QP_PERM_CASE(TT, KK)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < kQpN; i++)                                                      \
+    _Pragma("unroll") for (int i = 0; i < NV; i++)                                                        \
         LV(c)[i] = (i < (KK)) ? sgw * wsc * LV(R.g)[((TT) + i) < kQpN ? (TT) + i : 0]                     \
                               : ((i < (KK) + (TT)) ? sgw * LV(R.g)[(i - (KK)) >= 0 ? i - (KK) : 0] : real_t(0.0));
 
-// WS != 0: report the working set (reference row indices) in out.act -- diagnostics the lean kernel build leaves out
-template <int WS>
+// WS != 0: report the working set (reference row indices) in out.act -- diagnostics the lean kernel build leaves out.
+// NV >= nv: compile-time bound of the variable count (12, 9 or 6); every dot product, rank-one update and QR step runs over NV
+// entries instead of the maximum 12 (the padded entries are exact zeros, so the result does not depend on NV).
+template <int WS, int NV = kQpN>
 DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */) {
     DWBC_LANE_DECL;
     const int k = nv - t;
-    PLA(real_t, Mx, kQpN);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
+    PLA(real_t, Mx, NV);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
     PL(real_t, d);          // g . x of the own row (normalised row, scaled variables)
     PL(real_t, fs);         // |g| / |a|: factor from the normalised slack to slack / (norm of the unscaled row)
     PL(real_t, u);          // slot lanes: multiplier
@@ -82,14 +84,14 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     PL(int, key);
     PL(real_t, m);
     PL(real_t, dz);
-    real_t xu[kQpN];
+    real_t xu[NV];
     DWBC_QPT_INIT();
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) xu[i] = real_t(0.0);
+    for (int i = 0; i < NV; i++) xu[i] = real_t(0.0);
     LANES {
         real_t s2 = real_t(0.0), a2 = real_t(0.0);
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) {
+        for (int j = 0; j < NV; j++) {
             const real_t g2 = LV(R.g)[j] * LV(R.g)[j];
             s2 += g2;
             a2 += (j < t) ? g2 : g2 * (real_t(1.0) / (kQpScaleGI * kQpScaleGI));
@@ -101,7 +103,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         const real_t rg = zrow ? real_t(0.0) : real_t(1.0) / gn;
         LV(fs) = zrow ? real_t(1.0) : gn / sqrt(a2);
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) {
+        for (int j = 0; j < NV; j++) {
             LV(R.g)[j] *= rg;
             LV(Mx)[j] = (lane == j) ? real_t(1.0) : real_t(0.0);
         }
@@ -111,7 +113,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LV(u) = real_t(0.0);
         LV(akey) = 0;
         LV(actf) = 0;
-        LV(slotbit) = (lane >= 16 && lane < 16 + kQpN) ? (1 << (lane - 16)) : 0;
+        LV(slotbit) = (lane >= 16 && lane < 16 + NV) ? (1 << (lane - 16)) : 0;
         LV(m) = real_t(0.0);
         LV(dz) = real_t(0.0);
     }
@@ -141,23 +143,23 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         }
         if (++it > max_iter) { status = 0; break; }
         // normal of the violated side (GI is stated for n^T x >= b': hi side -> n = -g, lo side -> n = +g)
-        real_t gp[kQpN];
+        real_t gp[NV];
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) gp[j] = BCASTA(R.g, j, p);
+        for (int j = 0; j < NV; j++) gp[j] = BCASTA(R.g, j, p);
         const real_t sgn = side ? real_t(1.0) : -real_t(1.0);
         LANES {
             real_t s_ = real_t(0.0);
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) s_ += LV(Mx)[j] * gp[j];
+            for (int j = 0; j < NV; j++) s_ += LV(Mx)[j] * gp[j];
             LV(m) = sgn * s_;  // lanes 0..11: z = H n;  slot lanes: r = N^+ n
         }
-        real_t zu[kQpN];
+        real_t zu[NV];
 #pragma unroll
-        for (int i = 0; i < kQpN; i++) zu[i] = BCAST(m, i);
+        for (int i = 0; i < NV; i++) zu[i] = BCAST(m, i);
         LANES {
             real_t s_ = real_t(0.0);
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) s_ += LV(R.g)[j] * zu[j];
+            for (int j = 0; j < NV; j++) s_ += LV(R.g)[j] * zu[j];
             LV(dz) = s_;  // change of g.x per unit step along z
             LV(val) = side ? LV(R.lo) + LV(d) : LV(R.hi) - LV(d);
         }
@@ -179,7 +181,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         const bool full = zok && t2 <= t1;
         if (zok) {
 #pragma unroll
-            for (int i = 0; i < kQpN; i++) xu[i] += tstep * zu[i];
+            for (int i = 0; i < NV; i++) xu[i] += tstep * zu[i];
             LANES { LV(d) += tstep * LV(dz); }
         }
         LANES { LV(u) -= tstep * LV(m); }
@@ -189,13 +191,13 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             // working set += (p, side): H -= z z^T / zg, N^+ rows -= r_a z^T / zg, new N^+ row = z^T / zg
             int slot = 0;
 #pragma unroll
-            for (int a = kQpN - 1; a >= 0; a--) slot = ((used >> a) & 1) ? slot : a;
+            for (int a = NV - 1; a >= 0; a--) slot = ((used >> a) & 1) ? slot : a;
             const real_t inv_ = fast_rcp(zg);
             LANES {
                 real_t coef = LV(m) * inv_;
                 if (lane == 16 + slot) { coef = -inv_; LV(u) = up; LV(akey) = kmin; }
 #pragma unroll
-                for (int j = 0; j < kQpN; j++) LV(Mx)[j] -= coef * zu[j];
+                for (int j = 0; j < NV; j++) LV(Mx)[j] -= coef * zu[j];
                 if (lane == p) LV(actf) |= (side ? 2 : 1);
             }
             used |= 1 << slot;
@@ -208,22 +210,22 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             LANES {
                 if (lane == l) {
 #pragma unroll
-                    for (int j = 0; j < kQpN; j++) V[j] = LV(Mx)[j];
+                    for (int j = 0; j < NV; j++) V[j] = LV(Mx)[j];
                 }
             }
             WSYNC();
-            real_t rho[kQpN], rr = real_t(0.0);
+            real_t rho[NV], rr = real_t(0.0);
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) { rho[j] = V[j]; rr += rho[j] * rho[j]; }
+            for (int j = 0; j < NV; j++) { rho[j] = V[j]; rr += rho[j] * rho[j]; }
             const real_t inv_ = fast_rcp(rr);
             LANES {
                 real_t dd = real_t(0.0);
 #pragma unroll
-                for (int j = 0; j < kQpN; j++) dd += LV(Mx)[j] * rho[j];
+                for (int j = 0; j < NV; j++) dd += LV(Mx)[j] * rho[j];
                 real_t coef = dd * inv_;
-                if (lane < kQpN) coef = -V[lane] * inv_;
+                if (lane < NV) coef = -V[lane] * inv_;
 #pragma unroll
-                for (int j = 0; j < kQpN; j++) LV(Mx)[j] = (lane == l) ? real_t(0.0) : LV(Mx)[j] - coef * rho[j];
+                for (int j = 0; j < NV; j++) LV(Mx)[j] = (lane == l) ? real_t(0.0) : LV(Mx)[j] - coef * rho[j];
                 if (lane == l) LV(u) = real_t(0.0);
                 if (lane == (kl >> 1)) LV(actf) &= ~((kl & 1) ? 2 : 1);
             }
@@ -255,7 +257,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     // Tikhonov point on the working set = the GI iterate (the fallback of the canon, and the answer when one of the two
     // variable blocks is empty)
 #pragma unroll
-    for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
+    for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
     if (!(k > 0 && t > 0)) return;
     // ---- lexicographic least-norm point on the working set: contact block weighted by kQpScalePolish.  The weighted
     //      normal of an active row stays in its owner lane, entries in POSITION order (contact variables first = row
@@ -264,7 +266,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     //      substitution R^T y = b is folded into the same step (acc = b - sum_j R[j] y_j per lane).
     {
         const real_t wsc = kQpScalePolish / kQpScaleGI;
-        PLA(real_t, c, kQpN);
+        PLA(real_t, c, NV);
         PL(real_t, acc);
         PL(int, pend);
         LANES {
@@ -273,35 +275,35 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             else if (t == 3 && k == 6) { DWBC_QP_PERM_CASE(3, 6) }
             else {
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) {
+                for (int i = 0; i < NV; i++) {
                     const int var = (i < k) ? t + i : i - k;
                     real_t gv = real_t(0.0);
 #pragma unroll
-                    for (int j = 0; j < kQpN; j++) gv = (j == var) ? LV(R.g)[j] : gv;
+                    for (int j = 0; j < NV; j++) gv = (j == var) ? LV(R.g)[j] : gv;
                     LV(c)[i] = (i < nv) ? sgw * gv * ((i < k) ? wsc : real_t(1.0)) : real_t(0.0);
                 }
             }
             LV(acc) = LV(actf) ? ((LV(actf) & 2) ? LV(R.lo) : LV(R.hi)) : real_t(0.0);
             LV(pend) = LV(actf) ? 1 : 0;
         }
-        real_t y[kQpN];
+        real_t y[NV];
 #pragma unroll
-        for (int i = 0; i < kQpN; i++) y[i] = real_t(0.0);
+        for (int i = 0; i < NV; i++) y[i] = real_t(0.0);
         WSYNC();
 #pragma unroll
-        for (int s = 0; s < kQpN; s++) {
+        for (int s = 0; s < NV; s++) {
             if (s < q) {
                 LANES {
                     real_t c2 = real_t(0.0);
 #pragma unroll
-                    for (int j = s; j < kQpN; j++) c2 += LV(c)[j] * LV(c)[j];
+                    for (int j = s; j < NV; j++) c2 += LV(c)[j] * LV(c)[j];
                     LV(val) = LV(pend) ? -c2 : DWBC_QP_INF;
                 }
                 int jp;
                 WAVE_ARGMIN_F32(val, jp);
-                real_t v[kQpN];
+                real_t v[NV];
 #pragma unroll
-                for (int j = s; j < kQpN; j++) v[j] = BCASTA(c, j, jp);
+                for (int j = s; j < NV; j++) v[j] = BCASTA(c, j, jp);
                 const real_t nrm2 = -BCAST(val, jp);
                 const real_t a0 = v[s];
                 const real_t nrm = sqrt(nrm2);
@@ -314,15 +316,15 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                     if (LV(pend)) {
                         real_t dd = real_t(0.0);
 #pragma unroll
-                        for (int j = s; j < kQpN; j++) dd += v[j] * LV(c)[j];
+                        for (int j = s; j < NV; j++) dd += v[j] * LV(c)[j];
                         dd *= bt;
 #pragma unroll
-                        for (int j = s; j < kQpN; j++) LV(c)[j] -= dd * v[j];
+                        for (int j = s; j < NV; j++) LV(c)[j] -= dd * v[j];
                     }
                     if (lane == 0) {
 #pragma unroll
-                        for (int j = s; j < kQpN; j++) V[s * kQpN + j] = v[j];
-                        V[kQpN * kQpN + s] = bt;
+                        for (int j = s; j < NV; j++) V[s * NV + j] = v[j];
+                        V[NV * NV + s] = bt;
                     }
                 }
                 const real_t ys = BCAST(acc, jp) * fast_rcp(alpha);
@@ -337,33 +339,33 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         WSYNC();
         // x~ = Q [y; 0] = H_0 ... H_{q-1} [y; 0] on a uniform 12-vector
 #pragma unroll
-        for (int s = kQpN - 1; s >= 0; s--) {
+        for (int s = NV - 1; s >= 0; s--) {
             if (s < q) {
                 real_t dd = real_t(0.0);
-                real_t v[kQpN];
+                real_t v[NV];
 #pragma unroll
-                for (int j = s; j < kQpN; j++) { v[j] = V[s * kQpN + j]; dd += v[j] * y[j]; }
-                dd *= V[kQpN * kQpN + s];
+                for (int j = s; j < NV; j++) { v[j] = V[s * NV + j]; dd += v[j] * y[j]; }
+                dd *= V[NV * NV + s];
 #pragma unroll
-                for (int j = s; j < kQpN; j++) y[j] -= dd * v[j];
+                for (int j = s; j < NV; j++) y[j] -= dd * v[j];
             }
         }
         DWBC_QPT(6);
         // back to variable order, in the GI scaling (for the slack test) and unscaled (result)
-        real_t xs[kQpN];
+        real_t xs[NV];
         if (t == 6 && k == 6) {
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) xs[j] = (j < 6) ? y[6 + j] : y[j - 6] * wsc;
+            for (int j = 0; j < NV; j++) xs[j] = (j < 6) ? y[(6 + j) < NV ? 6 + j : 0] : y[j >= 6 ? j - 6 : 0] * wsc;
         } else if (t == 3 && k == 6) {
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) xs[j] = (j < 3) ? y[6 + j] : (j < 9 ? y[j - 3] * wsc : real_t(0.0));
+            for (int j = 0; j < NV; j++) xs[j] = (j < 3) ? y[(6 + j) < NV ? 6 + j : 0] : (j < 9 ? y[j >= 3 ? j - 3 : 0] * wsc : real_t(0.0));
         } else {
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) {
+            for (int j = 0; j < NV; j++) {
                 const int pos = (j >= t) ? j - t : k + j;
                 real_t yv = real_t(0.0);
 #pragma unroll
-                for (int i = 0; i < kQpN; i++) yv = (i == pos) ? y[i] : yv;
+                for (int i = 0; i < NV; i++) yv = (i == pos) ? y[i] : yv;
                 xs[j] = (j < nv) ? yv * ((j >= t) ? wsc : real_t(1.0)) : real_t(0.0);
             }
         }
@@ -371,7 +373,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LANES {
             real_t dd = real_t(0.0);
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) dd += LV(R.g)[j] * xs[j];
+            for (int j = 0; j < NV; j++) dd += LV(R.g)[j] * xs[j];
             const real_t sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - dd) * LV(fs);
             const real_t sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + dd) * LV(fs);
             LV(val) = sl < sh ? sl : sh;
@@ -383,7 +385,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         if (!(wv < -kQpFeasTol)) {
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
+            for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
         }
     }
 }
