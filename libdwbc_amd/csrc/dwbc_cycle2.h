@@ -9,6 +9,8 @@
 //
 // Reference functions restated: see the table at the top of dwbc_cycle.h.
 #pragma once
+#include <type_traits>
+
 #include "dwbc_cycle.h"
 #include "dwbc_velocity.h"
 #include "dwbc_fstar.h"
@@ -404,25 +406,30 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         // T1[:, lane] = J_t * (lane's column of A^-1 N_c): all task rows in one pass, zero columns of J_t skipped
-        LANES {
-            real_t tc_[T];
+        // (instantiated for 3 and 6 task rows: a 3-dof level does not pay for the padding of the 6-wide blocks)
+        auto t1_rows = [&](auto ttc) {
+            constexpr int TT = decltype(ttc)::value;
+            LANES {
+                real_t tc_[TT];
 #pragma unroll
-            for (int r = 0; r < T; r++) tc_[r] = real_t(0.0);
+                for (int r = 0; r < TT; r++) tc_[r] = real_t(0.0);
 #pragma unroll
-            for (int ib = 0; ib < N; ib += 3) {
-                if ((tm >> ib) & 7) {
+                for (int ib = 0; ib < N; ib += 3) {
+                    if ((tm >> ib) & 7) {
 #pragma unroll
-                    for (int i = ib; i < ib + 3 && i < N; i++)
+                        for (int i = ib; i < ib + 3 && i < N; i++)
 #pragma unroll
-                        for (int r = 0; r < T; r++) tc_[r] += Jtt[i * T + r] * LV(s)[i];
+                            for (int r = 0; r < TT; r++) tc_[r] += Jtt[i * T + r] * LV(s)[i];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < TT; r++) {
+                    if (lane < N) T1[r * N + lane] = tc_[r];
+                    if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
                 }
             }
-#pragma unroll
-            for (int r = 0; r < T; r++) {
-                if (lane < N) T1[r * N + lane] = tc_[r];
-                if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
-            }
-        }
+        };
+        if (t <= 3) t1_rows(std::integral_constant<int, 3>{}); else t1_rows(std::integral_constant<int, T>{});
         DWBC_SYNC();
         if (lv == 0) DWBC_FSTAMP(14);  // level 0: Jt + T1
         for (int idx = th.tid; idx < t * t; idx += NT) {  // J_t A^-1 N_c J_t^T
@@ -530,7 +537,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
         real_t *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
         DWBC_SYNC();
-        for (int idx = th.tid; idx < T * M; idx += NT) {  // Q = Lambda T1[:,6:]  (zero padded to T rows)
+        for (int idx = th.tid; idx < t * M; idx += NT) {  // Q = Lambda T1[:,6:]
             const int i = idx / M, j = idx - i * M;
             real_t acc = real_t(0.0);
             if (i < t)
@@ -539,47 +546,52 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             Q[idx] = acc;
         }
         DWBC_SYNC();
-        for (int r = 0; r < T; r++) {
-            LANES {
-                real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-                for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
-                const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
-            }
-        }
-        DWBC_SYNC();
-        if (lv == 0) DWBC_FSTAMP(21);  // level 0: Q, QW
-        mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
-        const int cond = spd_inverse_small(L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
-        DWBC_SYNC();
-        if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
-        // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
         real_t *Ul = L + S::U + lv * M * T;
         real_t *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;
-        LANES {
-            real_t jk[T], qw[T];
+        int cond = 1;
+        auto jkt_rows = [&](auto ttc) {
+            constexpr int TT = decltype(ttc)::value;
+            for (int r = 0; r < TT; r++) {
+                LANES {
+                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
-            for (int r = 0; r < T; r++) qw[r] = QW[r * M + (lane < M ? lane : 0)];
-#pragma unroll
-            for (int r2 = 0; r2 < T; r2++) {
-                real_t acc = real_t(0.0);
-#pragma unroll
-                for (int r = 0; r < T; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : real_t(0.0);
-                jk[r2] = acc;
-                if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
-            }
-#pragma unroll
-            for (int r3 = 0; r3 < T; r3++) {
-                real_t acc = real_t(0.0);
-#pragma unroll
-                for (int r2 = 0; r2 < T; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : real_t(0.0);
-                if (lane < M) {
-                    Xs[lane * T + r3] = acc;
-                    Ul[lane * T + r3] = acc;
+                    for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
+                    const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                    if (lane < M) QW[r * M + lane] = acc;  // (Q W^+)[r][lane]
                 }
             }
-        }
+            DWBC_SYNC();
+            if (lv == 0) DWBC_FSTAMP(21);  // level 0: Q, QW
+            mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
+            cond = spd_inverse_small(L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
+            DWBC_SYNC();
+            if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
+            // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
+            LANES {
+                real_t jk[TT], qw[TT];
+#pragma unroll
+                for (int r = 0; r < TT; r++) qw[r] = QW[r * M + (lane < M ? lane : 0)];
+#pragma unroll
+                for (int r2 = 0; r2 < TT; r2++) {
+                    real_t acc = real_t(0.0);
+#pragma unroll
+                    for (int r = 0; r < TT; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : real_t(0.0);
+                    jk[r2] = acc;
+                    if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
+                }
+#pragma unroll
+                for (int r3 = 0; r3 < TT; r3++) {
+                    real_t acc = real_t(0.0);
+#pragma unroll
+                    for (int r2 = 0; r2 < TT; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : real_t(0.0);
+                    if (lane < M) {
+                        Xs[lane * T + r3] = acc;
+                        Ul[lane * T + r3] = acc;
+                    }
+                }
+            }
+        };
+        if (t <= 3) jkt_rows(std::integral_constant<int, 3>{}); else jkt_rows(std::integral_constant<int, T>{});
         DWBC_SYNC();
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
             const int tp = su.t_dof[pl];
