@@ -13,6 +13,7 @@ namespace dwbc {
 // ------------------------------------------------------------------------------------------------
 template <int N, int NB, int NT>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const BatchIO io) {
+    static_assert(NT == 64, "one wavefront per instance: DWBC_SYNC is a wavefront-scope fence");
     extern __shared__ __attribute__((aligned(16))) real_t lds[];
     const int inst = blockIdx.x;
     if (inst >= io.B) return;

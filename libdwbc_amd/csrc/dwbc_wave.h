@@ -30,7 +30,11 @@
 #define PLA(type, x, n) type x[n]
 #define LV(x) x
 #define LANES
+#ifdef DWBC_BLOCK_BARRIER
 #define WSYNC() __syncthreads()
+#else
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")  /* see DWBC_SYNC in dwbc_cycle.h */
+#endif
 #define DWBC_LANE_DECL const int lane = (int)threadIdx.x
 #define BCAST(x, src) dwbc::readlane_f64((x), (src))
 #define BCASTA(x, j, src) dwbc::readlane_f64((x)[(j)], (src))
