@@ -27,6 +27,20 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak (public spec), for --dtype f
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
 
 
+def host_cores():
+    """CPU threads this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's
+    share of the host, 16 cores, to a job although all 256 logical CPUs are visible) -- oversubscribing the quota makes the
+    OpenMP baseline slower, not faster."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("DWBC_CPU_THREADS", "16")))
+
+
 def hbm_traffic_per_launch(kernel_name, batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes) if they were
     taken on the same kernel and batch; None otherwise.  The accesses are 8 B per lane, for which the gfx950 FETCH_SIZE
@@ -194,7 +208,7 @@ def main():
 
             M = orc.make_model(cases.tocabi_model())
             S = orc.make_setup(cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
-            cores = len(os.sched_getaffinity(0))
+            cores = host_cores()
             qs, fls, fss = cases.synth_batch(2048, seed=20251226 + 2)
             orc.cycle_batch(M, S, qs[:64], fls[:64], fss[:64], cores)
             done, t1 = 0, time.perf_counter()
