@@ -15,7 +15,7 @@
 
 using namespace dwbc;
 
-extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, const void **fn, const void **fn_wide, int *lds_bytes);
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, int topo, const void **fn, const void **fn_wide, int *lds_bytes, int *topo_out);
 
 // DWBC_F32 batches: the fp32 kernels (dwbc_kernels_f32.hip) work on the double buffers of the boundary; the model table is
 // converted to float once
@@ -67,7 +67,7 @@ struct dwbc_batch {
     int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
     float *f_body = nullptr;
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
-    int f32_lds = 0, f32_key = -1;
+    int f32_lds = 0, f32_key = -1, f32_topo = 0;
     int hqp = 1;
     bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
     // host mirrors of the inputs
@@ -177,6 +177,7 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     m->m.body_table(body);
     m->m.topo_table(topo);
     setup_set_parents(b->su, topo.data());
+    if (getenv("DWBC_DENSE_SWEEP")) b->su.topo_kind = 0;  // test hook: the generic (dense) A^-1 sweep on a model that has a constant tree
     if ((e = hipMalloc(&b->d_body, body.size() * sizeof(double))) != hipSuccess) return bad("hipMalloc", e);
     if ((e = hipMalloc(&b->d_topo, topo.size() * sizeof(int))) != hipSuccess) return bad("hipMalloc", e);
     if ((e = hipMemcpy(b->d_body, body.data(), body.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bad("hipMemcpy", e);
@@ -438,7 +439,7 @@ static bool lean_ok(const dwbc_batch *b) {
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const char *kv = getenv("DWBC_KERNEL");
     const int which = reduced ? 2 : ((kv && std::string(kv) == "v1") ? 1 : 0);
-    return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which);
+    return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind);
 }
 
 // fp32 launch: the fp32 kernels read and write the double buffers of the boundary themselves (io_t); only the model table is
@@ -446,9 +447,9 @@ static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
 static int launch_f32(dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
     const int lean = lean_ok(b) ? 1 : 0;
-    const int key = (which * 16 + b->su.n_levels) * 2 + lean;
+    const int key = ((which * 16 + b->su.n_levels) * 2 + lean) * 2 + (b->su.topo_kind ? 1 : 0);
     if (key != b->f32_key) {
-        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, lean, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds))
+        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, lean, b->su.topo_kind, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds, &b->f32_topo))
             return fail("no fp32 kernel for this model / number of task levels");
         HIP_OK(hipFuncSetAttribute(b->f32_fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
         if (b->f32_fn_wide) HIP_OK(hipFuncSetAttribute(b->f32_fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
@@ -747,8 +748,15 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "dwbc::";  // as rocprofv3 prints the instantiations
     if (!ke) return "";
+    const std::string topo = ", " + pre + (ke->topo == 1 ? "TopoTocabi" : "TopoGeneric");
+    const std::string sz = std::to_string(ke->n) + ", " + std::to_string(ke->nb);
     if (b->last_reduced) {
-        name = pre + "dwbc_cycle_kernel_reduced<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64>";
+        name = pre + "dwbc_cycle_kernel_reduced<" + sz + ", " + std::to_string(ke->nlv) + ", 64" + topo + ">";
+        return name.c_str();
+    }
+    const char *kv = getenv("DWBC_KERNEL");
+    if (kv && std::string(kv) == "v1" && b->dtype != DWBC_F32) {
+        name = pre + "dwbc_cycle_kernel<" + sz + ", 64>";
         return name.c_str();
     }
     int n_cu = b->n_cu;
@@ -756,12 +764,9 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) n_cu = prop.multiProcessorCount;
     }
-    const bool v1 = ke->fn_wide == nullptr;
-    const bool wide = !v1 && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
-    name = v1 ? "dwbc_cycle_kernel<" + std::to_string(ke->n) + ", " + std::to_string(ke->nb) + ", 64>"
-              : std::string(wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + std::to_string(ke->n) + ", " +
-                    std::to_string(ke->nb) + ", " + std::to_string(ke->nlv) + ", 64" + (v1 ? "" : (ke->fn_lean && lean_ok(b) ? ", false" : ", true")) + ">";
-    name = pre + name;
+    const bool wide = ke->fn_wide && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
+    name = pre + (wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + sz + ", " + std::to_string(ke->nlv) + ", 64" +
+           (ke->fn_lean && lean_ok(b) ? ", false" : ", true") + topo + ">";
     return name.c_str();
 }
 

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "dwbc_cycle.h"
+#include "dwbc_topo.h"
 #include "dwbc_velocity.h"
 #include "dwbc_fstar.h"
 #include "dwbc_nohqp.h"
@@ -192,6 +193,61 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
     return ok;
 }
 
+// The same sweep for a joint-space mass matrix, which is sparse by the kinematic tree: A[i][j] != 0 only if dof i is an
+// ancestor or a descendant of dof j.  Pivoting leaves first (k = NN-1 .. 0; a parent's index is below its children's) keeps
+// that pattern without fill-in: when k is the pivot all its descendants have been swept and none of its ancestors, the swept
+// set is a forest of complete subtrees, so column k is non-zero exactly on the relatives of k (Featherstone's branch-induced
+// sparsity).  Rows outside the relatives would receive c_i * h with c_i == 0.0 exactly, so leaving them out changes no bit
+// of the result of this pivot order.  The pattern is a compile-time constant (Topo, dwbc_topo.h): the pivots are unrolled by
+// template recursion and each keeps only its relatives' rows -- for TOCABI 753 of the 1521 FMA + broadcast pairs.
+template <class Topo, int NN, int K>
+DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
+    DWBC_LANE_DECL;
+    constexpr unsigned long long rel = Topo::relatives(K);
+    real_t d = BCAST(dg, K);
+    if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
+    const real_t rp = fast_rcp(d);
+#ifdef DWBC_HOST_EMU
+    real_t snap_[NN];
+    for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[K][i_];
+#endif
+    LANES {
+        const real_t cj = LV(s)[K];
+        const real_t h = (lane == K) ? (real_t(1.0) - rp) : cj * rp;
+#pragma unroll
+        for (int i = 0; i < NN; i++) {
+            if ((rel >> i) & 1ull) {
+#ifdef DWBC_HOST_EMU
+                const real_t ci = snap_[i];
+#else
+                const real_t ci = readlane_f64(LV(s)[i], K);
+#endif
+                LV(s)[i] -= ci * h;
+            }
+        }
+        LV(dg) = (lane == K) ? -rp : LV(dg) - cj * h;
+    }
+    if constexpr (K > 0) tree_pivot<Topo, NN, K - 1>(s, dg, ok);
+}
+
+template <class Topo, int NN>
+DWBC_WDEV int sweep_inverse_tree(PLA_REF(real_t, s, NN), PL_REF(real_t, dg)) {
+    DWBC_LANE_DECL;
+    static_assert(NN == Topo::ndof, "topology / kernel size mismatch");
+    int ok = 1;
+    LANES {
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - real_t(1.0) : LV(s)[i];
+    }
+    tree_pivot<Topo, NN, NN - 1>(s, dg, ok);
+    LANES {
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        LV(dg) = -LV(dg);
+    }
+    return ok;
+}
+
 // inverse of a small SPD matrix (n <= 12) held in LDS: column per lane in registers + the sweep above.  Used for
 // Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
 // where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
@@ -279,7 +335,7 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
 // EXTRAS = false compiles the optional paths out (task-link trajectories, qdot outputs, COM / TASK_CUSTOM levels, hqp = false):
 // merely having them inlined costs the common cycle 2 % (register allocation around the 39-column register matrix), so the
 // launcher picks the lean instantiation whenever none of them is in use.
-template <int N, int NB, int NLV, int NT, bool EXTRAS = true>
+template <int N, int NB, int NLV, int NT, bool EXTRAS = true, class Topo = TopoGeneric>
 DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
     using S = Lds2<N, NB, NLV>;
     constexpr bool kExtras = EXTRAS;

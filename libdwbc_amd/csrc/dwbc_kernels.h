@@ -33,19 +33,20 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const Ba
     if (inst >= io.B) return;                                                            \
     Thr th{(int)threadIdx.x};                                                            \
     int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
-    cycle_instance_v2<N, NB, NLV, NT, EXTRAS>(th, su, io, inst, lds, iL);
+    cycle_instance_v2<N, NB, NLV, NT, EXTRAS, Topo>(th, su, io, inst, lds, iL);
 // EXTRAS: see cycle_instance_v2 -- false = the lean build the launcher uses when no optional path is requested
-template <int N, int NB, int NLV, int NT, bool EXTRAS>
+// Topo: a constant kinematic tree (dwbc_topo.h) whose sparsity the A^-1 sweep uses, or TopoGeneric
+template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
-template <int N, int NB, int NLV, int NT, bool EXTRAS>
+template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
 
 // reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
-template <int N, int NB, int NLV, int NT>
+template <int N, int NB, int NLV, int NT, class Topo>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
     static_assert(NT == 64, "one wavefront per instance");
     extern __shared__ __attribute__((aligned(16))) real_t lds[];
@@ -53,70 +54,84 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, 
     if (inst >= io.B) return;
     Thr th{(int)threadIdx.x};
     int *iL = reinterpret_cast<int *>(lds + LdsR<N, NB, NLV>::rtotal);
-    cycle_instance_reduced<N, NB, NLV, NT>(th, su, io, inst, lds, iL);
+    cycle_instance_reduced<N, NB, NLV, NT, Topo>(th, su, io, inst, lds, iL);
 }
 
 constexpr int kNT = 64;
 
 struct KernelEntry {
     int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
+    int topo;        // Setup::topo_kind the instantiation was built for (1: TopoTocabi's constant tree); 0 = any tree
     void (*fn)(const Setup, const BatchIO);
     int lds_bytes;
     void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
     void (*fn_lean)(const Setup, const BatchIO);       // the same two without the optional paths (EXTRAS = false), or nullptr
     void (*fn_wide_lean)(const Setup, const BatchIO);
 };
-// instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs.
+// instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
+// flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).
 // index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 #ifdef DWBC_EXPERIMENT
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false>},
+    {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>},
 };
 const KernelEntry kKernelsReduced[] = {
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 2, 1, dwbc_cycle_kernel_reduced<39, 34, 2, kNT, TopoTocabi>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
 };
 #else
 const KernelEntry kKernels[] = {
-    {39, 34, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, true>,
-     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false>},
-    {39, 34, 2, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false>},
-    {39, 34, 3, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, true>,
-     dwbc_cycle_kernel_v2<39, 34, 3, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false>},
-    {39, 34, 4, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, true>,
-     dwbc_cycle_kernel_v2<39, 34, 4, kNT, false>, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, false>},
+    {39, 34, 1, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true, TopoTocabi>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, true, TopoTocabi>,
+     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false, TopoTocabi>},
+    {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>},
+    {39, 34, 3, 1, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true, TopoTocabi>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, true, TopoTocabi>,
+     dwbc_cycle_kernel_v2<39, 34, 3, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false, TopoTocabi>},
+    {39, 34, 4, 1, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true, TopoTocabi>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, true, TopoTocabi>,
+     dwbc_cycle_kernel_v2<39, 34, 4, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, false, TopoTocabi>},
+    {39, 34, 1, 0, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true, TopoGeneric>, Lds2<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 2, 0, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoGeneric>, Lds2<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 3, 0, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true, TopoGeneric>, Lds2<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 4, 0, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true, TopoGeneric>, Lds2<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
 };
 const KernelEntry kKernelsReduced[] = {
-    {39, 34, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT>, LdsR<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
-    {39, 34, 2, dwbc_cycle_kernel_reduced<39, 34, 2, kNT>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
-    {39, 34, 3, dwbc_cycle_kernel_reduced<39, 34, 3, kNT>, LdsR<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},
-    {39, 34, 4, dwbc_cycle_kernel_reduced<39, 34, 4, kNT>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 1, 1, dwbc_cycle_kernel_reduced<39, 34, 1, kNT, TopoTocabi>, LdsR<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 2, 1, dwbc_cycle_kernel_reduced<39, 34, 2, kNT, TopoTocabi>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 3, 1, dwbc_cycle_kernel_reduced<39, 34, 3, kNT, TopoTocabi>, LdsR<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 4, 1, dwbc_cycle_kernel_reduced<39, 34, 4, kNT, TopoTocabi>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 1, 0, dwbc_cycle_kernel_reduced<39, 34, 1, kNT, TopoGeneric>, LdsR<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 2, 0, dwbc_cycle_kernel_reduced<39, 34, 2, kNT, TopoGeneric>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 3, 0, dwbc_cycle_kernel_reduced<39, 34, 3, kNT, TopoGeneric>, LdsR<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 4, 0, dwbc_cycle_kernel_reduced<39, 34, 4, kNT, TopoGeneric>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
 #ifdef DWBC_EXPERIMENT
-const KernelEntry kKernelsV1[] = {{0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr}};
+const KernelEntry kKernelsV1[] = {{0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr}};
 #else
 const KernelEntry kKernelsV1[] = {
-    {39, 34, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr, nullptr, nullptr},
+    {39, 34, 0, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
 
 // which: 0 = register-resident kernel (default), 1 = LDS-resident reference kernel (DWBC_KERNEL=v1), 2 = reduced dynamics
-inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which) {
-    if (which == 2) {
-        for (const auto &k : kKernelsReduced)
-            if (k.n == n && k.nb == nb && k.nlv == nlv) return &k;
-        return nullptr;
-    }
+// topo: Setup::topo_kind of the loaded model -- an instantiation for that constant tree is preferred, else the generic one
+inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which, int topo) {
     if (which == 1) {
         for (const auto &k : kKernelsV1)
             if (k.n == n && k.nb == nb) return &k;
         return nullptr;
     }
-    for (const auto &k : kKernels)
-        if (k.n == n && k.nb == nb && k.nlv == nlv) return &k;
+    for (int pass = 0; pass < 2; pass++) {
+        const int want = pass == 0 ? topo : 0;
+        if (which == 2) {
+            for (const auto &k : kKernelsReduced)
+                if (k.n == n && k.nb == nb && k.nlv == nlv && k.topo == want) return &k;
+        } else {
+            for (const auto &k : kKernels)
+                if (k.n == n && k.nb == nb && k.nlv == nlv && k.topo == want) return &k;
+        }
+    }
     return nullptr;
 }
 

@@ -6,12 +6,13 @@
 #include "dwbc_kernels.h"
 #undef dwbc
 
-extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, const void **fn, const void **fn_wide, int *lds_bytes) {
-    const dwbc_f32::KernelEntry *k = dwbc_f32::lookup_kernel(n, nb, nlv, which);
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, int topo, const void **fn, const void **fn_wide, int *lds_bytes, int *topo_out) {
+    const dwbc_f32::KernelEntry *k = dwbc_f32::lookup_kernel(n, nb, nlv, which, topo);
     if (!k || !k->fn) return 0;
     const bool ln = lean && k->fn_lean;
     *fn = reinterpret_cast<const void *>(ln ? k->fn_lean : k->fn);
     *fn_wide = reinterpret_cast<const void *>(ln ? k->fn_wide_lean : k->fn_wide);
     *lds_bytes = k->lds_bytes;
+    *topo_out = k->topo;
     return 1;
 }

@@ -258,7 +258,7 @@ DWBC_DEV int jkt_reduced(Thr th, real_t *L, PLA_REF(real_t, w, 18), int t, int R
     return ok;
 }
 
-template <int N, int NB, int NLV, int NT>
+template <int N, int NB, int NLV, int NT, class Topo = TopoGeneric>
 DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
     using S = LdsR<N, NB, NLV>;
     constexpr int M = S::M, C = S::C, T = S::T, RSX = S::RSX, RMX = S::RMX, NCX = S::NCX;

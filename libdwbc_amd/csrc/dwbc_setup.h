@@ -5,6 +5,7 @@
 #include <string>
 
 #include "dwbc_types.h"
+#include "dwbc_topo.h"
 
 namespace dwbc {
 
@@ -23,6 +24,7 @@ inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
 // parent body of every body (Model::topo_table()[0..nb)); must be installed before contacts / tasks are added
 inline void setup_set_parents(Setup &su, const int *parent) {
     for (int i = 0; i < su.nb && i < kMaxBodies; i++) su.parent[i] = parent[i];
+    su.topo_kind = TopoTocabi::matches(su.nb, parent) ? 1 : 0;
 }
 
 // dofs on the path from `link` to the floating base: bits 0..5 (base) and bit (b + 5) for every moving body b on the path

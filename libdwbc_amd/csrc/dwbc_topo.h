@@ -1,0 +1,41 @@
+// Compile-time kinematic trees.  The joint-space mass matrix is sparse by the tree (A[i][j] != 0 only when dof i is an
+// ancestor or a descendant of dof j); a kernel instantiated for one robot size can be given that pattern as a constant and
+// drop the structurally zero work from its A^-1 sweep (sweep_inverse_tree in dwbc_cycle2.h).  The host compares the loaded
+// model's parent table with the constant one (setup_set_parents) and the kernel falls back to the dense sweep on a mismatch,
+// so a table here is an optimisation for a known robot, never an assumption about the model.
+#pragma once
+
+namespace dwbc {
+
+// no constant tree: the dense sweep, correct for any model of the instantiated size
+struct TopoGeneric {};
+
+// TOCABI (tests/golden/dyros_tocabi.urdf; the robot of every reference test, example and BASELINE config): pelvis 0, left leg
+// 1-6, right leg 7-12, waist 13-15, left arm 16-23, head 24-25, right arm 26-33.  RBDL body order = URDF depth-first order.
+struct TopoTocabi {
+    static constexpr int nb = 34;
+    static constexpr int ndof = nb + 5;
+    static constexpr int parent[nb] = {0, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 15, 24, 15, 26, 27, 28, 29, 30, 31, 32};
+    static constexpr bool anc_or_self(int a, int b) {
+        while (b > a) b = parent[b];
+        return a == b;
+    }
+    // bit i set <=> dof i couples with dof k (dofs 0..5 belong to body 0, dof d >= 6 to body d - 5)
+    static constexpr unsigned long long relatives(int k) {
+        unsigned long long m = 0;
+        const int bk = k < 6 ? 0 : k - 5;
+        for (int i = 0; i < ndof; i++) {
+            const int bi = i < 6 ? 0 : i - 5;
+            if (anc_or_self(bi, bk) || anc_or_self(bk, bi)) m |= 1ull << i;
+        }
+        return m;
+    }
+    static bool matches(int n_bodies, const int *par) {
+        if (n_bodies != nb) return false;
+        for (int i = 0; i < nb; i++)
+            if ((par[i] < 0 ? 0 : par[i]) != parent[i]) return false;
+        return true;
+    }
+};
+
+}  // namespace dwbc

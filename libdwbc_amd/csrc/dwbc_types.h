@@ -59,6 +59,7 @@ struct Setup {
     // structural support of the Jacobians: bit d set <=> dof d (0..5 base, 6.. joints) moves the link.  Derived from the
     // kinematic tree when a contact / task link is registered; lets the products J A^-1 and J A^-1 N_c skip zero columns.
     int parent[kMaxBodies];
+    int topo_kind;  // 1: the parent table equals TopoTocabi's (dwbc_topo.h) and the kernels may use its constant sparsity
     unsigned long long c_dofmask[kMaxContacts];
     unsigned long long t_dofmask[kMaxLevels];
     // on-device task reference (dwbc_fstar.h): gains of TaskLink::SetTaskGain (pos_p pos_d pos_a rot_p rot_d, 3 each) and the

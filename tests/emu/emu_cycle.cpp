@@ -101,17 +101,20 @@ int emu_run_reduced(EmuCtx *c, int B, const double *q, const unsigned char *flag
     std::vector<int> ilds(64);
     for (int b = 0; b < B; b++) {
         Thr th{0};
-        if (c->su.n_levels == 1) cycle_instance_reduced<39, 34, 1, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 2) cycle_instance_reduced<39, 34, 2, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 3) cycle_instance_reduced<39, 34, 3, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else cycle_instance_reduced<39, 34, 4, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        if (c->su.n_levels == 1) cycle_instance_reduced<39, 34, 1, 1, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 2) cycle_instance_reduced<39, 34, 2, 1, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 3) cycle_instance_reduced<39, 34, 3, 1, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else cycle_instance_reduced<39, 34, 4, 1, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
     }
     from_real(rdump, dump);
     return 1;
 }
 
 static int g_emu_hqp = 1;
+static int g_emu_dense = 0;
 void emu_set_hqp(int hqp) { g_emu_hqp = hqp; }
+// 1: two-level full-dynamics runs use the TopoGeneric (dense A^-1 sweep) instantiation instead of TOCABI's constant tree
+void emu_set_dense(int d) { g_emu_dense = d; }
 static const double *g_emu_custom = nullptr;
 int emu_add_custom_task(EmuCtx *c, int level, int dof) { return setup_add_custom_task(c->su, level, dof, c->err) ? 1 : 0; }
 void emu_set_custom(const double *J) { g_emu_custom = J; }
@@ -157,10 +160,11 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     for (int b = 0; b < B; b++) {
         Thr th{0};
         if (v1) cycle_instance<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 1) cycle_instance_v2<39, 34, 1, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 2) cycle_instance_v2<39, 34, 2, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 3) cycle_instance_v2<39, 34, 3, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else cycle_instance_v2<39, 34, 4, 1>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 1) cycle_instance_v2<39, 34, 1, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 2 && g_emu_dense) cycle_instance_v2<39, 34, 2, 1, true, TopoGeneric>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 2) cycle_instance_v2<39, 34, 2, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else if (c->su.n_levels == 3) cycle_instance_v2<39, 34, 3, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        else cycle_instance_v2<39, 34, 4, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
     }
     from_real(rdump, dump);
     return 1;

@@ -364,3 +364,36 @@ def test_gpu_hqp_false_vs_oracle():
     assert np.abs(wbc.get("tau") - tau).max() < 1e-6
     wbc.solve(hqp=True)  # and back
     assert wbc.get("status").mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_gpu_generic_tree_instantiation_matches_tocabi_one(monkeypatch):
+    """A model whose tree is not the constant TOCABI one runs the TopoGeneric instantiation (dense A^-1 sweep).  The test hook
+    DWBC_DENSE_SWEEP makes a TOCABI batch take that route: same torques to rounding, full and reduced dynamics, and the
+    launcher reports the other kernel."""
+    B = 256
+    q, flags, fstar = cases.synth_batch(B, seed=4242, yaw=True)
+    w1 = _make(B)
+    tau1, wr1, st1 = _run(w1, q, flags, fstar)
+    assert "TopoTocabi" in w1.kernel_name()
+    monkeypatch.setenv("DWBC_DENSE_SWEEP", "1")
+    w2 = _make(B)
+    monkeypatch.delenv("DWBC_DENSE_SWEEP")
+    tau2, wr2, st2 = _run(w2, q, flags, fstar)
+    assert "TopoGeneric" in w2.kernel_name()
+    assert (st1 == st2).all() and (st1 == 1).mean() > 0.5
+    ok = st1 == 1
+    assert np.abs(tau1[ok] - tau2[ok]).max() < 1e-7
+    assert np.abs(wr1[ok] - wr2[ok]).max() < 1e-6
+    tau_r, wr_r, st_r, _ = _oracle(B, q, flags, fstar)
+    ok = ok & (st_r == 1)
+    assert np.abs(tau2[ok] - tau_r[ok]).max() < TOL
+    for w in (w1, w2):  # reduced dynamics (no torque limit on that path)
+        w.set_torque_limit(None)
+        w.solve(reduced=True)
+    assert "TopoGeneric" in w2.kernel_name() and "reduced" in w2.kernel_name()
+    s1, s2 = w1.get("status"), w2.get("status")
+    ok = (s1 == 1) & (s2 == 1)
+    assert ok.mean() > 0.5
+    d = np.abs(w1.get("tau")[ok] - w2.get("tau")[ok]).max(axis=(1, 2))
+    assert np.quantile(d, 0.99) < 1e-6

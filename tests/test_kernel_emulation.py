@@ -213,3 +213,35 @@ def test_emulated_kernel_hqp_false(cfg):
     assert np.abs(r["tau"] - tau).max() < 1e-6
     if cfg != "mixed":
         assert np.abs(tau[:, 2]).max() > 1.0
+
+
+def test_tree_sweep_matches_dense_sweep_and_mass_matrix_pattern():
+    """The A^-1 sweep of the TOCABI instantiations skips the rows the kinematic tree makes structurally zero
+    (sweep_inverse_tree, dwbc_topo.h).  Check the premise on the dumped mass matrix -- A[i][j] == 0.0 exactly unless dof i is an
+    ancestor or a descendant of dof j -- and that the TopoGeneric instantiation (dense sweep, pivots in the other order)
+    returns the same A^-1 and torques to rounding."""
+    contacts, tasks, lim = cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM
+    q, fl, fs = cases.synth_batch(16, seed=77, yaw=True)
+    e = Emu(cases.URDF, contacts, tasks, lim)
+    rt = e.run(q, fl, fs, dump=True)
+    rd = e.run(q, fl, fs, dump=True, dense=True)
+    parent = e.model_arrays()["parent"]
+    n = e.n
+    body = lambda d: 0 if d < 6 else d - 5
+
+    def anc(a, b):  # a ancestor-or-self of b
+        while b > a:
+            b = parent[b]
+        return a == b
+
+    rel = np.array([[anc(body(i), body(j)) or anc(body(j), body(i)) for j in range(n)] for i in range(n)])
+    assert rel.sum() == 753  # 12 leg dofs x 12 + 3 waist x 27 + 16 arm x 17 + 2 head x 11 + 6 base x 39
+    A = e.dump_field(rt["dump"], "A", (n, n))
+    assert (A[:, ~rel] == 0.0).all()
+    Ai_t, Ai_d = e.dump_field(rt["dump"], "A_inv", (n, n)), e.dump_field(rd["dump"], "A_inv", (n, n))
+    assert np.abs(Ai_t - Ai_d).max() < 1e-11 * np.abs(Ai_d).max()
+    for b in range(A.shape[0]):
+        assert np.abs(Ai_t[b] @ A[b] - np.eye(n)).max() < 1e-10
+    assert (rt["status"] == rd["status"]).all()
+    ok = rt["status"] == 1
+    assert np.abs(rt["tau"][ok] - rd["tau"][ok]).max() < 1e-7
