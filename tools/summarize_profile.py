@@ -27,7 +27,7 @@ def main():
             if "dwbc_cycle_kernel" not in row["Kernel_Name"]:
                 continue
             if kinfo is None:
-                kinfo = dict(kernel=row["Kernel_Name"][:60], grid=row["Grid_Size"], wg=row["Workgroup_Size"], lds=row["LDS_Block_Size"],
+                kinfo = dict(kernel=row["Kernel_Name"][:110], grid=row["Grid_Size"], wg=row["Workgroup_Size"], lds=row["LDS_Block_Size"],
                              scratch=row["Scratch_Size"], vgpr=row["VGPR_Count"], agpr=row["Accum_VGPR_Count"], sgpr=row["SGPR_Count"])
             a = acc.setdefault(row["Counter_Name"], [0.0, 0])
             a[0] += float(row["Counter_Value"])
