@@ -284,6 +284,26 @@ void Model::topo_table(std::vector<int> &out) const {
         out[nb + i] = depth[i];
         out[2 * nb + i] = subtree[i];
     }
+    // the coupled dof pairs of the mass matrix, (j << 8) | k for every dof k on the path from dof j to the root (k <= j;
+    // dofs 0..5 = floating base, dof d >= 6 = joint of body d - 5): the CRBA fills A[j][k] = A[k][j] = S_k . F_j pair by
+    // pair, 64 independent pairs per round, instead of one dependent walk up the tree per dof
+    std::vector<int> pairs;
+    const int nd = nb + 5;
+    for (int j = 0; j < nd; j++) {
+        int k = j;
+        for (;;) {
+            pairs.push_back((j << 8) | k);
+            if (k == 0) break;
+            if (k < 6) {
+                k--;
+            } else {
+                const int pb = parent[k - 5] < 0 ? 0 : parent[k - 5];
+                k = pb == 0 ? 5 : pb + 5;
+            }
+        }
+    }
+    out.push_back((int)pairs.size());
+    out.insert(out.end(), pairs.begin(), pairs.end());
 }
 
 bool load_urdf(const std::string &path, bool floating_base, Model &out, std::string &err) {
