@@ -84,11 +84,21 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # DWBC_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
+        # devices, collectives go through host tensors).  The driver's runs use the default, RCCL with one GPU per rank.
+        backend = os.environ.get("DWBC_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
+        backend = None
         torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    cdev = dev if backend in (None, "nccl") else torch.device("cpu")  # where collective buffers live
     B = args.batch
 
     model = D.Model.from_urdf(cases.URDF)
@@ -128,7 +138,8 @@ def main():
         if world == 1:
             return None
         pack = torch.cat([ttau.sum(dim=1), twr, tst.to(torch.float64)[:, None]], dim=1).contiguous()  # B x 46
-        out = torch.empty((world * B, pack.shape[1]), dtype=torch.float64, device=dev)
+        pack = pack.to(cdev)
+        out = torch.empty((world * B, pack.shape[1]), dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(out, pack)
         return out
 
@@ -149,7 +160,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     status_ok = float(tst.float().mean().item())
