@@ -1,0 +1,29 @@
+"""One-off randomized parity sweep on the GPU: the fp64 product kernel against oracle/dwbc_oracle.c on 5 seeds x 4096
+instances for each contact / task configuration of the test-suite (result kept in profiles/r01_final_parity_stress.txt)."""
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+import libdwbc_amd as D
+from tests import cases
+from oracle import orc
+M = orc.make_model(cases.tocabi_model())
+def make(B, tasks):
+    model = D.Model.from_urdf(cases.URDF); w = D.Batch(model, B, device=0)
+    for c in cases.CONTACTS_2: w.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    for lv, links in enumerate(tasks):
+        for mode, link, pt in links: w.add_task(lv, mode, link, pt)
+    w.set_torque_limit(np.array(cases.TAU_LIM)); return w
+B = 4096
+cfgs = {"ds": (cases.TASKS_2LEVEL, {}), "ds_yaw": (cases.TASKS_2LEVEL, dict(yaw=True)), "mixed": (cases.TASKS_2LEVEL, dict(contact_mode="mixed")),
+        "ss_L": (cases.TASKS_3LEVEL_SWING_R, dict(contact_mode="L", levels=3)), "ss_R": (cases.TASKS_3LEVEL_SWING_L, dict(contact_mode="R", levels=3))}
+for name, (tasks, kw) in cfgs.items():
+    w = make(B, tasks); S = orc.make_setup(cases.CONTACTS_2, tasks, cases.TAU_LIM)
+    worst = 0.0; mism = 0; tot = 0; okc = 0
+    for seed in range(5):
+        q, fl, fs = cases.synth_batch(B, seed=9000 + seed, **kw)
+        w.set_state(q); w.set_contact(fl); w.set_fstar_all(fs); w.solve()
+        tau, st = w.get("tau"), w.get("status")
+        tr, wr, sr, _ = orc.cycle_batch(M, S, q, fl, fs, 16)
+        mism += int((st != sr).sum()); tot += B
+        ok = (st == 1) & (sr == 1); okc += int(ok.sum())
+        worst = max(worst, float(np.abs(tau[ok] - tr[ok]).max()))
+    print(f"{name:7s} instances {tot}  status mismatches {mism}  ok {okc}  max|tau - oracle| {worst:.3e}", flush=True)
