@@ -129,8 +129,9 @@ DWBC_WDEV int sweep_inverse_regs(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), rea
         DWBC_SYNC();
     }
     LANES {
+        DWBC_LANE_OPAQUE(le);  // own compares: the prologue's masks are not kept alive (spilled) across the sweep
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le) ? -LV(dg) : -LV(s)[i];
         LV(dg) = -LV(dg);
     }
     DWBC_SYNC();
@@ -148,8 +149,9 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
     static_assert(NN <= 40, "five candidate registers per kr");
     int ok = 1;
     LANES {
+        DWBC_LANE_OPAQUE(lp);
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - real_t(1.0) : LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lp) ? LV(dg) - real_t(1.0) : LV(s)[i];
     }
     for (int kb = 0; kb < (NN + 7) / 8; kb++) {
 #pragma unroll
@@ -164,13 +166,17 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
                 for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[k][i_];
 #endif
                 LANES {
+                    // small NN: the pivot loop unrolls completely, k folds to a constant and the masks would be shared by every inlined
+                    // copy (spills).  Large NN keeps the plain lane: an asm in the loop body sends the register matrix to scratch.
+                    DWBC_LANE_OPAQUE_IF(lk, NN <= 16);
                     // own element k = 8*kb + kr: static candidates, uniform selector
                     real_t cj = LV(s)[kr];
                     if (8 + kr < NN) cj = (kb == 1) ? LV(s)[(8 + kr) < NN ? 8 + kr : 0] : cj;
                     if (16 + kr < NN) cj = (kb == 2) ? LV(s)[(16 + kr) < NN ? 16 + kr : 0] : cj;
                     if (24 + kr < NN) cj = (kb == 3) ? LV(s)[(24 + kr) < NN ? 24 + kr : 0] : cj;
                     if (32 + kr < NN) cj = (kb == 4) ? LV(s)[(32 + kr) < NN ? 32 + kr : 0] : cj;
-                    const real_t h = (lane == k) ? (real_t(1.0) - rp) : cj * rp;
+                    const bool piv = lk == k;
+                    const real_t h = piv ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll
                     for (int i = 0; i < NN; i++) {
 #ifdef DWBC_HOST_EMU
@@ -180,14 +186,15 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
 #endif
                         LV(s)[i] -= ci * h;
                     }
-                    LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
+                    LV(dg) = piv ? -rp : LV(dg) - cj * h;
                 }
             }
         }
     }
     LANES {
+        DWBC_LANE_OPAQUE(le);  // own compares: the prologue's masks are not kept alive (spilled) across the sweep
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le) ? -LV(dg) : -LV(s)[i];
         LV(dg) = -LV(dg);
     }
     return ok;
@@ -205,15 +212,20 @@ DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
     DWBC_LANE_DECL;
     constexpr unsigned long long rel = Topo::relatives(K);
     real_t d = BCAST(dg, K);
-    if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
+    int pos = d > real_t(0.0) ? 1 : 0;
+    DWBC_FLAG_VGPR(pos);
+    ok &= pos;
+    if (!(d > real_t(0.0))) d = real_t(1.0);
     const real_t rp = fast_rcp(d);
 #ifdef DWBC_HOST_EMU
     real_t snap_[NN];
     for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[K][i_];
 #endif
     LANES {
+        DWBC_LANE_OPAQUE(lk);
+        const bool piv = lk == K;
         const real_t cj = LV(s)[K];
-        const real_t h = (lane == K) ? (real_t(1.0) - rp) : cj * rp;
+        const real_t h = piv ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll
         for (int i = 0; i < NN; i++) {
             if ((rel >> i) & 1ull) {
@@ -225,7 +237,7 @@ DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
                 LV(s)[i] -= ci * h;
             }
         }
-        LV(dg) = (lane == K) ? -rp : LV(dg) - cj * h;
+        LV(dg) = piv ? -rp : LV(dg) - cj * h;
     }
     if constexpr (K > 0) tree_pivot<Topo, NN, K - 1>(s, dg, ok);
 }
@@ -236,13 +248,16 @@ DWBC_WDEV int sweep_inverse_tree(PLA_REF(real_t, s, NN), PL_REF(real_t, dg)) {
     static_assert(NN == Topo::ndof, "topology / kernel size mismatch");
     int ok = 1;
     LANES {
+        DWBC_LANE_OPAQUE(lp);
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? LV(dg) - real_t(1.0) : LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lp) ? LV(dg) - real_t(1.0) : LV(s)[i];
     }
     tree_pivot<Topo, NN, NN - 1>(s, dg, ok);
+    ok = DWBC_FLAG_UNIFORM(ok);
     LANES {
+        DWBC_LANE_OPAQUE(le);  // own compares: the prologue's masks are not kept alive (spilled) across the sweep
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lane) ? -LV(dg) : -LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le) ? -LV(dg) : -LV(s)[i];
         LV(dg) = -LV(dg);
     }
     return ok;
@@ -281,10 +296,11 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
     }
     DWBC_SYNC();  // Out may alias Ain
     LANES {
+        DWBC_LANE_OPAQUE(lc);  // see DWBC_LANE_OPAQUE: the unit-vector masks of every inlined copy would otherwise be shared kernel-wide
         real_t y[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            real_t v = (lane == i) ? real_t(1.0) : real_t(0.0);
+            real_t v = (lc == i) ? real_t(1.0) : real_t(0.0);
 #pragma unroll
             for (int k = 0; k < i; k++) v -= Lc[i][k] * y[k];
             y[i] = v * ri[i];
@@ -534,6 +550,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
 #pragma unroll
         for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * k + a] : real_t(0.0);
         if (k > 0) {
+            DWBC_LANE_OPAQUE(lw);
             real_t dp = real_t(0.0);
 #pragma unroll
             for (int i = 0; i < M; i++) {
@@ -541,7 +558,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
                 LV(w)[i] += alpha * pij;
-                dp = (i == lane) ? pij : dp;
+                dp = (i == lw) ? pij : dp;
             }
             LV(dw) += alpha * dp;
         }

@@ -89,6 +89,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
     for (int i = 0; i < NV; i++) xu[i] = real_t(0.0);
     LANES {
+        DWBC_LANE_OPAQUE(lq);
         real_t s2 = real_t(0.0), a2 = real_t(0.0);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
@@ -105,7 +106,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             LV(R.g)[j] *= rg;
-            LV(Mx)[j] = (lane == j) ? real_t(1.0) : real_t(0.0);
+            LV(Mx)[j] = (lq == j) ? real_t(1.0) : real_t(0.0);
         }
         if (LV(R.hi) < DWBC_QP_INF && !zrow) LV(R.hi) *= rg;
         if (LV(R.lo) < DWBC_QP_INF && !zrow) LV(R.lo) *= rg;

@@ -18,6 +18,10 @@
 #define LANES for (int lane = 0; lane < 64; ++lane)
 #define WSYNC() ((void)0)
 #define DWBC_LANE_DECL ((void)0)
+#define DWBC_LANE_OPAQUE(name) const int name = lane
+#define DWBC_LANE_OPAQUE_IF(name, cond) const int name = lane
+#define DWBC_FLAG_VGPR(f) ((void)0)
+#define DWBC_FLAG_UNIFORM(f) (f)
 #define BCAST(x, src) ((x)[(src)])                 /* uniform value of per-lane scalar x in lane src */
 #define BCASTA(x, j, src) ((x)[(src)][(j)])        /* uniform value of per-lane array element x[j] in lane src */
 #define SHFLA(x, j, src) ((x)[(src)][(j)])         /* inside LANES: x[j] of lane `src` (src may differ per lane) */
@@ -36,6 +40,14 @@
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")  /* see DWBC_SYNC in dwbc_cycle.h */
 #endif
 #define DWBC_LANE_DECL const int lane = (int)threadIdx.x
+// a copy of the lane index the optimiser cannot identify with `lane`: comparisons against it are not merged with (and kept
+// alive across) the same comparisons elsewhere -- 39 hoisted `lane == K` masks are 78 SGPRs, i.e. spills through v_writelane
+#define DWBC_LANE_OPAQUE(name) int name = lane; asm volatile("" : "+v"(name))
+#define DWBC_LANE_OPAQUE_IF(name, cond) int name = lane; if constexpr (cond) { asm volatile("" : "+v"(name)); }
+// a wave-uniform flag kept in a VGPR while it is accumulated over unrolled steps (as lane masks, N pending compare results
+// are 2 N SGPRs), and read back as a scalar at the end
+#define DWBC_FLAG_VGPR(f) asm volatile("" : "+v"(f))
+#define DWBC_FLAG_UNIFORM(f) __builtin_amdgcn_readfirstlane(f)
 #define BCAST(x, src) dwbc::readlane_f64((x), (src))
 #define BCASTA(x, j, src) dwbc::readlane_f64((x)[(j)], (src))
 #define SHFLA(x, j, src) __shfl((x)[(j)], (src), 64)
