@@ -10,7 +10,9 @@ OUT=$R/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# the timing pass runs long enough for the clocks to ramp (a 20-step run reads ~4 % slow); the counter passes stay short
+TBENCH="python3 $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline $*"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TBENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 if [ "$MODE" = "full" ]; then
