@@ -569,7 +569,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
     }
     DWBC_FSTAMP(18);  // W + alpha P assembled
-    if (!sweep_inverse_rl<M>(w, dw)) st_contact = 0;
+    // dense, but with compile-time pivots (TopoDense): no selector chain for the lane's own pivot-row element, 126.3 -> 125.3 us
+    if (!sweep_inverse_tree<TopoDense<M>, M>(w, dw)) st_contact = 0;
     DWBC_FSTAMP(19);  // W sweep
     LANES {
         if (k > 0) {

@@ -10,6 +10,13 @@ namespace dwbc {
 // no constant tree: the dense sweep, correct for any model of the instantiated size
 struct TopoGeneric {};
 
+// every pair couples: sweep_inverse_tree<TopoDense<NN>, NN> is the dense sweep with compile-time pivots
+template <int NN>
+struct TopoDense {
+    static constexpr int ndof = NN;
+    static constexpr unsigned long long relatives(int) { return ~0ull; }
+};
+
 // TOCABI (tests/golden/dyros_tocabi.urdf; the robot of every reference test, example and BASELINE config): pelvis 0, left leg
 // 1-6, right leg 7-12, waist 13-15, left arm 16-23, head 24-25, right arm 26-33.  RBDL body order = URDF depth-first order.
 struct TopoTocabi {
