@@ -376,8 +376,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     // ---- NwJw and the projector on null(W) from the closed-form internal-wrench basis (see dwbc_cycle.h stage 1)
     real_t *Vb = L + S::c_Vb, *VG = L + S::c_VG;
     if (k > 0) {
+        // k is 0 or 6 (one or two 6D contacts): inside this block it is the constant K6, so that the small products below
+        // unroll with compile-time strides after inlining
+        static_assert(kMaxActiveContacts == 2, "k in {0, 6}");
+        constexpr int K6 = 6;
         const real_t *Pc = L + S::Pc;
-        for (int idx = th.tid; idx < M * k; idx += NT) {
+        for (int idx = th.tid; idx < M * K6; idx += NT) {
             const int r = idx / 6, a = idx - r * 6;  // k == 6 here
             const int ci = 1 + a / 6, e = a % 6;
             real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
@@ -397,11 +401,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         DWBC_FSTAMP(7);  // Vb
-        for (int idx = th.tid; idx < k * k; idx += NT) {
+        for (int idx = th.tid; idx < K6 * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             real_t acc = real_t(0.0);
             _Pragma("unroll 8")
-            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * k + j];
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * K6 + j];
             L[S::c_s2 + idx] = acc;
         }
         DWBC_FSTAMP(8);  // JV
@@ -410,36 +414,36 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_FSTAMP(8);
         {
             real_t *JV = L + S::c_s2, *Gi = L + S::c_s2 + 36, *Bm = L + S::c_s2 + 72, *Sm6 = L + S::c_s2 + 108;  // 4 x (6x6) in C*C = 144
-            mm_tn<NT>(th, Gi, k, Vb, k, Vb, k, k, M, k);                      // G
+            mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
             DWBC_SYNC();
-            spd_inverse_small(Gi, k, k, Gi, k, L + S::c_s1);                   // G^-1
-            mm_nn<NT>(th, VG, k, Vb, k, Gi, k, M, k, k);                       // VG = Vb G^-1   (projector P = VG Vb^T)
-            mm_nn<NT>(th, Bm, k, JV, k, Gi, k, k, k, k);                       // B = JV G^-1
+            spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::c_s1);                   // G^-1
+            mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1   (projector P = VG Vb^T)
+            mm_nn<NT>(th, Bm, K6, JV, K6, Gi, K6, K6, K6, K6);                       // B = JV G^-1
             DWBC_SYNC();
-            mm_nt<NT>(th, Sm6, k, Bm, k, JV, k, k, k, k);                      // S = B JV^T  (SPD)
+            mm_nt<NT>(th, Sm6, K6, Bm, K6, JV, K6, K6, K6, K6);                      // S = B JV^T  (SPD)
             DWBC_SYNC();
-            if (!spd_inverse_small(Sm6, k, k, Sm6, k, L + S::c_s1)) st_contact = 0;
-            mm_nn<NT>(th, Bm, k, Sm6, k, JV, k, k, k, k);                      // X = S^-1 JV
+            if (!spd_inverse_small(Sm6, K6, K6, Sm6, K6, L + S::c_s1)) st_contact = 0;
+            mm_nn<NT>(th, Bm, K6, Sm6, K6, JV, K6, K6, K6, K6);                      // X = S^-1 JV
             DWBC_SYNC();
-            mm_nt<NT>(th, L + S::NwJw, k, VG, k, Bm, k, M, k, k);              // NwJw = VG X^T
+            mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
             DWBC_SYNC();
         }
         DWBC_FSTAMP(12);  // VG
         // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
-        for (int idx = th.tid; idx < cd * k; idx += NT) {
+        for (int idx = th.tid; idx < cd * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             real_t acc = real_t(0.0);
             _Pragma("unroll 8")
-            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
+            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::NwJw + c * K6 + j];
             L[S::c_s1 + idx] = acc;
         }
         DWBC_SYNC();
-        for (int idx = th.tid; idx < cd * k; idx += NT) {
+        for (int idx = th.tid; idx < cd * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
             const real_t *R = L + S::Rc + a * 9;
-            const real_t *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
-            L[S::FNl + idx] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[k] + R[2 * 3 + x] * src[2 * k];
+            const real_t *src = L + S::c_s1 + (6 * a + 3 * h) * K6 + j;
+            L[S::FNl + idx] = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[K6] + R[2 * 3 + x] * src[2 * K6];
         }
         DWBC_SYNC();
     }
@@ -548,7 +552,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     PLA(real_t, vbr, 6);  // row `lane` of Vb
     LANES {
 #pragma unroll
-        for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * k + a] : real_t(0.0);
+        for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * 6 + a] : real_t(0.0);
         if (k > 0) {
             DWBC_LANE_OPAQUE(lw);
             real_t dp = real_t(0.0);
@@ -556,7 +560,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int i = 0; i < M; i++) {
                 real_t pij = real_t(0.0);
 #pragma unroll
-                for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
+                for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
                 LV(w)[i] += alpha * pij;
                 dp = (i == lw) ? pij : dp;
             }
@@ -578,7 +582,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int i = 0; i < M; i++) {
                 real_t pij = real_t(0.0);
 #pragma unroll
-                for (int a = 0; a < 6; a++) pij += VG[i * k + a] * LV(vbr)[a];
+                for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
                 LV(w)[i] -= ialpha * pij;
             }
         }
@@ -645,19 +649,30 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 real_t jk[TT], qw[TT];
 #pragma unroll
                 for (int r = 0; r < TT; r++) qw[r] = QW[r * M + (lane < M ? lane : 0)];
+                const bool exact = t == TT;  // the usual case (task dof 3 or 6): compile-time stride, no per-element guards
 #pragma unroll
                 for (int r2 = 0; r2 < TT; r2++) {
                     real_t acc = real_t(0.0);
+                    if (exact) {
 #pragma unroll
-                    for (int r = 0; r < TT; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : real_t(0.0);
+                        for (int r = 0; r < TT; r++) acc += qw[r] * Pi[r * TT + r2];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < TT; r++) acc += (r < t && r2 < t) ? qw[r] * Pi[r * t + r2] : real_t(0.0);
+                    }
                     jk[r2] = acc;
                     if (dump && lane < M && r2 < t) dump[dl.J_kt + lv * M * T + lane * t + r2] = acc;
                 }
 #pragma unroll
                 for (int r3 = 0; r3 < TT; r3++) {
                     real_t acc = real_t(0.0);
+                    if (exact) {
 #pragma unroll
-                    for (int r2 = 0; r2 < TT; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : real_t(0.0);
+                        for (int r2 = 0; r2 < TT; r2++) acc += jk[r2] * Lt[r2 * TT + r3];
+                    } else {
+#pragma unroll
+                        for (int r2 = 0; r2 < TT; r2++) acc += (r2 < t && r3 < t) ? jk[r2] * Lt[r2 * t + r3] : real_t(0.0);
+                    }
                     if (lane < M) {
                         Xs[lane * T + r3] = acc;
                         Ul[lane * T + r3] = acc;
