@@ -451,7 +451,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_FSTAMP(13);  // FNl
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
     for (int lv = 0; lv < su.n_levels; lv++) {
-        const int t = su.t_dof[lv];
+        // the level body is instantiated for 3 and 6 task rows; in the lean build (no TASK_CUSTOM level) the row count of a
+        // level is exactly one of the two, so `t` is a compile-time constant there and every t-dependent loop unrolls
+        auto level_body = [&](auto ttl) {
+        constexpr int TTL = decltype(ttl)::value;
+        const int t = kExtras ? su.t_dof[lv] : TTL;
         real_t *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
         const unsigned long long tm = su.t_dofmask[lv];
         DWBC_SYNC();
@@ -527,6 +531,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jtt[(idx % N) * T + idx / N];
             for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
         }
+            };
+        if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
     }
     DWBC_SYNC();
     DWBC_STAMP(3);  // task Jacobians / Lambda_task / NwJw / projector done
@@ -609,7 +615,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     // ================= stage 3a: task-space dynamics for every level (wbd.cpp:207-261) =================
     int rankbad = 0;
     for (int lv = 0; lv < su.n_levels; lv++) {
-        const int t = su.t_dof[lv];
+        // the level body is instantiated for 3 and 6 task rows; in the lean build (no TASK_CUSTOM level) the row count of a
+        // level is exactly one of the two, so `t` is a compile-time constant there and every t-dependent loop unrolls
+        auto level_body = [&](auto ttl) {
+        constexpr int TTL = decltype(ttl)::value;
+        const int t = kExtras ? su.t_dof[lv] : TTL;
         const real_t *Lt = L + S::c_Lt + lv * T * T;
         const FastDiv fdt(t);
         const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
@@ -704,6 +714,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         if (!cond) rankbad |= (1 << lv);
         DWBC_STAMP(6 + 3 * lv);
+            };
+        if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
     }
     DWBC_SYNC();
 
