@@ -358,7 +358,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     constexpr int M = S::M, C = S::C, T = S::T;
     DWBC_LANE_DECL;
     (void)iL;
-    const int nb = su.nb;
+    // a constant tree fixes the body count and the depth as well (the launcher checked the model against it)
+    constexpr bool kTree = !std::is_same<Topo, TopoGeneric>::value;
+    const int nb = kTree ? NB : su.nb;
     const real_t *body = io.body;
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
     const io_t *qin = io.q + (size_t)inst * (N + 1);

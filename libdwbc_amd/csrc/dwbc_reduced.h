@@ -265,7 +265,8 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     constexpr bool kExtras = true;
     DWBC_LANE_DECL;
     (void)iL;
-    const int nb = su.nb;
+    constexpr bool kTree = !std::is_same<Topo, TopoGeneric>::value;
+    const int nb = kTree ? NB : su.nb;
     const real_t *body = io.body;
     const int *topo = io.topo;
     const io_t *qin = io.q + (size_t)inst * (N + 1);

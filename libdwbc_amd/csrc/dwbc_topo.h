@@ -22,6 +22,7 @@ struct TopoDense {
 struct TopoTocabi {
     static constexpr int nb = 34;
     static constexpr int ndof = nb + 5;
+    static constexpr int maxdepth = 11;  // deepest bodies: the hands (3 waist joints + 8 arm joints below the pelvis)
     static constexpr int parent[nb] = {0, 0, 1, 2, 3, 4, 5, 0, 7, 8, 9, 10, 11, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 15, 24, 15, 26, 27, 28, 29, 30, 31, 32};
     static constexpr bool anc_or_self(int a, int b) {
         while (b > a) b = parent[b];
@@ -37,6 +38,16 @@ struct TopoTocabi {
         }
         return m;
     }
+    static constexpr int depth_of(int b) {
+        int d = 0;
+        while (b > 0) { b = parent[b]; d++; }
+        return d;
+    }
+    static constexpr int computed_maxdepth() {
+        int m = 0;
+        for (int b = 0; b < nb; b++) m = depth_of(b) > m ? depth_of(b) : m;
+        return m;
+    }
     static bool matches(int n_bodies, const int *par) {
         if (n_bodies != nb) return false;
         for (int i = 0; i < nb; i++)
@@ -44,5 +55,7 @@ struct TopoTocabi {
         return true;
     }
 };
+
+static_assert(TopoTocabi::computed_maxdepth() == TopoTocabi::maxdepth, "TopoTocabi::maxdepth");
 
 }  // namespace dwbc
