@@ -558,9 +558,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const real_t ialpha = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
     DWBC_SYNC();
     PLA(real_t, vbr, 6);  // row `lane` of Vb
+    PLA(real_t, pc, M);   // column `lane` of the projector P = VG Vb^T: kept in registers across the sweep for the correction
     LANES {
 #pragma unroll
         for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * 6 + a] : real_t(0.0);
+#pragma unroll
+        for (int i = 0; i < M; i++) LV(pc)[i] = real_t(0.0);
         if (k > 0) {
             DWBC_LANE_OPAQUE(lw);
             real_t dp = real_t(0.0);
@@ -569,6 +572,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 real_t pij = real_t(0.0);
 #pragma unroll
                 for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
+                LV(pc)[i] = pij;
                 LV(w)[i] += alpha * pij;
                 dp = (i == lw) ? pij : dp;
             }
@@ -587,12 +591,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     LANES {
         if (k > 0) {
 #pragma unroll
-            for (int i = 0; i < M; i++) {
-                real_t pij = real_t(0.0);
-#pragma unroll
-                for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
-                LV(w)[i] -= ialpha * pij;
-            }
+            for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];
         }
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         real_t acc = real_t(0.0);
