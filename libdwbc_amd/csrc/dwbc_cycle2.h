@@ -788,11 +788,13 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         {
             // task level: x = [f*_qp (t) ; contact_qp (k)], rows [U | s NwJw];  redistribution: x = c (k), rows [NwJw]
             const real_t *P1 = is_task ? Ul : L + S::NwJw;
-            const int ld1 = is_task ? T : k, n1 = is_task ? t : k, n2 = is_task ? k : 0;
+            // strides of NwJw / FNl: k is 0 (blocks unused) or 6, so the constant 6 serves both and folds after inlining
+            static_assert(T == 6, "stride of U equals the stride of NwJw");
+            const int n1 = is_task ? t : k, n2 = is_task ? k : 0;
             const real_t *W1 = is_task ? F : L + S::FNl;
-            const int ldw1 = is_task ? kQpLd : k;
-            qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, ld1, n1, L + S::NwJw, k, n2,
-                                     is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, k, fv, base, n1,
+            const int ldw1 = is_task ? kQpLd : 6;
+            qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
+                                     is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, 6, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
         }
         const int slot = is_task ? qi : kMaxLevels;
@@ -818,7 +820,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
                 real_t c = real_t(0.0);
                 _Pragma("unroll 8")
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[t + j];
                 L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
             }
             if (dump) {
@@ -829,7 +831,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int i = th.tid; i < M; i += NT) {
                 real_t c = real_t(0.0);
                 _Pragma("unroll 8")
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[j];
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[j];
                 L[S::tc + i] += c;    // torque_contact_ += NwJw c   (dwbc.cpp:1549)
             }
             if (dump)
