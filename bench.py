@@ -5,13 +5,21 @@ A "step" = one pass of the fused hot path (UpdateKinematics .. CalcContactRedist
 batch of B synthetic TOCABI states that are already resident in HBM.  N = 1 workload = BASELINE.json configs[1]:
 batch = 1024, double support, 2-level HQP (pelvis 6D, upper-body rotation), tau limit 300, fp64.
 N > 1: every rank solves its own B instances (weak scaling, no data-path collective); the only collective is the
-final RCCL all_gather of (tau[33], wrench[12], status) of the last step, inside the timed region.
+final RCCL all_gather of (tau[33], wrench[12], status) of the last step, inside the timed region
+(libdwbc_amd/shard.py: slice bounds, packing, gather).
+
+`python bench.py --gpus N` without WORLD_SIZE in the environment is its own launcher: it starts N fresh child
+processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything in the parent touches the
+GPU and exits with their status.  Under torchrun (WORLD_SIZE set) it is a rank.  DWBC_BENCH_BACKEND=gloo rehearses the
+multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the gather goes through host tensors).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,11 @@ F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit 
 PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak (public spec), for --dtype f32 runs
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
+# The governing roof is fp64 arithmetic throughput: 78.6 TFLOP/s whether issued as VALU FMAs or as MFMA f64 (same rate on
+# MI355X).  The contract's label for a compute roof is "mfma"; the note says which pipe the kernel actually uses.
+ROOF_BOUND = "mfma"
+ROOF_NOTE = ("compute roof = fp64 FMA throughput, 78.6 TFLOP/s public spec (vector rate = matrix rate on MI355X); the kernel issues "
+             "its fp64 work on the VALU (no MFMA instruction); algorithmic flop of the reference's dense formulas")
 
 
 def host_cores():
@@ -55,7 +68,7 @@ def hbm_traffic_per_launch(kernel_name, batch):
         return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -68,51 +81,166 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="arithmetic type of the kernels (f32: measured for DESIGN.md only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
 
-    import libdwbc_amd as D
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started by hand: N child processes, one rank per GPU.  The parent has not imported torch or
+    touched the GPU (a process that has must never be re-executed on this pool), it only waits and returns the worst status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+class HipEngine:
+    """The product path of one rank: a Batch of B instances on the rank's GPU with inputs and outputs bound to torch tensors."""
+
+    def __init__(self, args, rank, local_rank):
+        import torch
+
+        import libdwbc_amd as D
+        from tests import cases
+
+        self.torch = torch
+        self.dev = torch.device(f"cuda:{local_rank}")
+        B = args.batch
+        model = D.Model.from_urdf(cases.URDF)
+        wbc = D.Batch(model, B, device=local_rank, dtype=args.dtype)
+        for c in cases.CONTACTS_2:
+            wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+        wbc.add_task(0, D.TASK_LINK_6D, 0)
+        wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+        wl = args.workload
+        self.reduced = wl == "reduced"
+        self.hqp = not args.no_hqp
+        if wl == "ss3":
+            wbc.add_task(2, D.TASK_LINK_6D, 12)  # swing (right) foot, SURVEY 8d config 3
+        if not self.reduced:
+            wbc.set_torque_limit(np.array(cases.TAU_LIM))  # the reference's reduced path runs without the limit (App. C-10)
+        q, flags, fstar = rank_inputs(args, rank)
+        dev = self.dev
+        self.tq = torch.from_numpy(q).to(dev)
+        self.tf = torch.from_numpy(flags).to(dev)
+        self.ts = torch.from_numpy(fstar).to(dev)
+        self.tau = torch.zeros((B, 3, 33), dtype=torch.float64, device=dev)
+        self.wrench = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+        self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        for name, t in (("in_q", self.tq), ("in_contact", self.tf), ("in_fstar", self.ts), ("tau", self.tau), ("wrench", self.wrench), ("status", self.status)):
+            wbc.bind_tensor(name, t)
+        self.stream = torch.cuda.current_stream()
+        wbc.set_stream(self.stream.cuda_stream)
+        self.wbc = wbc
+
+    def solve(self):
+        self.wbc.solve(hqp=self.hqp, reduced=self.reduced)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def kernel_ms(self, steps):
+        """kernel-only time with HIP events on the launch stream (roofline.achieved)"""
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(self.stream)
+        for _ in range(steps):
+            self.solve()
+        ev1.record(self.stream)
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / steps
+
+    def info(self):
+        nt, lds = self.wbc.launch_info()
+        return dict(kernel=self.wbc.kernel_name(), threads=nt, lds=lds)
+
+
+def rank_inputs(args, rank):
+    """Seeded synthetic inputs of one rank (SURVEY 8d recipe); the global batch of an N-rank job is their concatenation."""
     from tests import cases
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    kw = {"ss3": dict(contact_mode="L", levels=3), "mixed": dict(contact_mode="mixed")}.get(args.workload, {})
+    return cases.synth_batch(args.batch, seed=20251226 + 2 + 1000 * rank, **kw)
+
+
+def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
+    """One rank of the job: warm up, time exactly `steps` solves + the final gather between barriers, return (on rank 0) the
+    JSON line and the gathered [tau_total | wrench | status] rows of all ranks.  `engine_factory` is the solver of the rank's
+    slice (the HIP engine; tests/test_sharding_gloo.py passes a CPU stand-in to drive this function without a GPU)."""
+    import torch
+
+    from libdwbc_amd import shard
+
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # DWBC_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
-        # devices, collectives go through host tensors).  The driver's runs use the default, RCCL with one GPU per rank.
-        backend = os.environ.get("DWBC_BENCH_BACKEND", "nccl")
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    else:
-        backend = None
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    cdev = dev if backend in (None, "nccl") else torch.device("cpu")  # where collective buffers live
+    eng = engine_factory(args, rank, local_rank)
     B = args.batch
+    total = world * B
+    lo, hi = shard.shard_range(total, rank, world)  # this rank's contiguous slice of the global batch
+    assert hi - lo == B
+    sizes = [shard.shard_range(total, r, world)[1] - shard.shard_range(total, r, world)[0] for r in range(world)]
+    cdev = eng.dev if backend in (None, "nccl") else torch.device("cpu")  # where collective buffers live
 
-    model = D.Model.from_urdf(cases.URDF)
-    wbc = D.Batch(model, B, device=local_rank, dtype=args.dtype)
-    for c in cases.CONTACTS_2:
-        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
-    wbc.add_task(0, D.TASK_LINK_6D, 0)
-    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
-    wl = args.workload
-    reduced = wl == "reduced"
-    if wl == "ss3":
-        wbc.add_task(2, D.TASK_LINK_6D, 12)  # swing (right) foot, SURVEY 8d config 3
-    if not reduced:
-        wbc.set_torque_limit(np.array(cases.TAU_LIM))  # the reference's reduced path runs without the limit (App. C-10)
+    def gather_final():
+        pack = shard.pack_outputs_torch(eng.tau, eng.wrench, eng.status)
+        if world == 1:
+            return pack
+        return shard.gather_packed(pack.to(cdev), dist, world, sizes)
+
+    for _ in range(args.warmup):
+        eng.solve()
+    gather_final()
+    eng.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.solve()
+    gathered = gather_final()
+    eng.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    status_ok = float(eng.status.float().mean().item())
+    kern_ms = eng.kernel_ms(args.steps)
+    line = None
+    if rank == 0:
+        line = make_line(args, world, dt, kern_ms, status_ok, eng.info(), backend)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return line, gathered
+
+
+def make_line(args, world, dt, kern_ms, status_ok, info, backend):
+    B, wl = args.batch, args.workload
     f_alg = {"ds2": F_ALG, "ss3": 1.37e6, "mixed": F_ALG, "reduced": F_ALG}[wl]
     workload_name = {
         "ds2": "BASELINE configs[1]: batch=1024 per GPU, TOCABI double support, 2-level HQP (pelvis 6D + upper-body rotation), tau limit 300, fp64",
@@ -120,128 +248,106 @@ def main():
         "mixed": "BASELINE configs[3]: TOCABI mixed contact modes LR/L/R = 1/2,1/4,1/4 per instance, 2-level HQP, tau limit 300, fp64",
         "reduced": "BASELINE configs[4] in fp64: TOCABI double support through the reduced (centroidal) dynamics path, 2-level HQP, no tau limit",
     }[wl]
-    kw = {"ss3": dict(contact_mode="L", levels=3), "mixed": dict(contact_mode="mixed")}.get(wl, {})
-    q, flags, fstar = cases.synth_batch(B, seed=20251226 + 2 + 1000 * rank, **kw)
-    tq = torch.from_numpy(q).to(dev)
-    tf = torch.from_numpy(flags).to(dev)
-    ts = torch.from_numpy(fstar).to(dev)
-    # outputs packed per instance as [tau(3x33) | wrench(12) | status] for the final gather
-    ttau = torch.zeros((B, 3, 33), dtype=torch.float64, device=dev)
-    twr = torch.zeros((B, 12), dtype=torch.float64, device=dev)
-    tst = torch.zeros((B,), dtype=torch.int32, device=dev)
-    for name, t in (("in_q", tq), ("in_contact", tf), ("in_fstar", ts), ("tau", ttau), ("wrench", twr), ("status", tst)):
-        wbc.bind_tensor(name, t)
-    stream = torch.cuda.current_stream()
-    wbc.set_stream(stream.cuda_stream)
+    value = world * B * args.steps / dt
+    achieved = f_alg * B / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+    peak = PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS
+    line = {
+        "metric": "HQP control cycles/sec (batched TOCABI)",
+        "value": value,
+        "unit": "cycles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": workload_name + (" [hqp = false]" if args.no_hqp else ""),
+            "batch_per_gpu": B,
+            "threads_per_instance": info["threads"],
+            "lds_bytes_per_instance": info["lds"],
+            "status_ok_fraction": status_ok,
+            "collective_backend": {None: "none (one rank)", "nccl": "rccl"}.get(backend, backend),
+        },
+        "roofline": {
+            "bound": ROOF_BOUND,
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": achieved / peak if achieved else None,
+            "traffic": hbm_traffic_per_launch(info["kernel"], B),
+            "traffic_unit": "bytes per launch, from the committed rocprofv3 PMC passes of this command (FETCH_SIZE + WRITE_SIZE, "
+                            + os.path.relpath(PMC_SUMMARY, ROOT) + "), not measured in this run",
+            "kernel": info["kernel"],
+            "kernel_ms": kern_ms,
+            "flop_per_cycle": f_alg,
+            "note": ROOF_NOTE,
+        },
+    }
+    return line
 
-    def gather_final():
-        if world == 1:
-            return None
-        pack = torch.cat([ttau.sum(dim=1), twr, tst.to(torch.float64)[:, None]], dim=1).contiguous()  # B x 46
-        pack = pack.to(cdev)
-        out = torch.empty((world * B, pack.shape[1]), dtype=torch.float64, device=cdev)
-        dist.all_gather_into_tensor(out, pack)
-        return out
 
-    for _ in range(args.warmup):
-        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
-    gather_final()
-    torch.cuda.synchronize()
+def cpu_baseline(args):
+    """The CPU restatement (oracle, OpenMP over instances) timed on this box's host cores on a bounded sample of the workload."""
+    from oracle import orc
+    from tests import cases
+
+    M = orc.make_model(cases.tocabi_model())
+    S = orc.make_setup(cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    cores = host_cores()
+    qs, fls, fss = cases.synth_batch(2048, seed=20251226 + 2)
+    orc.cycle_batch(M, S, qs[:64], fls[:64], fss[:64], cores)
+    done, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < args.cpu_seconds:
+        orc.cycle_batch(M, S, qs, fls, fss, cores)
+        done += qs.shape[0]
+    cdt = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    orc.cycle_batch(M, S, qs[:512], fls[:512], fss[:512], 1)
+    single = 512 / (time.perf_counter() - t2)
+    return {
+        "value": done / cdt,
+        "unit": "cycles/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} cycles of the same workload (2048-instance seeded batches repeated for {cdt:.1f} s), "
+                  f"oracle/dwbc_oracle.c -O3 OpenMP over instances; single thread: {single:.0f} cycles/s",
+    }
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args.gpus, argv)  # nothing above has touched the GPU
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}", file=sys.stderr)
+        return 2
+    backend = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
-    gather_final()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    status_ok = float(tst.float().mean().item())
+        # DWBC_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks.  The driver's runs use
+        # the default, RCCL with one GPU per rank.
+        backend = os.environ.get("DWBC_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            import torch
 
-    # kernel-only time with HIP events on the launch stream (roofline.achieved)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(args.steps):
-        wbc.solve(hqp=not args.no_hqp, reduced=reduced)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+    line, _ = rank_main(args, rank, local_rank, world, backend)
     if rank == 0:
-        value = world * B * args.steps / dt
-        achieved = f_alg * B / (kern_ms * 1e-3) / 1e12
-        nt, lds = wbc.launch_info()
-        line = {
-            "metric": "HQP control cycles/sec (batched TOCABI)",
-            "value": value,
-            "unit": "cycles/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": workload_name + (" [hqp = false]" if args.no_hqp else ""),
-                "batch_per_gpu": B,
-                "threads_per_instance": nt,
-                "lds_bytes_per_instance": lds,
-                "status_ok_fraction": status_ok,
-            },
-            "roofline": {
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / (PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS),
-                "traffic": hbm_traffic_per_launch(wbc.kernel_name(), B),
-                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_final_pmc_summary.json)",
-                "kernel": wbc.kernel_name(),
-                "kernel_ms": kern_ms,
-                "flop_per_cycle": f_alg,
-                "note": "fp64 FMA roof (vector = matrix rate on MI355X, public spec 78.6 TFLOP/s); algorithmic flop of the "
-                        "reference's dense formulas.  batch 1024 = one wave per SIMD, where tools/ubench measures 23.3 TFLOP/s "
-                        "for back-to-back fp64 FMAs from a single wave (24.0 for MFMA f64 16x16x4): DESIGN.md 'Measured'",
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline and wl == "ds2":
-            from oracle import orc
-
-            M = orc.make_model(cases.tocabi_model())
-            S = orc.make_setup(cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
-            cores = host_cores()
-            qs, fls, fss = cases.synth_batch(2048, seed=20251226 + 2)
-            orc.cycle_batch(M, S, qs[:64], fls[:64], fss[:64], cores)
-            done, t1 = 0, time.perf_counter()
-            while time.perf_counter() - t1 < args.cpu_seconds:
-                orc.cycle_batch(M, S, qs, fls, fss, cores)
-                done += qs.shape[0]
-            cdt = time.perf_counter() - t1
-            t2 = time.perf_counter()
-            orc.cycle_batch(M, S, qs[:512], fls[:512], fss[:512], 1)
-            single = 512 / (time.perf_counter() - t2)
-            line["cpu_baseline"] = {
-                "value": done / cdt,
-                "unit": "cycles/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": f"{done} cycles of the same workload (2048-instance seeded batches repeated for {cdt:.1f} s), "
-                          f"oracle/dwbc_oracle.c -O3 OpenMP over instances; single thread: {single:.0f} cycles/s",
-            }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "ds2":
+            line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

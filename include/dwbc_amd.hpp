@@ -167,7 +167,8 @@ class RobotData {
             cc_[i].contact = on; flags_[i] = on ? 1 : 0;
             if (on) { contact_link_num_++; contact_dof_ += 6; }
         }
-        dwbc_batch_set_contact(batch_, flags_.data());
+        contact_ok_ = dwbc_batch_set_contact(batch_, flags_.data()) != 0;
+        if (!contact_ok_) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;  // e.g. more than 2 active contacts
         dirty_ = true;
     }
     // ---- tasks (dwbc.h:318-333)
@@ -269,7 +270,7 @@ class RobotData {
     dwbc_model *model_ = nullptr;
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
-    bool dirty_ = true, redistributed_ = false, reduced_ = false, hqp_ = true;
+    bool dirty_ = true, redistributed_ = false, reduced_ = false, hqp_ = true, contact_ok_ = true;
     double sent_time_ = -1.0e300;
     void reduced_on() { if (!reduced_) { reduced_ = true; dirty_ = true; } }
     int diag_[96] = {0};
@@ -290,7 +291,7 @@ class RobotData {
         return m;
     }
     int refresh(bool init = true) {
-        if (!batch_) return 0;
+        if (!batch_ || !contact_ok_) return 0;  // a refused SetContact leaves nothing to solve
         for (size_t l = 0; l < ts_.size(); l++)  // task-link trajectories / gains set since the last launch
             for (size_t j = 0; j < ts_[l].task_link_.size(); j++) {
                 TaskLinkView &tl = ts_[l].task_link_[j];
@@ -303,7 +304,7 @@ class RobotData {
         if (control_time_ != sent_time_) { dwbc_batch_set_control_time(batch_, &control_time_); sent_time_ = control_time_; dirty_ = true; }
         if (!dirty_) return 1;
         if (!dwbc_batch_solve(batch_, (hqp_ ? DWBC_SOLVE_HQP : 0) | (init ? DWBC_SOLVE_INIT : 0) | (reduced_ ? DWBC_SOLVE_REDUCED : 0))) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
-        const int n = system_dof_, m = model_dof_, cd = contact_dof_, k = cd > 6 ? cd - 6 : 0;
+        const int n = system_dof_, m = model_dof_, cd = contact_dof_ > 12 ? 12 : (int)contact_dof_, k = cd > 6 ? cd - 6 : 0;
         std::vector<double> tau(3 * m);
         dwbc_batch_get(batch_, DWBC_TAU, tau.data(), tau.size() * 8);
         torque_grav_.assign(tau.begin(), tau.begin() + m);

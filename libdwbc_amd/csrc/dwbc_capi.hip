@@ -352,6 +352,14 @@ int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, con
 int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags) {
     if (b->su.n_contacts == 0) return fail("Contact Constraint size mismatch");  // include/dwbc.h:438-441
     if (b->d_flags && !b->own_flags) return fail("contact flags are bound to a device buffer");
+    // the kernels stack at most kMaxActiveContacts simultaneous 6D contacts (the reference: any number, src/dwbc.cpp:445-453);
+    // an instance with more is refused here instead of failing on the device (status 0, zero torques)
+    const int ncn = b->su.n_contacts;
+    for (int i = 0; i < b->B; i++) {
+        int on = 0;
+        for (int c = 0; c < ncn; c++) on += flags[(size_t)i * ncn + c] ? 1 : 0;
+        if (on > kMaxActiveContacts) return fail("more than 2 simultaneously active contacts in one instance: not supported by the device path");
+    }
     memcpy(b->h_flags.data(), flags, b->h_flags.size());
     b->dirty_flags = true;
     return 1;
@@ -437,8 +445,7 @@ static bool lean_ok(const dwbc_batch *b) {
 }
 
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
-    const char *kv = getenv("DWBC_KERNEL");
-    const int which = reduced ? 2 : ((kv && std::string(kv) == "v1") ? 1 : 0);
+    const int which = reduced ? 2 : 0;
     return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind);
 }
 
@@ -544,7 +551,6 @@ static int launch(dwbc_batch *b, bool reduced = false) {
 int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
     b->hqp = (flags & DWBC_SOLVE_HQP) ? 1 : 0;
     if (!b->hqp && (flags & DWBC_SOLVE_REDUCED)) return fail("hqp=false is not built on the reduced dynamics path");
-    if (!b->hqp && getenv("DWBC_KERNEL") && std::string(getenv("DWBC_KERNEL")) == "v1") return fail("hqp=false needs the default kernel");
     if (b->su.n_levels < 1) return fail("no task space");
     if (b->su.n_contacts < 1) return fail("no contact constraint");
     const bool reduced = flags & DWBC_SOLVE_REDUCED;
@@ -752,11 +758,6 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     const std::string sz = std::to_string(ke->n) + ", " + std::to_string(ke->nb);
     if (b->last_reduced) {
         name = pre + "dwbc_cycle_kernel_reduced<" + sz + ", " + std::to_string(ke->nlv) + ", 64" + topo + ">";
-        return name.c_str();
-    }
-    const char *kv = getenv("DWBC_KERNEL");
-    if (kv && std::string(kv) == "v1" && b->dtype != DWBC_F32) {
-        name = pre + "dwbc_cycle_kernel<" + sz + ", 64>";
         return name.c_str();
     }
     int n_cu = b->n_cu;

@@ -850,11 +850,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
 
     // ================= outputs =================
     io_t *tau = io.tau + (size_t)inst * 3 * M;
-    for (int i = th.tid; i < 3 * M; i += NT) tau[i] = L[S::tg + i];
+    for (int i = th.tid; i < 3 * M; i += NT) tau[i] = too_many ? real_t(0.0) : L[S::tg + i];
     io_t *wr = io.wrench + (size_t)inst * 12;
     for (int i = th.tid; i < 12; i += NT) {
         real_t acc = real_t(0.0);
-        if (i < cd) {
+        if (i < cd && !too_many) {
             acc = -L[S::PC + i];
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);

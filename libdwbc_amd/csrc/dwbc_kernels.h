@@ -8,21 +8,7 @@
 
 namespace dwbc {
 
-// ------------------------------------------------------------------------------------------------
-// kernel: one workgroup (one 64-lane wavefront) per robot instance, everything between q and tau in LDS
-// ------------------------------------------------------------------------------------------------
-template <int N, int NB, int NT>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel(const Setup su, const BatchIO io) {
-    static_assert(NT == 64, "one wavefront per instance: DWBC_SYNC is a wavefront-scope fence");
-    extern __shared__ __attribute__((aligned(16))) real_t lds[];
-    const int inst = blockIdx.x;
-    if (inst >= io.B) return;
-    Thr th{(int)threadIdx.x};
-    int *iL = reinterpret_cast<int *>(lds + Lds<N, NB>::total);
-    cycle_instance<N, NB, NT>(th, su, io, inst, lds, iL);
-}
-
-// register-resident version (dwbc_cycle2.h): the default.  Two builds of the same body:
+// register-resident kernel (dwbc_cycle2.h): one workgroup (one 64-lane wavefront) per robot instance.  Two builds of the same body:
 //   _v2   amdgpu_waves_per_eu(2): VGPR + AGPR <= 256, so a fifth workgroup of a CU (the LDS map allows 5 at <= 31 KB) can
 //         share a SIMD -- the throughput build for batches larger than 4 instances per CU
 //   _v2w  no register cap (one wave per SIMD): ~7 % shorter single-instance latency -- used while B <= 4 x CUs
@@ -70,7 +56,6 @@ struct KernelEntry {
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
 // flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).
-// index 0: register-resident kernel (default); index 1: LDS-resident reference kernel (DWBC_KERNEL=v1, for A/B runs)
 #ifdef DWBC_EXPERIMENT
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
@@ -106,22 +91,9 @@ const KernelEntry kKernelsReduced[] = {
     {39, 34, 4, 0, dwbc_cycle_kernel_reduced<39, 34, 4, kNT, TopoGeneric>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
-#ifdef DWBC_EXPERIMENT
-const KernelEntry kKernelsV1[] = {{0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr}};
-#else
-const KernelEntry kKernelsV1[] = {
-    {39, 34, 0, 0, dwbc_cycle_kernel<39, 34, kNT>, Lds<39, 34>::total_bytes, nullptr, nullptr, nullptr},
-};
-#endif
-
-// which: 0 = register-resident kernel (default), 1 = LDS-resident reference kernel (DWBC_KERNEL=v1), 2 = reduced dynamics
+// which: 0 = full-model kernel, 2 = reduced dynamics
 // topo: Setup::topo_kind of the loaded model -- an instantiation for that constant tree is preferred, else the generic one
 inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which, int topo) {
-    if (which == 1) {
-        for (const auto &k : kKernelsV1)
-            if (k.n == n && k.nb == nb) return &k;
-        return nullptr;
-    }
     for (int pass = 0; pass < 2; pass++) {
         const int want = pass == 0 ? topo : 0;
         if (which == 2) {

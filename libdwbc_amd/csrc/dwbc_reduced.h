@@ -1048,6 +1048,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             }
             c_ = (i < cd && i < RM && k > 0) ? L[S::tcR + i] : real_t(0.0);
             if (!st_task) { t_ = real_t(0.0); c_ = real_t(0.0); }
+            if (too_many) { g_ = real_t(0.0); t_ = real_t(0.0); c_ = real_t(0.0); }
             tau[i] = g_;
             tau[M + i] = t_;
             tau[2 * M + i] = c_;
@@ -1057,7 +1058,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
         io_t *wr = io.wrench + (size_t)inst * 12;
         for (int i = th.tid; i < 12; i += NT) {
             real_t acc = real_t(0.0);
-            if (i < cd) {
+            if (i < cd && !too_many) {
                 acc = -L[S::PC + i];
                 for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * L[S::tg + c];
             }

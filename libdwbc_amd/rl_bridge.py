@@ -14,6 +14,12 @@ qpos is MuJoCo order (pos3, quaternion w x y z, 33 joints); the reorder to RBDL 
 last) follows rl_wbc_bridge.cpp:88-98.  The controller setup (feet contacts, pelvis 6D + upper-body rotation tasks,
 torque limit 300) is rl_wbc_bridge.cpp:19-43.  numpy arrays or torch CUDA tensors are accepted; with CUDA tensors the
 reorder runs on the device and nothing crosses PCIe.
+
+`hqp`: the reference's CalcTorque() (rl_wbc_bridge.cpp:123-129) sets `task_init = false` and calls
+`CalcTaskControlTorque(task_init)` / `CalcContactRedistribute(task_init)`, whose FIRST parameter is `hqp`
+(include/dwbc.h:349,298) -- so the reference bridge effectively runs hqp = false (plain task hierarchy + closed-form
+two-foot redistribution, no QP, no torque-limit or cone rows) with init = true.  hqp=False (the default) reproduces
+that; hqp=True runs the QP cascade every step (what tests/dwbc_test.cpp exercises and what the goldens pin).
 """
 import numpy as np
 
@@ -39,9 +45,11 @@ def mujoco_to_rbdl_q(qpos):
 
 
 class RlWBCBridge:
-    def __init__(self, n_envs, urdf, device=0, torque_limit=300.0, dtype="f64"):
-        """dtype="f32": the fp32 kernels -- the bridge returns float32 torques either way"""
+    def __init__(self, n_envs, urdf, device=0, torque_limit=300.0, dtype="f64", hqp=False):
+        """dtype="f32": the fp32 kernels -- the bridge returns float32 torques either way.
+        hqp=False: the reference bridge's effective behaviour (module docstring); hqp=True: QP cascade every step."""
         self.n_envs = int(n_envs)
+        self.hqp = bool(hqp)
         self.model = Model.from_urdf(urdf)
         self.wbc = Batch(self.model, self.n_envs, device=device, dtype=dtype)
         self.model_dof = self.wbc.m
@@ -87,7 +95,8 @@ class RlWBCBridge:
 
     # reference rl_wbc_bridge.cpp:123-129
     def CalcTorque(self):
-        self.wbc.solve(hqp=True, init=self.task_init)
+        # hqp = false: the closed-form branch has no QP state, `init` is irrelevant there (the reference passes true)
+        self.wbc.solve(hqp=self.hqp, init=True if not self.hqp else self.task_init)
         self.task_init = False
 
     # reference rl_wbc_bridge.cpp:131-139: float vector of torque_grav_ + torque_task_ + torque_contact_

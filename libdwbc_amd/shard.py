@@ -16,6 +16,13 @@ def pack_outputs(tau, wrench, status):
     return np.concatenate([tau.sum(axis=1), np.asarray(wrench), np.asarray(status, dtype=np.float64)[:, None]], axis=1)
 
 
+def pack_outputs_torch(tau, wrench, status):
+    """the same packing on torch tensors (any device): (B,3,m), (B,12), (B,) -> (B, m+13) float64"""
+    import torch
+
+    return torch.cat([tau.sum(dim=1), wrench, status.to(torch.float64)[:, None]], dim=1).contiguous()
+
+
 def gather_packed(packed, dist, world, sizes):
     """all_gather of per-rank packed rows (torch tensor, possibly ragged over ranks) -> (sum sizes, cols)."""
     import torch

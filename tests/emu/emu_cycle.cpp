@@ -81,7 +81,7 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
     return -1;
 }
 int emu_diag_count() { return DG_COUNT; }
-int emu_lds_bytes() { return Lds<39, 34>::total_bytes; }
+int emu_lds_bytes() { return Lds2<39, 34, 2>::total_bytes; }
 
 int emu_lds_bytes_reduced(int nlv) { return nlv == 1 ? LdsR<39, 34, 1>::total_bytes : nlv == 2 ? LdsR<39, 34, 2>::total_bytes : nlv == 3 ? LdsR<39, 34, 3>::total_bytes : LdsR<39, 34, 4>::total_bytes; }
 int emu_lds_bytes_v2(int nlv) { return nlv == 1 ? Lds2<39, 34, 1>::total_bytes : nlv == 2 ? Lds2<39, 34, 2>::total_bytes : nlv == 3 ? Lds2<39, 34, 3>::total_bytes : Lds2<39, 34, 4>::total_bytes; }
@@ -153,14 +153,11 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.body = rb.data();
     io.topo = c->topo.data();
     io.hqp = g_emu_hqp;
-    std::vector<real_t> lds(Lds<39, 34>::total + Lds2<39, 34, 4>::total + 64);
+    std::vector<real_t> lds(Lds2<39, 34, 4>::total + 64);
     std::vector<int> ilds(64);
-    const char *kv = getenv("DWBC_KERNEL");
-    const bool v1 = kv && std::string(kv) == "v1";
     for (int b = 0; b < B; b++) {
         Thr th{0};
-        if (v1) cycle_instance<39, 34, 1>(th, c->su, io, b, lds.data(), ilds.data());
-        else if (c->su.n_levels == 1) cycle_instance_v2<39, 34, 1, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
+        if (c->su.n_levels == 1) cycle_instance_v2<39, 34, 1, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
         else if (c->su.n_levels == 2 && g_emu_dense) cycle_instance_v2<39, 34, 2, 1, true, TopoGeneric>(th, c->su, io, b, lds.data(), ilds.data());
         else if (c->su.n_levels == 2) cycle_instance_v2<39, 34, 2, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
         else if (c->su.n_levels == 3) cycle_instance_v2<39, 34, 3, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());

@@ -92,3 +92,46 @@ def test_gpu_f32_kernel_within_envelope(cfg):
     assert np.abs(w32[ok] - wr[ok][:, :12]).max() < 1.0  # contact wrench (N, Nm), |f_z| ~ 500 N
     # the fp64 batch next to it is untouched by the fp32 build
     assert np.abs(out["f64"][0][st == 1] - tau[st == 1]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_f32_reduced_kernel_config5_within_envelope():
+    """BASELINE configs[4] as written -- fp32 arithmetic x reduced (centroidal) dynamics path -- at B = 8192 on the GPU (one
+    rank's share of a 65536 batch is 8192), against the fp64 numpy restatement of the reduced path on a seeded subset and
+    through size-independent properties on the full batch.  Same envelope as the emulation test above."""
+    import libdwbc_amd as D
+    from tests.test_reduced_path import oracle_batch
+
+    B, NS = 8192, 96
+    q, fl, fs = cases.synth_batch(B, seed=4245)
+    out = {}
+    for dt in ("f32", "f64"):
+        wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0, dtype=dt)
+        for c in cases.CONTACTS_2:
+            wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+        wbc.add_task(0, D.TASK_LINK_6D, 0)
+        wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+        wbc.set_state(q)
+        wbc.set_contact(fl)
+        wbc.set_fstar_all(fs)
+        wbc.solve(reduced=True)
+        out[dt] = (wbc.get("tau"), wbc.get("wrench"), wbc.get("status"))
+        name = wbc.kernel_name()
+        assert "dwbc_cycle_kernel_reduced" in name and name.startswith("dwbc_f32::" if dt == "f32" else "dwbc::")
+    t32, w32, s32 = out["f32"]
+    t64, w64, s64 = out["f64"]
+    # (1) seeded subset against the oracle (numpy restatement, seconds per 100 instances)
+    tau, wr, st = oracle_batch(q[:NS], fl[:NS], fs[:NS])
+    assert (s32[:NS] == st).mean() >= 0.9
+    ok = (st == 1) & (s32[:NS] == 1)
+    assert ok.mean() > 0.5
+    assert np.abs(t32[:NS][ok][:, :2] - tau[ok][:, :2]).max() < TOL_F32  # gravity and task torque
+    assert np.median(np.abs(t32[:NS][ok][:, 2] - tau[ok][:, 2]).max(axis=1)) < 1.0  # redistribution: H_temp^T H_temp is ill conditioned in fp32
+    # (2) full batch: fp32 against the fp64 kernel (itself checked against the oracle in tests/test_reduced_path.py)
+    assert (s32 == s64).mean() >= 0.9
+    both = (s32 == 1) & (s64 == 1)
+    assert both.mean() > 0.5
+    assert np.abs(t32[:, 0] - t64[:, 0]).max() < 0.05  # gravity torque: no QP involved
+    assert np.abs(t32[both][:, 1] - t64[both][:, 1]).max() < TOL_F32
+    assert np.isfinite(t32).all() and np.isfinite(w32).all()
+    assert (w32[s32 == 1][:, 2] < 0).all() and (w32[s32 == 1][:, 8] < 0).all()  # both feet loaded (f_z < 0 convention)

@@ -397,3 +397,84 @@ def test_gpu_generic_tree_instantiation_matches_tocabi_one(monkeypatch):
     assert ok.mean() > 0.5
     d = np.abs(w1.get("tau")[ok] - w2.get("tau")[ok]).max(axis=(1, 2))
     assert np.quantile(d, 0.99) < 1e-6
+
+
+def test_more_than_two_active_contacts_fail_loudly():
+    """The device path stacks at most two simultaneous 6D contacts (the reference: any number, src/dwbc.cpp:445-453).  An
+    instance with three flags is never solved with a subset: the host entry point refuses the flags, and flags that reach the
+    kernel through a bound device buffer give status 0 with zero torques and wrench for that instance only."""
+    import torch
+
+    import libdwbc_amd as D
+
+    B = 8
+    wbc = _make(B, contacts=cases.CONTACTS_4)
+    q, fl2, fs = cases.synth_batch(B, seed=31)
+    flags = np.zeros((B, 4), np.uint8)
+    flags[:, :2] = 1
+    bad = flags.copy()
+    bad[3] = [1, 1, 1, 0]
+    wbc.set_state(q)
+    wbc.set_fstar_all(fs)
+    with pytest.raises(D.batch.DwbcError, match="more than 2"):
+        wbc.set_contact(bad)
+    # device-resident flags cannot be inspected by the host: the kernel fails the instance
+    tf = torch.from_numpy(bad).cuda()
+    wbc.bind_tensor("in_contact", tf)
+    wbc.solve()
+    tau, wr, st = wbc.get("tau"), wbc.get("wrench"), wbc.get("status")
+    assert st[3] == 0 and np.abs(tau[3]).max() == 0.0 and np.abs(wr[3]).max() == 0.0
+    tau_o, wr_o, st_o, _ = _oracle(B, q, flags[:, :2].copy(), fs)
+    keep = np.arange(B) != 3
+    assert (st[keep] == st_o[keep]).all() and st[keep].all()
+    assert np.abs(tau[keep] - tau_o[keep]).max() < TOL
+
+
+def test_zmp_and_contact_frames_on_device():
+    """getZMP(getContactForce(tau_total)) and cc_[i].xc_pos / rotm / zmp_pos (reference src/dwbc.cpp:898-939,
+    src/contact_constraint.cpp:53-54) from the dump record of the HIP kernel, against the numpy restatement."""
+    from oracle.dwbc_np import Cycle
+
+    B = 6
+    q, fl, fs = cases.synth_batch(B, seed=61, yaw=True)
+    wbc = _make(B)
+    wbc.enable_dump(True)
+    tau, wr, st = _run(wbc, q, fl, fs)
+    z, cp, cr = wbc.get("zmp"), wbc.get("contact_pos"), wbc.get("contact_rot")
+    assert st.all()
+    for b in range(B):
+        c = Cycle(cases.tocabi_model())
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.add_task(0, 0, 0)
+        c.add_task(1, 6, 15)
+        c.set_torque_limit(cases.TAU_LIM)
+        t = c.run(q[b], [1, 1], [fs[b, :6], fs[b, 6:]])
+        zmp, zs = c.get_zmp(c.contact_force(t))
+        assert np.abs(z[b, 0] - zmp).max() < 1e-6 and np.abs(z[b, 1] - zs[0]).max() < 1e-6 and np.abs(z[b, 2] - zs[1]).max() < 1e-6
+        for a, link in enumerate((6, 12)):
+            assert np.abs(cp[b, a] - (c.p[link] + c.R[link] @ np.array(cases.FOOT_POINT))).max() < 1e-12
+            assert np.abs(cr[b, a] - c.R[link]).max() < 1e-12
+    # the ZMP lies inside the support polygon spanned by the two feet (a size-independent sanity property)
+    assert (np.abs(z[:, 0, :2] - 0.5 * (cp[:, 0, :2] + cp[:, 1, :2])) < 0.5).all()
+
+
+def test_gpu_bench_two_ranks_gloo():
+    """`python bench.py --gpus 2` on a one-GPU box with the gloo rehearsal switch: the launcher starts two ranks that share the
+    card, each runs bench.rank_main with the HIP engine, rank 0 prints one line with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DWBC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["collective_backend"] == "gloo" and line["config"]["status_ok_fraction"] > 0.9
+    assert line["value"] > 1e4 and line["roofline"]["kernel"].startswith("dwbc::dwbc_cycle_kernel_v2")
