@@ -26,8 +26,11 @@ template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
+#ifndef DWBC_WIDE_ATTR
+#define DWBC_WIDE_ATTR
+#endif
 template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
-__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
+__global__ __launch_bounds__(NT) DWBC_WIDE_ATTR void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
     DWBC_V2_BODY
 }
 
