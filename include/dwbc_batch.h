@@ -170,6 +170,45 @@ int dwbc_batch_launch_info(const dwbc_batch *b, int *threads_per_instance, int *
 /* name of the kernel the next dwbc_batch_solve will launch (as rocprofv3 prints it), for bench / profile bookkeeping */
 const char *dwbc_batch_kernel_name(const dwbc_batch *b);
 
+/* ---- generic hierarchical-QP class for a batch: DWBC::HQP / HQP_Hierarch (reference include/dwbc_hqp.h:8-141,
+ * src/dwbc_hqp.cpp).  Every level i poses  A_i y + a_i <= v (inequalities with slack), B_i y + b_i = w (equalities, least
+ * squares), optional cost 1/2 y^T H y; levels are solved in sequence inside the null space of the earlier equalities.  The
+ * reference solves each level with OSQP (not vendored); here each level is solved exactly on the device (DESIGN.md "HQP
+ * class").  All matrices are per instance, batch-major, row-major: A is B x ineq x nv, nv = acceleration + torque + contact. */
+typedef struct dwbc_hqp dwbc_hqp;
+enum dwbc_hqp_field {
+    DWBC_HQP_Y_ANS = 0,   /* (nv)   f64  hqp_hs_[level].y_ans_ */
+    DWBC_HQP_V_ANS = 1,   /* (ineq) f64  hqp_hs_[level].v_ans_ */
+    DWBC_HQP_W_ANS = 2,   /* (eq)   f64  hqp_hs_[level].w_ans_ = B y + b */
+    DWBC_HQP_STATUS = 3,  /* (1)    i32  1 solved / 0 failed (iteration limit, working set overflow, singular Hessian) */
+    DWBC_HQP_ITER = 4,    /* (1)    i32  active-set steps of the level */
+    DWBC_HQP_NULL_SIZE = 5, /* (1)  i32  hqp_hs_[level].null_space_size_ */
+    DWBC_HQP_A = 6, DWBC_HQP_a = 7, DWBC_HQP_B = 8, DWBC_HQP_b = 9  /* the (normalised) level matrices as stored */
+};
+dwbc_hqp *dwbc_hqp_create(int B, int device, int acceleration_size, int torque_size, int contact_size); /* HQP::initialize :16-21 */
+void dwbc_hqp_destroy(dwbc_hqp *h);
+int dwbc_hqp_add_hierarchy(dwbc_hqp *h, int ineq_const_size, int eq_const_size);   /* HQP::addHierarchy :425-434; returns the level */
+int dwbc_hqp_clear(dwbc_hqp *h);                                                    /* drop every level */
+/* HQP_Hierarch::updateConstraintMatrix :530-547 (A, a may be NULL for a level without inequalities) */
+int dwbc_hqp_update_constraint_matrix(dwbc_hqp *h, int level, const double *A, const double *a, const double *Bm, const double *b);
+int dwbc_hqp_update_cost_matrix(dwbc_hqp *h, int level, const double *H, const double *g);  /* updateCostMatrix :483-493 (g is stored, never read: as in the reference) */
+int dwbc_hqp_normalize_constraint_matrix(dwbc_hqp *h, int level);                   /* normalizeConstraintMatrix :555-581 */
+/* seed hqp_hs_[level].y_ans_ / v_ans_ directly, as ConfigureLQP does for level 0 (src/dwbc.cpp:4378-4381) */
+int dwbc_hqp_set_answer(dwbc_hqp *h, int level, const double *y_ans, const double *v_ans);
+int dwbc_hqp_prepare(dwbc_hqp *h);                    /* HQP::prepare :23-85 (the null-space chain itself is evaluated with the solve) */
+int dwbc_hqp_solve_first(dwbc_hqp *h, int init);      /* HQP::solvefirst :222-289 */
+int dwbc_hqp_solve_sequential(dwbc_hqp *h, int init); /* HQP::solveSequential :397-403; init is accepted and unused (exact solves have no warm state) */
+int dwbc_hqp_num_levels(const dwbc_hqp *h);
+size_t dwbc_hqp_field_bytes(const dwbc_hqp *h, int level, int field);
+int dwbc_hqp_get(dwbc_hqp *h, int level, int field, void *host_out, size_t bytes);
+/* RobotData::ConfigureLQP(hqp) src/dwbc.cpp:4304-4430 on the device, from the batch's last solve (needs dwbc_batch_enable_dump and
+ * the same contact flags in every instance): (re)builds the levels of `h` -- torque limit / floating-base dynamics,
+ * contact cones + acceleration limit / contact constraint, one equality level per task space -- and seeds level 0.
+ * RobotData::CalcControlTorqueLQP(hqp) src/dwbc.cpp:4432-4452 is dwbc_hqp_solve_sequential(h, init). */
+int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h);
+/* torque of the LQP answer, tau = A[6:] qddot + J_C^T[6:] f_c + B_[6:] (tests/sp_test/jacc_compare.cpp:416-418): B x m */
+int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,5 +10,6 @@ from .batch import (  # noqa: F401
 )
 
 from .rl_bridge import RlWBCBridge  # noqa: F401,E402
+from .hqp import HQP  # noqa: F401,E402
 
-__all__ = ["Batch", "Model", "DwbcError", "RlWBCBridge"]
+__all__ = ["Batch", "Model", "DwbcError", "RlWBCBridge", "HQP"]

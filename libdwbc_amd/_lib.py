@@ -53,6 +53,23 @@ SYMBOLS = [
     ("dwbc_batch_field_bytes", C.c_size_t, [_vp, _i]),
     ("dwbc_batch_launch_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     ("dwbc_batch_kernel_name", C.c_char_p, [_vp]),
+    # generic hierarchical-QP class + LQP configurator
+    ("dwbc_hqp_create", _vp, [_i, _i, _i, _i, _i]),
+    ("dwbc_hqp_destroy", None, [_vp]),
+    ("dwbc_hqp_add_hierarchy", _i, [_vp, _i, _i]),
+    ("dwbc_hqp_clear", _i, [_vp]),
+    ("dwbc_hqp_update_constraint_matrix", _i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    ("dwbc_hqp_update_cost_matrix", _i, [_vp, _i, _vp, _vp]),
+    ("dwbc_hqp_normalize_constraint_matrix", _i, [_vp, _i]),
+    ("dwbc_hqp_set_answer", _i, [_vp, _i, _vp, _vp]),
+    ("dwbc_hqp_prepare", _i, [_vp]),
+    ("dwbc_hqp_solve_first", _i, [_vp, _i]),
+    ("dwbc_hqp_solve_sequential", _i, [_vp, _i]),
+    ("dwbc_hqp_num_levels", _i, [_vp]),
+    ("dwbc_hqp_field_bytes", C.c_size_t, [_vp, _i, _i]),
+    ("dwbc_hqp_get", _i, [_vp, _i, _i, _vp, C.c_size_t]),
+    ("dwbc_batch_configure_lqp", _i, [_vp, _vp]),
+    ("dwbc_batch_lqp_torque", _i, [_vp, _vp, _vp]),
 ]
 
 _lib = None

@@ -1,0 +1,67 @@
+// dwbc_capi_internal.h -- the opaque handles of include/dwbc_batch.h as the translation units of libdwbc_hip.so see them
+// (dwbc_capi.hip: cycle kernels + batch API; dwbc_hqp_capi.hip: hierarchical-QP class + LQP configurator).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dwbc_batch.h"
+#include "dwbc_model.h"
+#include "dwbc_types.h"
+
+namespace dwbc {
+struct KernelEntry;
+std::string &capi_err();  // thread-local last error (dwbc_last_error)
+inline int capi_fail(const std::string &s) {
+    capi_err() = s;
+    return 0;
+}
+}  // namespace dwbc
+#define HIP_OK(expr)                                                                                           \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return dwbc::capi_fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+struct dwbc_model {
+    dwbc::Model m;
+};
+
+struct dwbc_batch {
+    const dwbc_model *model = nullptr;
+    int B = 0, device = 0, n = 0, m = 0;
+    dwbc::Setup su{};
+    const dwbc::KernelEntry *kern = nullptr;
+    hipStream_t stream = nullptr;
+    // device buffers (owned unless bound)
+    double *d_qdot = nullptr;  // B x n, allocated when the caller passes a qdot
+    double *d_traj = nullptr, *d_ctime = nullptr;  // on-device task reference inputs (dwbc_fstar.h)
+    double *d_custom = nullptr;  // B x n_custom x 6 x n: J_task of the TASK_CUSTOM levels
+    std::vector<double> h_custom;
+    bool dirty_custom = false;
+    std::vector<double> h_traj, h_ctime;
+    bool dirty_traj = false, dirty_ctime = false;
+    std::vector<double> h_qdot;
+    bool dirty_qdot = false;
+    double *d_q = nullptr, *d_fstar = nullptr, *d_tau = nullptr, *d_wrench = nullptr, *d_dump = nullptr, *d_body = nullptr;
+    unsigned char *d_flags = nullptr;
+    int *d_status = nullptr, *d_diag = nullptr, *d_topo = nullptr;
+    bool own_q = false, own_fstar = false, own_flags = false, own_tau = false, own_wrench = false, own_status = false;
+    int fstar_alloc = 0, flags_alloc = 0;
+    bool dump_on = false;
+    int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
+    float *f_body = nullptr;
+    const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
+    int f32_lds = 0, f32_key = -1, f32_topo = 0;
+    int hqp = 1;
+    bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
+    // host mirrors of the inputs
+    std::vector<double> h_q, h_fstar;
+    std::vector<unsigned char> h_flags;
+    bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
+    bool attr_set = false;
+    int n_cu = 0;
+    dwbc::DumpLayout dl{};
+};
+

@@ -1,0 +1,613 @@
+// dwbc_hqp.h -- the reference's generic hierarchical-QP class (HQP / HQP_Hierarch, include/dwbc_hqp.h, src/dwbc_hqp.cpp) for a
+// batch of instances, and the LQP configurator that fills it from a solved control cycle (RobotData::ConfigureLQP,
+// src/dwbc.cpp:4304-4430).  SURVEY 8 rows a16 / f3.  One workgroup (one wavefront) per instance.
+//
+//   level i:   min_{u, v}  1/2 |B_i Z u + (B_i y_prev + b_i)|^2  [+ 1/2 u^T Z^T H Z u + (Z^T H y_prev)^T u]  + 1/2 |v|^2
+//              s.t.        A_i Z u - v <= -(A_i y_prev) - a_i                      own inequalities, slack v   (dwbc_hqp.cpp:320-336)
+//                          A_j Z u     <= -(A_j y_prev) + v_ans_j - a_j   (j < i)  earlier levels, slack frozen (dwbc_hqp.cpp:366-384)
+//              y_i = y_prev + Z u,  Z = Z_{i-1},  Z_i = Z_{i-1} null(B_i Z_{i-1})    (dwbc_hqp.cpp:23-85, 388; math.cpp:349-360)
+//
+// The reference hands each level to OSQP (OsqpEigen, not vendored; ADMM at default tolerances on sparseView(1e-5) copies,
+// dwbc_hqp.cpp:583-631).  Here every level is solved EXACTLY by a dual active-set method in range-space form on the augmented
+// variable (u, v): the working set holds own rows whose slack is positive and earlier rows at their bound; with T_a = H^-1 c_a
+// kept per working-set row, M = C_W H^-1 C_W^T (+1 on the diagonal of own rows) is q x q and is refactorised every step.
+// The Hessian in u is only positive semi-definite in general (the LQP's internal-wrench directions carry no cost); canon, as
+// in oracle/hqp_np.py: Tikhonov term eps |u|^2 / 2.  PARITY UNPINNED in the reference (no fixture, no assertion).
+//
+// Storage: the level matrices, answers and the scratch (Z, H Z, C Z) live in HBM -- this is not the headline path; LDS holds
+// the solver state (H^-1, T, M, the vectors).  Code is NT-generic (strided loops + DWBC_SYNC) so that tests/emu runs it with
+// one host thread.
+#pragma once
+#include "dwbc_cycle.h"
+
+// this path keeps matrices in HBM that lanes of the wave hand to each other: a full workgroup barrier (waits for outstanding
+// vector-memory and LDS operations), not the wavefront-scope compiler fence of the cycle kernel
+#ifdef DWBC_HOST_EMU
+#define HQP_SYNC() ((void)0)
+#else
+#define HQP_SYNC() __syncthreads()
+#endif
+
+namespace dwbc {
+
+constexpr int kHqpMaxLevels = 8;
+constexpr int kHqpMaxQ = 32;   // working-set capacity of one level's QP
+constexpr int kHqpMaxEq = 16;  // equality rows of one level
+constexpr int kHqpMaxVar = 64; // y size (acceleration + torque + contact)
+
+struct HqpDesc {
+    int nv, n_levels, solve_first, max_iter;
+    double eps, tol;
+    int m[kHqpMaxLevels], e[kHqpMaxLevels], has_cost[kHqpMaxLevels];
+    // offsets (doubles) inside one instance's record
+    int oA[kHqpMaxLevels], oa[kHqpMaxLevels], oB[kHqpMaxLevels], ob[kHqpMaxLevels], oH[kHqpMaxLevels];
+    int oy[kHqpMaxLevels], ov[kHqpMaxLevels], ow[kHqpMaxLevels];
+    int rec;       // doubles per instance record
+    int max_rows;  // most inequality rows (own + earlier) any level sees
+    int scratch;   // doubles per instance of HBM scratch: Z (nv x nv) | HZ (nv x nv) | CZ (max_rows x nv)
+    int lds;       // doubles of LDS
+};
+enum HqpStat { HQS_STATUS = 0, HQS_ITER = kHqpMaxLevels, HQS_NULL = 2 * kHqpMaxLevels, HQS_COUNT = 3 * kHqpMaxLevels };
+struct HqpIO {
+    int B;
+    double *rec;
+    double *scratch;
+    int *stat;  // B x HQS_COUNT
+};
+
+// LDS map of the solver (doubles)
+struct HqpLds {
+    int Hinv, T, Mm, Lc, Bz, u, g, zu, tp, yp, cp, hy, rr, r, lam, rhs, vv, dd, sl, inw, wl, total;
+    __host__ __device__ static HqpLds make(int nv, int max_rows) {
+        HqpLds l;
+        int o = 0;
+        auto ev = [](int a) { return (a + 1) & ~1; };
+        l.Hinv = o; o += ev(nv * nv);
+        l.T = o; o += ev(kHqpMaxQ * nv);
+        l.Mm = o; o += kHqpMaxQ * kHqpMaxQ;
+        l.Lc = o; o += kHqpMaxQ * kHqpMaxQ;
+        l.Bz = o; o += ev(kHqpMaxEq * nv);
+        l.u = o; o += ev(nv);
+        l.g = o; o += ev(nv);
+        l.zu = o; o += ev(nv);
+        l.tp = o; o += ev(nv);
+        l.yp = o; o += ev(nv);
+        l.cp = o; o += ev(nv);
+        l.hy = o; o += ev(nv);
+        l.rr = o; o += kHqpMaxEq;
+        l.r = o; o += kHqpMaxQ;
+        l.lam = o; o += kHqpMaxQ;
+        l.rhs = o; o += kHqpMaxQ;
+        l.vv = o; o += ev(max_rows);
+        l.dd = o; o += ev(max_rows);
+        l.sl = o; o += ev(max_rows);
+        l.inw = o; o += ev(max_rows);
+        l.wl = o; o += kHqpMaxQ;
+        l.total = o + 8;
+        return l;
+    }
+};
+
+// record layout from the level sizes (host).  share_cost: every level with a cost reads ONE H block (the LQP gives all its
+// levels the same cost matrix, dwbc.cpp:4338-4342,4408,4424)
+inline void hqp_layout(HqpDesc &d, bool share_cost) {
+    int o = 0, shared = -1, rows = 0, max_rows = 0;
+    const int nv = d.nv;
+    for (int i = 0; i < d.n_levels; i++) {
+        d.oA[i] = o; o += d.m[i] * nv;
+        d.oa[i] = o; o += d.m[i];
+        d.oB[i] = o; o += d.e[i] * nv;
+        d.ob[i] = o; o += d.e[i];
+        if (d.has_cost[i]) {
+            if (share_cost && shared >= 0) d.oH[i] = shared;
+            else { d.oH[i] = o; shared = o; o += nv * nv; }
+        } else d.oH[i] = -1;
+        d.oy[i] = o; o += nv;
+        d.ov[i] = o; o += d.m[i];
+        d.ow[i] = o; o += d.e[i];
+        rows += d.m[i];
+        max_rows = rows > max_rows ? rows : max_rows;
+    }
+    d.rec = (o + 1) & ~1;
+    d.max_rows = max_rows > 0 ? max_rows : 1;
+    d.scratch = 2 * nv * nv + d.max_rows * nv;
+    d.lds = HqpLds::make(nv, d.max_rows).total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Z_view <- Z_view * Q, Q from the column-pivoted Householder QR of (Bm Z_view)^T; the view drops its first `rank` columns
+// (getNullSpace, src/math.cpp:349-360: Eigen COD with its default threshold [ext]; restated as oracle/hqp_np.py::get_null_space)
+// Z: nv x nv row-major (HBM), view = columns [off, nv).  Bm: e x nv.  Returns the rank.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT>
+DWBC_DEV int hqp_null_update(Thr th, double *Z, int nv, int off, const double *Bm, int e, double *Bz, double *vh) {
+    const int k = nv - off;
+    if (e == 0 || k == 0) return 0;
+    HQP_SYNC();
+    for (int idx = th.tid; idx < e * k; idx += NT) {
+        const int i = idx / k, j = idx - i * k;
+        double acc = 0.0;
+        for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * Z[c * nv + off + j];
+        Bz[i * k + j] = acc;
+    }
+    HQP_SYNC();
+    const int steps = e < k ? e : k;
+    double maxp = 0.0;
+    int rank = 0;
+    const double thr = 2.220446049250313e-16 * steps;
+    for (int s = 0; s < steps; s++) {
+        // pivot: the remaining row of Bz (= column of (B Z)^T) with the largest norm over entries [s, k)
+        int jp = s;
+        double best = -1.0;
+        for (int i = s; i < e; i++) {
+            double n2 = 0.0;
+            for (int c = s; c < k; c++) n2 += Bz[i * k + c] * Bz[i * k + c];
+            if (n2 > best) { best = n2; jp = i; }
+        }
+        HQP_SYNC();
+        if (jp != s)
+            for (int c = th.tid; c < k; c += NT) { const double t = Bz[s * k + c]; Bz[s * k + c] = Bz[jp * k + c]; Bz[jp * k + c] = t; }
+        HQP_SYNC();
+        const double nx = sqrt(best > 0.0 ? best : 0.0);
+        if (nx == 0.0) break;
+        const double x0 = Bz[s * k + s];
+        const double alpha = x0 > 0.0 ? -nx : nx;
+        double vn2 = 0.0;
+        for (int c = s; c < k; c++) {
+            const double vc = Bz[s * k + c] - (c == s ? alpha : 0.0);
+            vn2 += vc * vc;
+        }
+        HQP_SYNC();
+        for (int c = th.tid; c < k; c += NT) vh[c] = c < s ? 0.0 : Bz[s * k + c] - (c == s ? alpha : 0.0);
+        HQP_SYNC();
+        if (vn2 > 0.0) {
+            const double beta = 2.0 / vn2;
+            for (int i = s + 1 + th.tid; i < e; i += NT) {  // remaining rows of Bz
+                double dd = 0.0;
+                for (int c = s; c < k; c++) dd += Bz[i * k + c] * vh[c];
+                dd *= beta;
+                for (int c = s; c < k; c++) Bz[i * k + c] -= dd * vh[c];
+            }
+            for (int i = th.tid; i < nv; i += NT) {  // rows of the view of Z
+                double dd = 0.0;
+                for (int c = s; c < k; c++) dd += Z[i * nv + off + c] * vh[c];
+                dd *= beta;
+                for (int c = s; c < k; c++) Z[i * nv + off + c] -= dd * vh[c];
+            }
+        }
+        const double ap = fabs(alpha);
+        if (s == 0) maxp = ap;
+        // pivots come out in non-increasing magnitude: the first one below the threshold ends the rank
+        if (ap > thr * maxp) rank++;
+        else break;
+        HQP_SYNC();
+    }
+    HQP_SYNC();
+    return rank;
+}
+
+// in-place inverse of the SPD k x k matrix S (LDS, row stride k) by Gauss-Jordan without pivoting; col / row: k doubles of
+// scratch each.  Returns 0 on a non-positive pivot.
+template <int NT>
+DWBC_DEV int hqp_spd_inverse(Thr th, double *S, int k, double *col, double *row) {
+    int ok = 1;
+    for (int p = 0; p < k; p++) {
+        HQP_SYNC();
+        double d = S[p * k + p];
+        if (!(d > 0.0)) { ok = 0; d = 1.0; }
+        const double rp = 1.0 / d;
+        for (int i = th.tid; i < k; i += NT) { col[i] = S[i * k + p]; row[i] = S[p * k + i]; }
+        HQP_SYNC();
+        for (int idx = th.tid; idx < k * k; idx += NT) {
+            const int i = idx / k, j = idx - i * k;
+            double v;
+            if (i == p && j == p) v = rp;
+            else if (i == p) v = row[j] * rp;
+            else if (j == p) v = -col[i] * rp;
+            else v = S[idx] - col[i] * row[j] * rp;
+            S[idx] = v;
+        }
+    }
+    HQP_SYNC();
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one instance: the cascade over the levels
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT>
+DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, double *L) {
+    const int nv = d.nv;
+    const HqpLds l = HqpLds::make(nv, d.max_rows);
+    double *rec = io.rec + (size_t)inst * d.rec;
+    double *Z = io.scratch + (size_t)inst * d.scratch, *HZ = Z + nv * nv, *CZ = HZ + nv * nv;
+    int *stat = io.stat + (size_t)inst * HQS_COUNT;
+    for (int idx = th.tid; idx < nv * nv; idx += NT) Z[idx] = (idx / nv == idx % nv) ? 1.0 : 0.0;
+    for (int i = th.tid; i < HQS_COUNT; i += NT) stat[i] = i < kHqpMaxLevels ? 1 : 0;
+    HQP_SYNC();
+    int off = 0;
+    for (int lv = 0; lv < d.n_levels; lv++) {
+        const int k = nv - off;
+        const bool solve = lv > 0 || d.solve_first;
+        const double *Bm = rec + d.oB[lv], *bv = rec + d.ob[lv];
+        const int e = d.e[lv], mo = d.m[lv];
+        if (solve) {
+            double *Hinv = L + l.Hinv, *T = L + l.T, *Mm = L + l.Mm, *Lc = L + l.Lc, *Bz = L + l.Bz;
+            double *u = L + l.u, *g = L + l.g, *zu = L + l.zu, *tp = L + l.tp, *yp = L + l.yp, *cp = L + l.cp, *hy = L + l.hy;
+            double *rr = L + l.rr, *r = L + l.r, *lam = L + l.lam, *rhs = L + l.rhs, *vv = L + l.vv, *dd = L + l.dd, *sl = L + l.sl;
+            double *inw = L + l.inw, *wl = L + l.wl;
+            int status = 1, iters = 0;
+            HQP_SYNC();
+            for (int i = th.tid; i < nv; i += NT) yp[i] = lv > 0 ? rec[d.oy[lv - 1] + i] : 0.0;
+            HQP_SYNC();
+            // ---- Bz = B Z, rr = B y_prev + b
+            for (int idx = th.tid; idx < e * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                double acc = 0.0;
+                for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * Z[c * nv + off + j];
+                Bz[i * k + j] = acc;
+            }
+            for (int i = th.tid; i < e; i += NT) {
+                double acc = bv[i];
+                for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * yp[c];
+                rr[i] = acc;
+            }
+            HQP_SYNC();
+            // ---- H = Bz^T Bz + eps I (+ Z^T Hc Z), g = Bz^T rr (+ Z^T Hc y_prev)
+            const double *Hc = d.has_cost[lv] ? rec + d.oH[lv] : nullptr;
+            if (Hc) {
+                for (int idx = th.tid; idx < nv * k; idx += NT) {
+                    const int i = idx / k, j = idx - i * k;
+                    double acc = 0.0;
+                    for (int c = 0; c < nv; c++) acc += Hc[i * nv + c] * Z[c * nv + off + j];
+                    HZ[i * nv + j] = acc;
+                }
+                for (int i = th.tid; i < nv; i += NT) {
+                    double acc = 0.0;
+                    for (int c = 0; c < nv; c++) acc += Hc[i * nv + c] * yp[c];
+                    hy[i] = acc;
+                }
+            }
+            HQP_SYNC();
+            for (int idx = th.tid; idx < k * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k;
+                double acc = (i == j) ? d.eps : 0.0;
+                for (int c = 0; c < e; c++) acc += Bz[c * k + i] * Bz[c * k + j];
+                if (Hc)
+                    for (int c = 0; c < nv; c++) acc += Z[c * nv + off + i] * HZ[c * nv + j];
+                Hinv[idx] = acc;
+            }
+            for (int i = th.tid; i < k; i += NT) {
+                double acc = 0.0;
+                for (int c = 0; c < e; c++) acc += Bz[c * k + i] * rr[c];
+                if (Hc)
+                    for (int c = 0; c < nv; c++) acc += Z[c * nv + off + i] * hy[c];
+                g[i] = acc;
+            }
+            HQP_SYNC();
+            if (!hqp_spd_inverse<NT>(th, Hinv, k, zu, tp)) status = 0;
+            // ---- rows: own (soft) first, then the earlier levels' (hard, slack frozen)
+            int nrows = 0;
+            for (int jj = 0; jj <= lv; jj++) {
+                const int j = jj == 0 ? lv : jj - 1;  // order: lv, 0, 1, .., lv - 1
+                const int mj = d.m[j];
+                if (mj == 0) continue;
+                const double *Aj = rec + d.oA[j], *aj = rec + d.oa[j], *vj = rec + d.ov[j];
+                for (int idx = th.tid; idx < mj * k; idx += NT) {
+                    const int i = idx / k, c2 = idx - i * k;
+                    double acc = 0.0;
+                    for (int c = 0; c < nv; c++) acc += Aj[i * nv + c] * Z[c * nv + off + c2];
+                    CZ[(nrows + i) * nv + c2] = acc;
+                }
+                for (int i = th.tid; i < mj; i += NT) {
+                    double acc = -aj[i];
+                    for (int c = 0; c < nv; c++) acc -= Aj[i * nv + c] * yp[c];
+                    if (j != lv) acc += vj[i];
+                    dd[nrows + i] = acc;
+                    vv[nrows + i] = 0.0;
+                    inw[nrows + i] = 0.0;
+                }
+                nrows += mj;
+            }
+            HQP_SYNC();
+            // ---- u = -H^-1 g
+            for (int i = th.tid; i < k; i += NT) {
+                double acc = 0.0;
+                for (int c = 0; c < k; c++) acc -= Hinv[i * k + c] * g[c];
+                u[i] = acc;
+            }
+            HQP_SYNC();
+            int nw = 0;
+            while (status) {
+                // most violated row outside the working set
+                for (int row = th.tid; row < nrows; row += NT) {
+                    double s = dd[row];
+                    for (int c = 0; c < k; c++) s -= CZ[row * nv + c] * u[c];
+                    if (row < mo) s += vv[row];
+                    sl[row] = inw[row] != 0.0 ? 1.0e300 : s;
+                }
+                HQP_SYNC();
+                int p = -1;
+                double worst = 1.0e300;
+                for (int row = 0; row < nrows; row++)
+                    if (sl[row] < worst) { worst = sl[row]; p = row; }
+                if (p < 0 || !(worst < -d.tol)) break;
+                const bool psoft = p < mo;
+                double lam_p = 0.0;
+                HQP_SYNC();
+                for (int c = th.tid; c < k; c += NT) cp[c] = CZ[p * nv + c];
+                HQP_SYNC();
+                for (int i = th.tid; i < k; i += NT) {
+                    double acc = 0.0;
+                    for (int c = 0; c < k; c++) acc += Hinv[i * k + c] * cp[c];
+                    tp[i] = acc;
+                }
+                HQP_SYNC();
+                for (;;) {  // steps on row p until it enters the working set
+                    if (++iters > d.max_iter) { status = 0; break; }
+                    for (int a = th.tid; a < nw; a += NT) {
+                        double acc = 0.0;
+                        for (int c = 0; c < k; c++) acc += T[a * nv + c] * cp[c];
+                        rhs[a] = acc;
+                    }
+                    HQP_SYNC();
+                    if (nw > 0 && th.tid == 0) {  // r = M^-1 rhs by a fresh Cholesky factor (q <= 32: serial, in LDS)
+                        for (int i = 0; i < nw; i++)
+                            for (int j = 0; j <= i; j++) {
+                                double s = Mm[i * kHqpMaxQ + j];
+                                for (int c = 0; c < j; c++) s -= Lc[i * kHqpMaxQ + c] * Lc[j * kHqpMaxQ + c];
+                                Lc[i * kHqpMaxQ + j] = (i == j) ? sqrt(s > 1e-300 ? s : 1e-300) : s / Lc[j * kHqpMaxQ + j];
+                            }
+                        for (int i = 0; i < nw; i++) {
+                            double s = rhs[i];
+                            for (int c = 0; c < i; c++) s -= Lc[i * kHqpMaxQ + c] * r[c];
+                            r[i] = s / Lc[i * kHqpMaxQ + i];
+                        }
+                        for (int i = nw - 1; i >= 0; i--) {
+                            double s = r[i];
+                            for (int c = i + 1; c < nw; c++) s -= Lc[c * kHqpMaxQ + i] * r[c];
+                            r[i] = s / Lc[i * kHqpMaxQ + i];
+                        }
+                    }
+                    HQP_SYNC();
+                    for (int i = th.tid; i < k; i += NT) {
+                        double acc = tp[i];
+                        for (int a = 0; a < nw; a++) acc -= r[a] * T[a * nv + i];
+                        zu[i] = acc;
+                    }
+                    HQP_SYNC();
+                    double nz = psoft ? 1.0 : 0.0, sp = dd[p] + (psoft ? vv[p] : 0.0), full = psoft ? 1.0 : 0.0;
+                    for (int c = 0; c < k; c++) { nz += cp[c] * zu[c]; sp -= cp[c] * u[c]; full += cp[c] * tp[c]; }
+                    // independent of the working set only if a fraction > 1e-9 of its H^-1-norm survives the projection
+                    const double t2 = nz > 1.0e-9 * full ? -sp / nz : 1.0e300;
+                    double t1 = 1.0e300;
+                    int drop = -1;
+                    for (int a = 0; a < nw; a++)
+                        if (r[a] > 1e-14) {
+                            const double ta = lam[a] / r[a];
+                            if (ta < t1) { t1 = ta; drop = a; }
+                        }
+                    const double t = t1 < t2 ? t1 : t2;
+#ifdef DWBC_HQP_TRACE
+                    printf("lv %d it %d p %d soft %d nw %d nz %.3e full %.3e sp %.3e t1 %.3e t2 %.3e drop %d\n", lv, iters, p, (int)psoft, nw, nz, full, sp, t1, t2, drop);
+#endif
+                    if (!(t < 1.0e299)) {
+                        // no step exists: the row depends on the working set and nothing can be traded against it.  Round-off
+                        // on a redundant row (|slack| < 1e-6) is not a violation: the row is set aside; otherwise the level fails
+                        if (-sp < 10.0 * d.tol) {  // HQP_TOL_DEP
+                            HQP_SYNC();
+                            if (th.tid == 0) inw[p] = 2.0;
+                            HQP_SYNC();
+                        } else status = 0;
+                        break;
+                    }
+                    HQP_SYNC();
+                    for (int i = th.tid; i < k; i += NT) u[i] -= t * zu[i];
+                    if (th.tid == 0) {
+                        if (psoft) vv[p] += t;
+                        for (int a = 0; a < nw; a++) {
+                            const int ja = (int)wl[a];
+                            if (ja < mo) vv[ja] -= t * r[a];
+                            lam[a] -= t * r[a];
+                        }
+                    }
+                    lam_p += t;
+                    HQP_SYNC();
+                    if (t2 <= t1) {  // full step: row p enters
+                        if (nw >= kHqpMaxQ) { status = 0; break; }
+                        for (int c = th.tid; c < k; c += NT) T[nw * nv + c] = tp[c];
+                        double mpp = psoft ? 1.0 : 0.0;
+                        for (int c = 0; c < k; c++) mpp += cp[c] * tp[c];
+                        if (th.tid == 0) {
+                            for (int a = 0; a < nw; a++) { Mm[a * kHqpMaxQ + nw] = rhs[a]; Mm[nw * kHqpMaxQ + a] = rhs[a]; }
+                            Mm[nw * kHqpMaxQ + nw] = mpp;
+                            wl[nw] = (double)p;
+                            lam[nw] = lam_p;
+                            inw[p] = 1.0;
+                        }
+                        nw++;
+                        HQP_SYNC();
+                        break;
+                    }
+                    // partial step: the blocking row leaves the working set, row p is tried again
+                    HQP_SYNC();
+                    if (th.tid == 0) {
+                        inw[(int)wl[drop]] = 0.0;
+                        for (int a = drop; a + 1 < nw; a++) {
+                            wl[a] = wl[a + 1];
+                            lam[a] = lam[a + 1];
+                        }
+                        for (int a = 0; a < nw; a++)
+                            for (int b2 = drop; b2 + 1 < nw; b2++) Mm[a * kHqpMaxQ + b2] = Mm[a * kHqpMaxQ + b2 + 1];
+                        for (int a = drop; a + 1 < nw; a++)
+                            for (int b2 = 0; b2 < nw; b2++) Mm[a * kHqpMaxQ + b2] = Mm[(a + 1) * kHqpMaxQ + b2];
+                    }
+                    HQP_SYNC();
+                    for (int a = drop; a + 1 < nw; a++) {
+                        for (int c = th.tid; c < k; c += NT) T[a * nv + c] = T[(a + 1) * nv + c];
+                        HQP_SYNC();
+                    }
+                    nw--;
+                    HQP_SYNC();
+                }
+            }
+            HQP_SYNC();
+            // ---- answers: y = y_prev + Z u, v_ans, w_ans = B y + b  (dwbc_hqp.cpp:388-394)
+            for (int i = th.tid; i < nv; i += NT) {
+                double acc = yp[i];
+                if (status)
+                    for (int c = 0; c < k; c++) acc += Z[i * nv + off + c] * u[c];
+                rec[d.oy[lv] + i] = acc;
+                hy[i] = acc;
+            }
+            for (int i = th.tid; i < mo; i += NT) rec[d.ov[lv] + i] = status ? vv[i] : 0.0;
+            HQP_SYNC();
+            for (int i = th.tid; i < e; i += NT) {
+                double acc = bv[i];
+                for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * hy[c];
+                rec[d.ow[lv] + i] = acc;
+            }
+            if (th.tid == 0) { stat[HQS_STATUS + lv] = status; stat[HQS_ITER + lv] = iters; }
+            HQP_SYNC();
+        }
+        // ---- null-space chain: Z_lv = Z_{lv-1} null(B_lv Z_{lv-1})
+        off += hqp_null_update<NT>(th, Z, nv, off, Bm, e, L + l.Bz, L + l.zu);
+        if (th.tid == 0) stat[HQS_NULL + lv] = nv - off;
+        HQP_SYNC();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RobotData::ConfigureLQP (src/dwbc.cpp:4304-4430) from the dump record of a solved cycle: y = [qddot (n); f_c (cd)],
+//   level 0: torque limit (tlim = 200, hard-coded in the reference) / floating-base dynamics, "solved" as y = [-A^-1 B_; 0]
+//   level 1: contact cones + joint acceleration limit (alim = 5) / J_C qddot = 0, cost 5 A / |A|_F on qddot
+//   level 2 + i: J_task_i qddot = f*_i, same cost
+// Rows are normalised (normalizeConstraintMatrix, dwbc_hqp.cpp:555-581).  Bn: RobotData::B_ of the instance.
+// ------------------------------------------------------------------------------------------------------------------
+struct LqpCfg {
+    int n, cd, nc, n_tasks;   // system dof, contact dof of the (uniform) contact state, active contacts, task levels
+    int t_dof[kMaxLevels];
+    int act[kMaxActiveContacts];
+    double lx[kMaxActiveContacts], ly[kMaxActiveContacts], mu[kMaxActiveContacts], muz[kMaxActiveContacts];
+    int oBn;  // offset of B_ inside the dump record (DumpLayout::B, or ::G when no qdot was supplied: B_(q, 0) = G_)
+    int fstar_off[kMaxLevels], fstar_total;
+    double tlim, alim;
+};
+
+template <int NT>
+DWBC_DEV void hqp_normalize_rows(Thr th, double *Mx, double *vx, int rows, int nv) {
+    for (int i = th.tid; i < rows; i += NT) {
+        double n2 = 0.0;
+        for (int c = 0; c < nv; c++) n2 += Mx[i * nv + c] * Mx[i * nv + c];
+        const double nrm = sqrt(n2);
+        if (nrm > 0.0) {
+            const double rn = 1.0 / nrm;
+            for (int c = 0; c < nv; c++) Mx[i * nv + c] *= rn;
+            vx[i] *= rn;
+        }
+    }
+}
+
+template <int NT>
+DWBC_DEV void lqp_configure_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d, const HqpIO &io, const double *dump, const io_t *fstar, int inst) {
+    const int n = cfg.n, m = n - 6, cd = cfg.cd, nv = d.nv;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *Ai = dm + dl.A_inv, *JC = dm + dl.J_C, *Bn = dm + cfg.oBn;
+    const io_t *fs = fstar + (size_t)inst * cfg.fstar_total;
+    double *rec = io.rec + (size_t)inst * d.rec;
+    for (int idx = th.tid; idx < d.rec; idx += NT) rec[idx] = 0.0;
+    HQP_SYNC();
+    // ---- level 0
+    {
+        double *A0 = rec + d.oA[0], *a0 = rec + d.oa[0], *B0 = rec + d.oB[0], *b0 = rec + d.ob[0];
+        for (int idx = th.tid; idx < m * nv; idx += NT) {
+            const int i = idx / nv, c = idx - i * nv;
+            const double v = c < n ? A[(6 + i) * n + c] : JC[(c - n) * n + 6 + i];  // [A_j | J_C^T_j]
+            A0[i * nv + c] = v;
+            A0[(m + i) * nv + c] = -v;
+        }
+        for (int i = th.tid; i < m; i += NT) { a0[i] = -cfg.tlim + Bn[6 + i]; a0[m + i] = -cfg.tlim - Bn[6 + i]; }
+        for (int idx = th.tid; idx < 6 * nv; idx += NT) {
+            const int i = idx / nv, c = idx - i * nv;
+            B0[idx] = c < n ? A[i * n + c] : JC[(c - n) * n + i];
+        }
+        for (int i = th.tid; i < 6; i += NT) b0[i] = Bn[i];
+        HQP_SYNC();
+        hqp_normalize_rows<NT>(th, A0, a0, 2 * m, nv);
+        hqp_normalize_rows<NT>(th, B0, b0, 6, nv);
+        double *y0 = rec + d.oy[0];
+        for (int i = th.tid; i < n; i += NT) {
+            double acc = 0.0;
+            for (int c = 0; c < n; c++) acc -= Ai[i * n + c] * Bn[c];
+            y0[i] = acc;
+        }
+    }
+    // ---- shared cost 5 A / |A|_F on the acceleration block
+    {
+        double f2 = 0.0;
+        for (int idx = 0; idx < n * n; idx++) f2 += A[idx] * A[idx];
+        const double sc = 5.0 / sqrt(f2);
+        double *Hc = rec + d.oH[1];
+        for (int idx = th.tid; idx < n * n; idx += NT) Hc[(idx / n) * nv + idx % n] = A[idx] * sc;
+    }
+    // ---- level 1
+    {
+        const int ncc = 10 * cfg.nc;
+        double *A1 = rec + d.oA[1], *a1 = rec + d.oa[1], *B1 = rec + d.oB[1], *b1 = rec + d.ob[1];
+        const double *Rc = dm + dl.contact_rot;
+        // getContactConstraintMatrix(): C = -A_const_a A_rot; row r of contact a acts on (R_a^T f, R_a^T m)
+        for (int idx = th.tid; idx < ncc * 6; idx += NT) {
+            const int rr_ = idx / 6, j = idx - rr_ * 6, a = rr_ / 10, r10 = rr_ - 10 * a;
+            const int ci = cfg.act[a];
+            (void)ci;
+            real_t w[6] = {0, 0, 0, 0, 0, 0};
+            // world unit wrench e_j -> local wrench (R^T applied to the force or the moment half)
+            const double *R = Rc + a * 9;
+            const int h = j / 3, x = j % 3;
+            for (int y = 0; y < 3; y++) w[3 * h + y] = (real_t)R[x * 3 + y];  // (R^T e_x)_y = R[x][y]
+            const double v = (double)cone_row(r10, (real_t)cfg.lx[a], (real_t)cfg.ly[a], (real_t)cfg.mu[a], (real_t)cfg.muz[a], w);
+            A1[rr_ * nv + n + 6 * a + j] = -v;
+        }
+        for (int i = th.tid; i < m; i += NT) {
+            A1[(ncc + i) * nv + 6 + i] = 1.0;
+            A1[(ncc + m + i) * nv + 6 + i] = -1.0;
+            a1[ncc + i] = -cfg.alim;
+            a1[ncc + m + i] = -cfg.alim;
+        }
+        for (int idx = th.tid; idx < cd * n; idx += NT) B1[(idx / n) * nv + idx % n] = JC[idx];
+        (void)b1;
+        HQP_SYNC();
+        hqp_normalize_rows<NT>(th, A1, a1, ncc + 2 * m, nv);
+        hqp_normalize_rows<NT>(th, B1, b1, cd, nv);
+    }
+    // ---- task levels
+    for (int i = 0; i < cfg.n_tasks; i++) {
+        const int t = cfg.t_dof[i];
+        double *Bt = rec + d.oB[2 + i], *bt = rec + d.ob[2 + i];
+        const double *Jt = dm + dl.J_task + i * kMaxTaskDof * n;
+        for (int idx = th.tid; idx < t * n; idx += NT) Bt[(idx / n) * nv + idx % n] = Jt[idx];
+        for (int j = th.tid; j < t; j += NT) bt[j] = -(double)fs[cfg.fstar_off[i] + j];
+        HQP_SYNC();
+        hqp_normalize_rows<NT>(th, Bt, bt, t, nv);
+    }
+    HQP_SYNC();
+}
+
+// tau = A[6:] qddot + J_C^T[6:] f_c + B_[6:]   (tests/sp_test/jacc_compare.cpp:416-418) from the last level's answer
+template <int NT>
+DWBC_DEV void lqp_torque_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d, const HqpIO &io, const double *dump, double *tau, int inst) {
+    const int n = cfg.n, m = n - 6, cd = cfg.cd;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *JC = dm + dl.J_C, *Bn = dm + cfg.oBn;
+    const double *y = io.rec + (size_t)inst * d.rec + d.oy[d.n_levels - 1];
+    for (int i = th.tid; i < m; i += NT) {
+        double acc = Bn[6 + i];
+        for (int c = 0; c < n; c++) acc += A[(6 + i) * n + c] * y[c];
+        for (int c = 0; c < cd; c++) acc += JC[c * n + 6 + i] * y[n + c];
+        tau[(size_t)inst * m + i] = acc;
+    }
+}
+
+}  // namespace dwbc

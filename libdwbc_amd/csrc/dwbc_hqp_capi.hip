@@ -1,0 +1,353 @@
+// dwbc_hqp_capi.hip -- C-ABI of the batched hierarchical-QP class and of the LQP configurator (include/dwbc_batch.h, section
+// "generic hierarchical-QP class"): kernels of dwbc_hqp.h + host bookkeeping.  gfx950 only, no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dwbc_capi_internal.h"
+#include "dwbc_hqp.h"
+
+using namespace dwbc;
+
+namespace {
+int fail(const std::string &s) { return capi_fail(s); }
+constexpr int kNT = 64;
+}  // namespace
+
+__global__ __launch_bounds__(kNT) void dwbc_hqp_kernel(const HqpDesc d, const HqpIO io) {
+    extern __shared__ __attribute__((aligned(16))) double hqp_lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    hqp_instance<kNT>(Thr{(int)threadIdx.x}, d, io, inst, hqp_lds);
+}
+__global__ __launch_bounds__(kNT) void dwbc_hqp_normalize_kernel(const HqpDesc d, const HqpIO io, int level) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    double *rec = io.rec + (size_t)inst * d.rec;
+    const Thr th{(int)threadIdx.x};
+    if (d.m[level] > 0) hqp_normalize_rows<kNT>(th, rec + d.oA[level], rec + d.oa[level], d.m[level], d.nv);
+    hqp_normalize_rows<kNT>(th, rec + d.oB[level], rec + d.ob[level], d.e[level], d.nv);
+}
+__global__ __launch_bounds__(kNT) void dwbc_lqp_configure_kernel(const LqpCfg cfg, const HqpDesc d, const HqpIO io, const double *dump, const double *fstar) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    lqp_configure_instance<kNT>(Thr{(int)threadIdx.x}, cfg, d, io, dump, fstar, inst);
+}
+__global__ __launch_bounds__(kNT) void dwbc_lqp_torque_kernel(const LqpCfg cfg, const HqpDesc d, const HqpIO io, const double *dump, double *tau) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    lqp_torque_instance<kNT>(Thr{(int)threadIdx.x}, cfg, d, io, dump, tau, inst);
+}
+
+struct dwbc_hqp {
+    int B = 0, device = 0;
+    int acc = 0, torque = 0, contact = 0;
+    HqpDesc d{};
+    bool laid_out = false, share_cost = false;
+    // host staging of what was handed over before the layout is fixed (dwbc_hqp_prepare), per level
+    struct Stage { std::vector<double> A, a, Bm, b, H, y, v; bool normalize = false; };
+    std::vector<Stage> stage;
+    double *d_rec = nullptr, *d_scratch = nullptr;
+    int *d_stat = nullptr;
+    hipStream_t stream = nullptr;
+    bool attr_set = false;
+    LqpCfg lqp{};  // set by dwbc_batch_configure_lqp
+    bool is_lqp = false;
+};
+
+namespace {
+int hqp_free(dwbc_hqp *h) {
+    if (h->d_rec) hipFree(h->d_rec);
+    if (h->d_scratch) hipFree(h->d_scratch);
+    if (h->d_stat) hipFree(h->d_stat);
+    h->d_rec = h->d_scratch = nullptr;
+    h->d_stat = nullptr;
+    h->laid_out = false;
+    return 1;
+}
+HqpIO hqp_io(const dwbc_hqp *h) { return HqpIO{h->B, h->d_rec, h->d_scratch, h->d_stat}; }
+// copy a per-instance block (len doubles at offset off of every record) host -> device
+int put_block(dwbc_hqp *h, int off, int len, const double *src) {
+    if (len == 0 || !src) return 1;
+    HIP_OK(hipMemcpy2D(h->d_rec + off, (size_t)h->d.rec * 8, src, (size_t)len * 8, (size_t)len * 8, h->B, hipMemcpyHostToDevice));
+    return 1;
+}
+int layout_and_alloc(dwbc_hqp *h) {
+    HIP_OK(hipSetDevice(h->device));
+    hqp_free(h);
+    if (h->d.n_levels < 1) return fail("HQP: no hierarchy");
+    hqp_layout(h->d, h->share_cost);
+    if (h->d.lds * 8 > 160 * 1024) return fail("HQP: the solver state of these sizes does not fit the 160 KB of LDS");
+    HIP_OK(hipMalloc(&h->d_rec, (size_t)h->B * h->d.rec * 8));
+    HIP_OK(hipMalloc(&h->d_scratch, (size_t)h->B * h->d.scratch * 8));
+    HIP_OK(hipMalloc(&h->d_stat, (size_t)h->B * HQS_COUNT * sizeof(int)));
+    HIP_OK(hipMemset(h->d_rec, 0, (size_t)h->B * h->d.rec * 8));
+    HIP_OK(hipMemset(h->d_stat, 0, (size_t)h->B * HQS_COUNT * sizeof(int)));
+    h->laid_out = true;
+    h->attr_set = false;
+    return 1;
+}
+int launch_solve(dwbc_hqp *h, int solve_first) {
+    if (!h->laid_out) return fail("HQP: call dwbc_hqp_prepare first");
+    HIP_OK(hipSetDevice(h->device));
+    if (!h->attr_set) {
+        HIP_OK(hipFuncSetAttribute((const void *)dwbc_hqp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->d.lds * 8));
+        h->attr_set = true;
+    }
+    HqpDesc d = h->d;
+    d.solve_first = solve_first;
+    hipLaunchKernelGGL(dwbc_hqp_kernel, dim3(h->B), dim3(kNT), (size_t)h->d.lds * 8, h->stream, d, hqp_io(h));
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+}  // namespace
+
+extern "C" {
+
+dwbc_hqp *dwbc_hqp_create(int B, int device, int acceleration_size, int torque_size, int contact_size) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { capi_err() = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
+    if (B < 1 || device < 0 || device >= ndev) { capi_err() = "bad arguments"; return nullptr; }
+    const int nv = acceleration_size + torque_size + contact_size;
+    if (nv < 1 || nv > kHqpMaxVar) { capi_err() = "HQP: variable size must be 1.." + std::to_string(kHqpMaxVar); return nullptr; }
+    auto *h = new dwbc_hqp();
+    h->B = B; h->device = device;
+    h->acc = acceleration_size; h->torque = torque_size; h->contact = contact_size;
+    h->d = HqpDesc{};
+    h->d.nv = nv;
+    h->d.max_iter = 400;
+    h->d.eps = 1.0e-6;   // Tikhonov weight of the canon (oracle/hqp_np.py HQP_EPS)
+    h->d.tol = 1.0e-6;   // HQP_TOL
+    return h;
+}
+void dwbc_hqp_destroy(dwbc_hqp *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hqp_free(h);
+    delete h;
+}
+int dwbc_hqp_clear(dwbc_hqp *h) {
+    hipSetDevice(h->device);
+    hqp_free(h);
+    h->d.n_levels = 0;
+    h->stage.clear();
+    h->is_lqp = false;
+    h->share_cost = false;
+    return 1;
+}
+int dwbc_hqp_num_levels(const dwbc_hqp *h) { return h->d.n_levels; }
+
+int dwbc_hqp_add_hierarchy(dwbc_hqp *h, int ineq, int eq) {
+    if (h->laid_out) { fail("HQP: hierarchy is fixed after dwbc_hqp_prepare (dwbc_hqp_clear starts over)"); return -1; }
+    if (h->d.n_levels >= kHqpMaxLevels) { fail("HQP: too many levels"); return -1; }
+    if (ineq < 0 || eq < 0 || eq > kHqpMaxEq) { fail("HQP: bad constraint sizes (equalities per level <= " + std::to_string(kHqpMaxEq) + ")"); return -1; }
+    const int lv = h->d.n_levels++;
+    h->d.m[lv] = ineq; h->d.e[lv] = eq; h->d.has_cost[lv] = 0;
+    h->stage.emplace_back();
+    return lv;
+}
+
+int dwbc_hqp_update_constraint_matrix(dwbc_hqp *h, int level, const double *A, const double *a, const double *Bm, const double *b) {
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    const int nv = h->d.nv, m = h->d.m[level], e = h->d.e[level];
+    if (m > 0 && (!A || !a)) return fail("HQP: inequality matrices missing");
+    if (e > 0 && (!Bm || !b)) return fail("HQP: equality matrices missing");
+    if (!h->laid_out) {
+        auto &st = h->stage[level];
+        if (m > 0) { st.A.assign(A, A + (size_t)h->B * m * nv); st.a.assign(a, a + (size_t)h->B * m); }
+        if (e > 0) { st.Bm.assign(Bm, Bm + (size_t)h->B * e * nv); st.b.assign(b, b + (size_t)h->B * e); }
+        return 1;
+    }
+    HIP_OK(hipSetDevice(h->device));
+    return put_block(h, h->d.oA[level], m * nv, A) && put_block(h, h->d.oa[level], m, a) && put_block(h, h->d.oB[level], e * nv, Bm) &&
+           put_block(h, h->d.ob[level], e, b);
+}
+
+int dwbc_hqp_update_cost_matrix(dwbc_hqp *h, int level, const double *H, const double *g) {
+    (void)g;  // stored by the reference (updateCostMatrix) and never read by solveSequentialSingle
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    if (!H) return fail("HQP: cost matrix missing");
+    const int nv = h->d.nv;
+    if (!h->laid_out) {
+        h->d.has_cost[level] = 1;
+        h->stage[level].H.assign(H, H + (size_t)h->B * nv * nv);
+        return 1;
+    }
+    if (!h->d.has_cost[level]) return fail("HQP: this level was prepared without a cost (set it before dwbc_hqp_prepare)");
+    HIP_OK(hipSetDevice(h->device));
+    return put_block(h, h->d.oH[level], nv * nv, H);
+}
+
+int dwbc_hqp_normalize_constraint_matrix(dwbc_hqp *h, int level) {
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    if (!h->laid_out) { h->stage[level].normalize = true; return 1; }
+    HIP_OK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(dwbc_hqp_normalize_kernel, dim3(h->B), dim3(kNT), 0, h->stream, h->d, hqp_io(h), level);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_hqp_set_answer(dwbc_hqp *h, int level, const double *y_ans, const double *v_ans) {
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    if (!h->laid_out) {
+        auto &st = h->stage[level];
+        if (y_ans) st.y.assign(y_ans, y_ans + (size_t)h->B * h->d.nv);
+        if (v_ans) st.v.assign(v_ans, v_ans + (size_t)h->B * h->d.m[level]);
+        return 1;
+    }
+    HIP_OK(hipSetDevice(h->device));
+    return put_block(h, h->d.oy[level], h->d.nv, y_ans) && put_block(h, h->d.ov[level], h->d.m[level], v_ans);
+}
+
+int dwbc_hqp_prepare(dwbc_hqp *h) {
+    if (h->laid_out) return 1;
+    if (!layout_and_alloc(h)) return 0;
+    const int nv = h->d.nv;
+    for (int lv = 0; lv < h->d.n_levels; lv++) {
+        auto &st = h->stage[lv];
+        const int m = h->d.m[lv], e = h->d.e[lv];
+        if (!st.A.empty() && !(put_block(h, h->d.oA[lv], m * nv, st.A.data()) && put_block(h, h->d.oa[lv], m, st.a.data()))) return 0;
+        if (!st.Bm.empty() && !(put_block(h, h->d.oB[lv], e * nv, st.Bm.data()) && put_block(h, h->d.ob[lv], e, st.b.data()))) return 0;
+        if (!st.H.empty() && !put_block(h, h->d.oH[lv], nv * nv, st.H.data())) return 0;
+        if (!st.y.empty() && !put_block(h, h->d.oy[lv], nv, st.y.data())) return 0;
+        if (!st.v.empty() && !put_block(h, h->d.ov[lv], m, st.v.data())) return 0;
+        if (st.normalize && !dwbc_hqp_normalize_constraint_matrix(h, lv)) return 0;
+        st = dwbc_hqp::Stage{};
+    }
+    return 1;
+}
+
+int dwbc_hqp_solve_first(dwbc_hqp *h, int init) {
+    (void)init;
+    // level 0 alone over the full variable: run the cascade restricted to one level
+    if (!h->laid_out && !dwbc_hqp_prepare(h)) return 0;
+    const int keep = h->d.n_levels;
+    h->d.n_levels = 1;
+    const int ok = launch_solve(h, 1);
+    h->d.n_levels = keep;
+    return ok;
+}
+int dwbc_hqp_solve_sequential(dwbc_hqp *h, int init) {
+    (void)init;
+    if (!h->laid_out && !dwbc_hqp_prepare(h)) return 0;
+    return launch_solve(h, 0);
+}
+
+size_t dwbc_hqp_field_bytes(const dwbc_hqp *h, int level, int field) {
+    if (level < 0 || level >= h->d.n_levels) return 0;
+    const size_t nv = h->d.nv, m = h->d.m[level], e = h->d.e[level], B = h->B;
+    switch (field) {
+        case DWBC_HQP_Y_ANS: return B * nv * 8;
+        case DWBC_HQP_V_ANS: case DWBC_HQP_a: return B * m * 8;
+        case DWBC_HQP_W_ANS: case DWBC_HQP_b: return B * e * 8;
+        case DWBC_HQP_STATUS: case DWBC_HQP_ITER: case DWBC_HQP_NULL_SIZE: return B * sizeof(int);
+        case DWBC_HQP_A: return B * m * nv * 8;
+        case DWBC_HQP_B: return B * e * nv * 8;
+        default: return 0;
+    }
+}
+
+int dwbc_hqp_get(dwbc_hqp *h, int level, int field, void *out, size_t bytes) {
+    if (!h->laid_out) return fail("HQP: nothing prepared");
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    if (bytes != dwbc_hqp_field_bytes(h, level, field)) return fail("HQP: size mismatch");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    if (bytes == 0) return 1;
+    int off = -1, len = 0;
+    const int nv = h->d.nv, m = h->d.m[level], e = h->d.e[level];
+    switch (field) {
+        case DWBC_HQP_Y_ANS: off = h->d.oy[level]; len = nv; break;
+        case DWBC_HQP_V_ANS: off = h->d.ov[level]; len = m; break;
+        case DWBC_HQP_W_ANS: off = h->d.ow[level]; len = e; break;
+        case DWBC_HQP_A: off = h->d.oA[level]; len = m * nv; break;
+        case DWBC_HQP_a: off = h->d.oa[level]; len = m; break;
+        case DWBC_HQP_B: off = h->d.oB[level]; len = e * nv; break;
+        case DWBC_HQP_b: off = h->d.ob[level]; len = e; break;
+        case DWBC_HQP_STATUS: case DWBC_HQP_ITER: case DWBC_HQP_NULL_SIZE: {
+            const int so = (field == DWBC_HQP_STATUS ? HQS_STATUS : field == DWBC_HQP_ITER ? HQS_ITER : HQS_NULL) + level;
+            HIP_OK(hipMemcpy2D(out, sizeof(int), h->d_stat + so, HQS_COUNT * sizeof(int), sizeof(int), h->B, hipMemcpyDeviceToHost));
+            return 1;
+        }
+        default: return fail("HQP: unknown field");
+    }
+    HIP_OK(hipMemcpy2D(out, (size_t)len * 8, h->d_rec + off, (size_t)h->d.rec * 8, (size_t)len * 8, h->B, hipMemcpyDeviceToHost));
+    return 1;
+}
+
+int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
+    if (!b || !h) return fail("NULL handle");
+    if (b->dtype != DWBC_F64) return fail("LQP: fp64 batches only");
+    if (h->B != b->B || h->device != b->device) return fail("LQP: the HQP object must have the batch's size and device");
+    if (!b->dump_on || !b->d_dump) return fail("LQP: needs dwbc_batch_enable_dump(b, 1) and a solved cycle (A_, A_inv_, J_C, B_, J_task come from it)");
+    if (b->last_reduced) return fail("LQP: run the full-model cycle first (ConfigureLQP_R is not built)");
+    if (b->su.n_custom > 0 || b->su.has_com_task) return fail("LQP: link task levels only");
+    if (b->h_flags.empty() || (b->d_flags && !b->own_flags)) return fail("LQP: contact flags must be set through dwbc_batch_set_contact (the host checks that they are uniform)");
+    const int ncn = b->su.n_contacts;
+    LqpCfg cfg{};
+    cfg.n = b->n;
+    cfg.nc = 0;
+    for (int c = 0; c < ncn; c++)
+        if (b->h_flags[c]) {
+            if (cfg.nc >= kMaxActiveContacts) return fail("LQP: more than 2 active contacts");
+            cfg.act[cfg.nc] = c;
+            cfg.lx[cfg.nc] = b->su.c_lx[c]; cfg.ly[cfg.nc] = b->su.c_ly[c]; cfg.mu[cfg.nc] = b->su.c_mu[c]; cfg.muz[cfg.nc] = b->su.c_muz[c];
+            cfg.nc++;
+        }
+    for (int i = 1; i < b->B; i++)
+        if (memcmp(&b->h_flags[(size_t)i * ncn], &b->h_flags[0], ncn) != 0)
+            return fail("LQP: every instance of the batch must be in the same contact state (the level sizes depend on it)");
+    if (cfg.nc < 1) return fail("LQP: no active contact");
+    cfg.cd = 6 * cfg.nc;
+    cfg.n_tasks = b->su.n_levels;
+    for (int i = 0; i < b->su.n_levels; i++) { cfg.t_dof[i] = b->su.t_dof[i]; cfg.fstar_off[i] = b->su.fstar_off[i]; }
+    cfg.fstar_total = b->su.fstar_total;
+    cfg.oBn = b->d_qdot ? b->dl.B : b->dl.G;  // B_(q, qdot = 0) = G_
+    cfg.tlim = 200.0;  // `tlim`, src/dwbc.cpp:4360
+    cfg.alim = 5.0;    // `alim`, src/dwbc.cpp:4398
+    if (h->acc != b->n || h->torque != 0 || h->contact != cfg.cd)
+        return fail("LQP: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(b->n) + ", 0, " + std::to_string(cfg.cd) + ")");
+    if (2 + cfg.n_tasks > kHqpMaxLevels) return fail("LQP: too many task levels");
+    // (re)build the hierarchy if its shape changed
+    bool same = h->is_lqp && h->laid_out && h->d.n_levels == 2 + cfg.n_tasks && h->lqp.cd == cfg.cd;
+    for (int i = 0; same && i < cfg.n_tasks; i++) same = h->d.e[2 + i] == cfg.t_dof[i];
+    if (!same) {
+        dwbc_hqp_clear(h);
+        h->share_cost = true;
+        if (dwbc_hqp_add_hierarchy(h, 2 * b->m, 6) < 0) return 0;
+        if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 2 * b->m, cfg.cd) < 0) return 0;
+        h->d.has_cost[1] = 1;
+        for (int i = 0; i < cfg.n_tasks; i++) {
+            if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[i]) < 0) return 0;
+            h->d.has_cost[2 + i] = 1;
+        }
+        if (!layout_and_alloc(h)) return 0;
+        h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+        h->is_lqp = true;
+    }
+    h->lqp = cfg;
+    h->stream = b->stream;
+    HIP_OK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(dwbc_lqp_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau) {
+    if (!b || !h || !tau) return fail("NULL argument");
+    if (!h->is_lqp || !h->laid_out) return fail("LQP: dwbc_batch_configure_lqp first");
+    HIP_OK(hipSetDevice(b->device));
+    double *d_tau = nullptr;
+    HIP_OK(hipMalloc(&d_tau, (size_t)b->B * b->m * 8));
+    hipLaunchKernelGGL(dwbc_lqp_torque_kernel, dim3(b->B), dim3(kNT), 0, b->stream, h->lqp, h->d, hqp_io(h), (const double *)b->d_dump, d_tau);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) e = hipMemcpy(tau, d_tau, (size_t)b->B * b->m * 8, hipMemcpyDeviceToHost);
+    hipFree(d_tau);
+    if (e != hipSuccess) return fail(std::string("lqp torque: ") + hipGetErrorString(e));
+    return 1;
+}
+
+}  // extern "C"

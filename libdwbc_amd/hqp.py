@@ -1,0 +1,125 @@
+"""Host-side mirror of the reference's generic hierarchical-QP class for a batch (include/dwbc_hqp.h: HQP, HQP_Hierarch) and of
+RobotData::ConfigureLQP / CalcControlTorqueLQP (src/dwbc.cpp:4304-4452).
+
+    hqp = HQP(B, acceleration_size, torque_size, contact_size)        # HQP::initialize
+    lv = hqp.addHierarchy(ineq, eq)                                   # HQP::addHierarchy
+    hqp.updateConstraintMatrix(lv, A, a, B, b)                        # per instance: A (B, ineq, nv) ...
+    hqp.updateCostMatrix(lv, H, g); hqp.normalizeConstraintMatrix(lv)
+    hqp.prepare(); hqp.solveSequential()                              # levels 1.. (solvefirst(): level 0)
+    y = hqp.y_ans(lv)                                                 # hqp_hs_[lv].y_ans_
+
+    hqp = HQP.for_lqp(wbc, contact_dof=12); wbc.solve(); hqp.configure_lqp(wbc); hqp.solveSequential(); tau = hqp.lqp_torque(wbc)
+
+All arithmetic happens in libdwbc_hip.so (dwbc_hqp.h); this is ctypes plumbing.
+"""
+import numpy as np
+
+from . import _lib
+from .batch import DwbcError, _check
+
+Y_ANS, V_ANS, W_ANS, STATUS, ITER, NULL_SIZE, MAT_A, VEC_a, MAT_B, VEC_b = range(10)
+
+
+class HQP:
+    def __init__(self, B, acceleration_size, torque_size, contact_size, device=0):
+        self._L = _lib.load()
+        self.B = int(B)
+        self.nv = acceleration_size + torque_size + contact_size
+        self.acceleration_size_, self.torque_size_, self.contact_size_ = acceleration_size, torque_size, contact_size
+        self._h = self._L.dwbc_hqp_create(self.B, int(device), int(acceleration_size), int(torque_size), int(contact_size))
+        if not self._h:
+            raise DwbcError(_lib.last_error())
+        self._sizes = []
+
+    @classmethod
+    def for_lqp(cls, wbc, contact_dof, device=0):
+        """the object RobotData::ConfigureLQP fills: y = [qddot (system dof); f_c (contact dof)]"""
+        return cls(wbc.B, wbc.n, 0, contact_dof, device=device)
+
+    def addHierarchy(self, ineq_const_size, eq_const_size):
+        lv = self._L.dwbc_hqp_add_hierarchy(self._h, int(ineq_const_size), int(eq_const_size))
+        if lv < 0:
+            raise DwbcError(_lib.last_error())
+        self._sizes.append((int(ineq_const_size), int(eq_const_size)))
+        return lv
+
+    def _arr(self, x, shape):
+        if x is None:
+            return None
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), shape))
+        return a
+
+    def updateConstraintMatrix(self, level, A, a, Bm, b):
+        m, e = self._sizes[level]
+        A_ = self._arr(A, (self.B, m, self.nv)) if m else None
+        a_ = self._arr(a, (self.B, m)) if m else None
+        B_ = self._arr(Bm, (self.B, e, self.nv)) if e else None
+        b_ = self._arr(b, (self.B, e)) if e else None
+        p = lambda x: x.ctypes.data if x is not None else None
+        _check(self._L.dwbc_hqp_update_constraint_matrix(self._h, level, p(A_), p(a_), p(B_), p(b_)))
+
+    def updateCostMatrix(self, level, H, g=None):
+        H_ = self._arr(H, (self.B, self.nv, self.nv))
+        g_ = self._arr(np.zeros(self.nv) if g is None else g, (self.B, self.nv))
+        _check(self._L.dwbc_hqp_update_cost_matrix(self._h, level, H_.ctypes.data, g_.ctypes.data))
+
+    def normalizeConstraintMatrix(self, level):
+        _check(self._L.dwbc_hqp_normalize_constraint_matrix(self._h, level))
+
+    def set_answer(self, level, y_ans, v_ans=None):
+        y_ = self._arr(y_ans, (self.B, self.nv))
+        v_ = self._arr(v_ans, (self.B, self._sizes[level][0])) if v_ans is not None else None
+        _check(self._L.dwbc_hqp_set_answer(self._h, level, y_.ctypes.data, v_.ctypes.data if v_ is not None else None))
+
+    def prepare(self):
+        _check(self._L.dwbc_hqp_prepare(self._h))
+
+    def solvefirst(self, init=True):
+        _check(self._L.dwbc_hqp_solve_first(self._h, 1 if init else 0))
+
+    def solveSequential(self, init=True):
+        _check(self._L.dwbc_hqp_solve_sequential(self._h, 1 if init else 0))
+
+    # ---- RobotData::ConfigureLQP / CalcControlTorqueLQP
+    def configure_lqp(self, wbc):
+        _check(self._L.dwbc_batch_configure_lqp(wbc._h, self._h))
+        n = self._L.dwbc_hqp_num_levels(self._h)
+        m = wbc.m
+        self._sizes = [(2 * m, 6), (None, self.contact_size_)] + [(0, wbc.task_dof(i)) for i in range(n - 2)]
+        nb = self._L.dwbc_hqp_field_bytes(self._h, 1, V_ANS)
+        self._sizes[1] = (nb // (8 * self.B), self.contact_size_)
+
+    def lqp_torque(self, wbc):
+        tau = np.zeros((self.B, wbc.m))
+        _check(self._L.dwbc_batch_lqp_torque(wbc._h, self._h, tau.ctypes.data))
+        return tau
+
+    def num_levels(self):
+        return self._L.dwbc_hqp_num_levels(self._h)
+
+    def get(self, level, field):
+        nb = self._L.dwbc_hqp_field_bytes(self._h, level, field)
+        is_int = field in (STATUS, ITER, NULL_SIZE)
+        out = np.zeros(nb // (4 if is_int else 8), dtype=np.int32 if is_int else np.float64)
+        _check(self._L.dwbc_hqp_get(self._h, level, field, out.ctypes.data, out.nbytes))
+        return out.reshape(self.B, -1) if not is_int else out
+
+    def y_ans(self, level):
+        return self.get(level, Y_ANS)
+
+    def v_ans(self, level):
+        return self.get(level, V_ANS)
+
+    def w_ans(self, level):
+        return self.get(level, W_ANS)
+
+    def close(self):
+        if self._h:
+            self._L.dwbc_hqp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -100,3 +100,69 @@ class Emu:
         assert off >= 0
         n = int(np.prod(shape))
         return dmp[:, off : off + n].reshape((dmp.shape[0],) + tuple(shape))
+
+
+class EmuHQP:
+    """host emulation of the batched hierarchical-QP kernels (libdwbc_amd/csrc/dwbc_hqp.h), same entry points as the C-ABI"""
+
+    def __init__(self, B, nv, m, e, has_cost, share_cost=False, solve_first=False):
+        L = lib(False)
+        self.L = L
+        L.emu_hqp_create.restype = C.c_void_p
+        L.emu_hqp_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.emu_hqp_data.restype = C.POINTER(C.c_double)
+        L.emu_hqp_data.argtypes = [C.c_void_p]
+        L.emu_hqp_stat.restype = C.POINTER(C.c_int)
+        L.emu_hqp_stat.argtypes = [C.c_void_p]
+        for f in ("emu_hqp_rec", "emu_hqp_lds_bytes"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.emu_hqp_offset.restype = C.c_int
+        L.emu_hqp_offset.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.emu_hqp_solve.argtypes = [C.c_void_p]
+        L.emu_hqp_destroy.argtypes = [C.c_void_p]
+        L.emu_lqp_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_lqp_torque.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.B, self.nv = B, nv
+        self.m = np.asarray(m, np.int32)
+        self.e = np.asarray(e, np.int32)
+        self.hc = np.asarray(has_cost, np.int32)
+        self.h = L.emu_hqp_create(B, nv, len(self.m), self.m.ctypes.data, self.e.ctypes.data, self.hc.ctypes.data, 1 if share_cost else 0, 1 if solve_first else 0)
+        self.rec = np.ctypeslib.as_array(L.emu_hqp_data(self.h), shape=(B, L.emu_hqp_rec(self.h)))
+        self.stat = np.ctypeslib.as_array(L.emu_hqp_stat(self.h), shape=(B, 24))
+
+    def block(self, level, what, shape):
+        """view of a per-instance block: what = 0 A 1 a 2 B 3 b 4 H 5 y 6 v 7 w"""
+        off = self.L.emu_hqp_offset(self.h, level, what)
+        n = int(np.prod(shape))
+        return self.rec[:, off : off + n].reshape((self.B,) + tuple(shape))
+
+    def solve(self):
+        self.L.emu_hqp_solve(self.h)
+
+    def configure_lqp(self, emu, act, dump, fstar, use_B=False):
+        act = np.asarray(act, np.int32)
+        dump = np.ascontiguousarray(dump, np.float64)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        self.L.emu_lqp_configure(self.h, emu.h, len(act), act.ctypes.data, 1 if use_B else 0, dump.ctypes.data, fstar.ctypes.data)
+
+    def lqp_torque(self, emu, nc, dump, use_B=False):
+        dump = np.ascontiguousarray(dump, np.float64)
+        tau = np.zeros((self.B, emu.m))
+        self.L.emu_lqp_torque(self.h, emu.h, nc, 1 if use_B else 0, dump.ctypes.data, tau.ctypes.data)
+        return tau
+
+    def status(self, level):
+        return self.stat[:, level]
+
+    def iters(self, level):
+        return self.stat[:, 8 + level]
+
+    def null_size(self, level):
+        return self.stat[:, 16 + level]
+
+    def __del__(self):
+        try:
+            self.L.emu_hqp_destroy(self.h)
+        except Exception:
+            pass

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../libdwbc_amd/csrc/dwbc_reduced.h"
+#include "../../libdwbc_amd/csrc/dwbc_hqp.h"
 #include "../../libdwbc_amd/csrc/dwbc_model.h"
 #include "../../libdwbc_amd/csrc/dwbc_setup.h"
 
@@ -165,5 +166,61 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     }
     from_real(rdump, dump);
     return 1;
+}
+
+// ---- generic HQP class (dwbc_hqp.h): levels described by (m, e, has_cost); per-instance records laid out by hqp_layout()
+struct EmuHqp {
+    HqpDesc d;
+    std::vector<double> rec, scratch;
+    std::vector<int> stat;
+    int B;
+};
+EmuHqp *emu_hqp_create(int B, int nv, int n_levels, const int *m, const int *e, const int *has_cost, int share_cost, int solve_first) {
+    auto *h = new EmuHqp();
+    h->d = HqpDesc{};
+    h->d.nv = nv; h->d.n_levels = n_levels; h->d.solve_first = solve_first; h->d.max_iter = 400; h->d.eps = 1.0e-6; h->d.tol = 1.0e-6;
+    for (int i = 0; i < n_levels; i++) { h->d.m[i] = m[i]; h->d.e[i] = e[i]; h->d.has_cost[i] = has_cost[i]; }
+    hqp_layout(h->d, share_cost != 0);
+    h->B = B;
+    h->rec.assign((size_t)B * h->d.rec, 0.0);
+    h->scratch.assign((size_t)B * h->d.scratch, 0.0);
+    h->stat.assign((size_t)B * HQS_COUNT, 0);
+    return h;
+}
+void emu_hqp_destroy(EmuHqp *h) { delete h; }
+int emu_hqp_rec(EmuHqp *h) { return h->d.rec; }
+int emu_hqp_offset(EmuHqp *h, int level, int what) {  // 0 A 1 a 2 B 3 b 4 H 5 y 6 v 7 w
+    const HqpDesc &d = h->d;
+    const int o[8] = {d.oA[level], d.oa[level], d.oB[level], d.ob[level], d.oH[level], d.oy[level], d.ov[level], d.ow[level]};
+    return o[what];
+}
+double *emu_hqp_data(EmuHqp *h) { return h->rec.data(); }
+int *emu_hqp_stat(EmuHqp *h) { return h->stat.data(); }
+int emu_hqp_lds_bytes(EmuHqp *h) { return h->d.lds * 8; }
+void emu_hqp_solve(EmuHqp *h) {
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    std::vector<double> lds(h->d.lds + 16);
+    for (int b = 0; b < h->B; b++) hqp_instance<1>(Thr{0}, h->d, io, b, lds.data());
+}
+// RobotData::ConfigureLQP from a dump record (B x DumpLayout::total doubles) + f*, then the cascade and the LQP torque
+void emu_lqp_configure(EmuHqp *h, EmuCtx *c, int nc, const int *act, int use_B, const double *dump, const double *fstar) {
+    LqpCfg cfg{};
+    cfg.n = c->model.ndof; cfg.nc = nc; cfg.cd = 6 * nc; cfg.n_tasks = c->su.n_levels;
+    const DumpLayout dl = DumpLayout::make(cfg.n);
+    for (int i = 0; i < c->su.n_levels; i++) { cfg.t_dof[i] = c->su.t_dof[i]; cfg.fstar_off[i] = c->su.fstar_off[i]; }
+    cfg.fstar_total = c->su.fstar_total;
+    for (int a = 0; a < nc; a++) { cfg.act[a] = act[a]; cfg.lx[a] = c->su.c_lx[act[a]]; cfg.ly[a] = c->su.c_ly[act[a]]; cfg.mu[a] = c->su.c_mu[act[a]]; cfg.muz[a] = c->su.c_muz[act[a]]; }
+    cfg.oBn = use_B ? dl.B : dl.G;
+    cfg.tlim = 200.0; cfg.alim = 5.0;
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    for (int b = 0; b < h->B; b++) lqp_configure_instance<1>(Thr{0}, cfg, h->d, io, dump, fstar, b);
+}
+void emu_lqp_torque(EmuHqp *h, EmuCtx *c, int nc, int use_B, const double *dump, double *tau) {
+    LqpCfg cfg{};
+    cfg.n = c->model.ndof; cfg.nc = nc; cfg.cd = 6 * nc;
+    const DumpLayout dl = DumpLayout::make(cfg.n);
+    cfg.oBn = use_B ? dl.B : dl.G;
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    for (int b = 0; b < h->B; b++) lqp_torque_instance<1>(Thr{0}, cfg, h->d, io, dump, tau, b);
 }
 }

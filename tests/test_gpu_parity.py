@@ -478,3 +478,28 @@ def test_gpu_bench_two_ranks_gloo():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["collective_backend"] == "gloo" and line["config"]["status_ok_fraction"] > 0.9
     assert line["value"] > 1e4 and line["roofline"]["kernel"].startswith("dwbc::dwbc_cycle_kernel_v2")
+
+
+def test_redundant_task_levels_do_not_abort_the_cascade():
+    """a redundant lower level (TASK_CUSTOM level whose Jacobian repeats rows of level 0) through the HIP
+    kernel and the restatement: both finish with status 1 and the same torques (see tests/test_kernel_emulation.py for why the
+    t x t blocks stay nonsingular; a rank-deficient task Jacobian itself makes Lambda_task undefined in the reference too)."""
+    from tests.test_kernel_emulation import _redundant_custom_case
+
+    import libdwbc_amd as D
+
+    B = 8
+    q, fl, fs, J, tau, st = _redundant_custom_case(B, 10)
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_custom_task(1, 3)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar(0, fs[:, :6])
+    wbc.set_custom_task(1, fs[:, 6:9], J)
+    wbc.solve()
+    assert (wbc.get("status") == st).all() and st.all()
+    assert np.abs(wbc.get("tau") - tau).max() < TOL

@@ -1,0 +1,304 @@
+"""the generic hierarchical-QP class (reference include/dwbc_hqp.h, src/dwbc_hqp.cpp) and the LQP
+configurator (RobotData::ConfigureLQP / CalcControlTorqueLQP, src/dwbc.cpp:4304-4452).
+
+PARITY UNPINNED in the reference: each level goes to OSQP (not vendored) and no test asserts a number of this path
+(tests/sp_test/herzog_test.cpp, jacc_compare.cpp only print).  What is pinned here:
+  * the numpy restatement (oracle/hqp_np.py) by first principles: every level's answer satisfies the KKT conditions of the
+    problem the reference poses, and the hierarchy holds (a later level never changes an earlier level's equality residual or
+    slack);
+  * the kernels (host emulation, then HIP through the C-ABI) against that restatement to 1e-6;
+  * on the golden CASE 1 / 2 states, the matrices the configurator builds from golden-pinned A_, A_inv_, J_C.
+"""
+import numpy as np
+import pytest
+
+from oracle import dwbc_np as Dn
+from oracle import hqp_np as H
+from tests import cases
+
+TOL = 1e-6
+
+
+def _random_hierarchy(rng, nv=14, levels=((6, 3), (5, 2), (0, 3), (4, 2)), cost_levels=(1, 3)):
+    """a small generic hierarchy with inequalities that bite: returns per-level dicts"""
+    out = []
+    for i, (m, e) in enumerate(levels):
+        d = dict(m=m, e=e)
+        d["A"] = rng.standard_normal((m, nv))
+        d["a"] = -0.3 * np.abs(rng.standard_normal(m)) + 0.4 * rng.standard_normal(m)
+        d["B"] = rng.standard_normal((e, nv))
+        d["b"] = rng.standard_normal(e)
+        if i in cost_levels:
+            Q = rng.standard_normal((nv, nv))
+            d["H"] = 0.05 * (Q @ Q.T)
+        out.append(d)
+    return out
+
+
+def _oracle_generic(levels, nv, solve_first=True):
+    hq = H.HQP()
+    hq.initialize(nv, 0, 0)
+    for d in levels:
+        hq.addHierarchy(d["m"], d["e"])
+        h = hq.hqp_hs_[-1]
+        h.updateConstraintMatrix(d["A"] if d["m"] else None, d["a"] if d["m"] else None, d["B"], d["b"])
+        if "H" in d:
+            h.updateCostMatrix(d["H"], np.zeros(nv))
+        h.normalizeConstraintMatrix()
+    hq.prepare()
+    ok = hq.solvefirst() if solve_first else 1
+    ok &= hq.solveSequential()
+    return hq, ok
+
+
+def _check_level_kkt(hq, i, tol=1e-6):
+    """KKT of level i's problem (module docstring of oracle/hqp_np.py) at its answer"""
+    hs = hq.hqp_hs_
+    h = hs[i]
+    n = h.variable_size_
+    y_prev = hs[i - 1].y_ans_ if i > 0 else np.zeros(n)
+    Z = hs[i - 1].Z_ if i > 0 else np.eye(n)
+    u = np.linalg.lstsq(Z, h.y_ans_ - y_prev, rcond=None)[0]
+    assert np.abs(Z @ u - (h.y_ans_ - y_prev)).max() < 1e-8  # the step stays in the null space of the earlier equalities
+    Bz = h.B_ @ Z
+    grad = Bz.T @ (Bz @ u + h.B_ @ y_prev + h.b_) + H.HQP_EPS * u
+    if h.enable_cost_:
+        grad = grad + Z.T @ h.H_ @ (y_prev + Z @ u)
+    lam_rows, lam_vals = [], []
+    if h.ineq_const_size_ > 0:
+        s = h.A_ @ h.y_ans_ + h.a_  # own rows: v = max(0, s), multiplier = v
+        assert np.abs(h.v_ans_ - np.maximum(s, 0.0)).max() < tol
+        grad = grad + (h.A_ @ Z).T @ h.v_ans_
+    for j in range(i):
+        hj = hs[j]
+        if hj.ineq_const_size_ == 0:
+            continue
+        sj = hj.A_ @ h.y_ans_ + hj.a_ - hj.v_ans_
+        assert sj.max() < tol  # earlier levels' rows hold with their frozen slack
+        act = sj > -1e-7
+        lam_rows.append((hj.A_ @ Z)[act])
+    if lam_rows and sum(r.shape[0] for r in lam_rows):
+        C = np.vstack(lam_rows)
+        lam = np.linalg.lstsq(C.T, -grad, rcond=None)[0]
+        assert np.abs(C.T @ lam + grad).max() < tol * (1 + np.abs(grad).max())
+        assert lam.min() > -1e-6 * (1 + np.abs(lam).max())
+    else:
+        assert np.abs(grad).max() < tol
+
+
+def test_oracle_generic_hierarchy_satisfies_kkt_and_priority():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        levels = _random_hierarchy(rng)
+        hq, ok = _oracle_generic(levels, 14)
+        assert ok == 1
+        assert [h.null_space_size_ for h in hq.hqp_hs_] == [11, 9, 6, 4]
+        for i in range(len(levels)):
+            _check_level_kkt(hq, i)
+        # priority: later answers keep the earlier levels' equality residuals (they move inside the null spaces)
+        for i in range(len(levels)):
+            for j in range(i):
+                hj = hq.hqp_hs_[j]
+                assert np.abs((hj.B_ @ hq.hqp_hs_[i].y_ans_ + hj.b_) - (hj.B_ @ hj.y_ans_ + hj.b_)).max() < 1e-8
+        assert any(len(h.working_set_) > 0 for h in hq.hqp_hs_)
+
+
+def _lqp_oracle(q, fstar, tasks=cases.TASKS_2LEVEL):
+    m = cases.tocabi_model()
+    c = Dn.Cycle(m)
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    for lv, links in enumerate(tasks):
+        for mode, link, pt in links:
+            c.add_task(lv, mode, link, pt)
+    c.update_kinematics(q)
+    c.set_contact([1, 1])
+    Bn = Dn.nonlinear_effects(m, q, np.zeros(39))
+    Js = [c.task_jacobian(i) for i in range(len(tasks))]
+    fs, off = [], 0
+    for J in Js:
+        fs.append(fstar[off : off + J.shape[0]])
+        off += J.shape[0]
+    hq = H.configure_lqp(c, Bn, Js, fs)
+    ok = hq.solveSequential()
+    return hq, ok, H.lqp_torque(c, Bn, hq.hqp_hs_[-1].y_ans_), c
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_oracle_lqp_on_golden_states(case):
+    """ConfigureLQP on the reference's CASE 1 / 2 states: the level matrices are built from golden-pinned quantities, the cascade
+    satisfies KKT level by level, and the resulting torque respects the rows it was asked to respect."""
+    q = np.array(cases.Q_CASE[case])
+    fs = np.array(list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1]))
+    hq, ok, tau, c = _lqp_oracle(q, fs)
+    assert ok == 1
+    assert np.abs(c.A_inv - cases.golden(case, "A_inv_")).max() < 1e-8 and np.abs(c.J_C - cases.golden(case, "J_C")).max() < 1e-10
+    hs = hq.hqp_hs_
+    assert [h.null_space_size_ for h in hs] == [45, 33, 27, 24]
+    assert [(h.ineq_const_size_, h.eq_const_size_) for h in hs] == [(66, 6), (86, 12), (0, 6), (0, 3)]
+    for i in range(1, 4):
+        _check_level_kkt(hq, i, tol=2e-6)
+    y = hs[-1].y_ans_
+    # floating-base dynamics hold exactly through the whole cascade (level 0 equality), the torque stays inside +-200
+    assert np.abs(hs[0].B_ @ y + hs[0].b_).max() < 1e-9
+    assert np.abs(tau).max() < H.LQP_TAU_LIM
+    # unilateral, loaded feet (f_z < 0 in the reference's sign convention) and accelerations inside +-5
+    assert y[39 + 2] < 0 and y[39 + 8] < 0 and np.abs(y[6:39]).max() <= H.LQP_ACC_LIM + 1e-6
+    # B_(q, 0) = G_ (what the kernel uses when no qdot was supplied)
+    assert np.abs(Dn.nonlinear_effects(cases.tocabi_model(), q, np.zeros(39)) - c.G).max() < 1e-9
+
+
+def test_emulated_hqp_generic_hierarchy_matches_oracle():
+    from tests.emu.emu import EmuHQP
+
+    rng = np.random.default_rng(11)
+    B, nv = 5, 14
+    probs = [_random_hierarchy(rng) for _ in range(B)]
+    m = [d["m"] for d in probs[0]]
+    e = [d["e"] for d in probs[0]]
+    hc = [1 if "H" in d else 0 for d in probs[0]]
+    eh = EmuHQP(B, nv, m, e, hc, share_cost=False, solve_first=True)
+    refs = []
+    for b, levels in enumerate(probs):
+        hq, ok = _oracle_generic(levels, nv)
+        assert ok == 1
+        refs.append(hq)
+        for lv, h in enumerate(hq.hqp_hs_):  # the emulation takes the normalised matrices the oracle built
+            if m[lv]:
+                eh.block(lv, 0, (m[lv], nv))[b] = h.A_
+                eh.block(lv, 1, (m[lv],))[b] = h.a_
+            eh.block(lv, 2, (e[lv], nv))[b] = h.B_
+            eh.block(lv, 3, (e[lv],))[b] = h.b_
+            if hc[lv]:
+                eh.block(lv, 4, (nv, nv))[b] = h.H_
+    eh.solve()
+    for b, hq in enumerate(refs):
+        for lv, h in enumerate(hq.hqp_hs_):
+            assert eh.status(lv)[b] == 1 and eh.null_size(lv)[b] == h.null_space_size_
+            assert np.abs(eh.block(lv, 5, (nv,))[b] - h.y_ans_).max() < TOL, (b, lv)
+            if m[lv]:
+                assert np.abs(eh.block(lv, 6, (m[lv],))[b] - h.v_ans_).max() < TOL
+            assert np.abs(eh.block(lv, 7, (e[lv],))[b] - h.w_ans_).max() < TOL
+    assert sum(int(eh.iters(lv).sum()) for lv in range(4)) > 0  # inequalities were active somewhere
+
+
+def test_emulated_lqp_matches_oracle_on_golden_and_synthetic_states():
+    from tests.emu.emu import Emu, EmuHQP
+
+    B = 6
+    q, fl, fs = cases.synth_batch(B, seed=23, yaw=True)
+    q[0], q[1] = cases.Q_CASE[1], cases.Q_CASE[2]
+    for i, case in enumerate((1, 2)):
+        fs[i] = list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])
+    fs[2:] *= 3.0  # larger task accelerations: more rows of the limits become active
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, dump=True)
+    eh = EmuHQP(B, 51, [66, 86, 0, 0], [6, 12, 6, 3], [0, 1, 1, 1], share_cost=True)
+    eh.configure_lqp(e, [0, 1], r["dump"], fs)
+    eh.solve()
+    tau = eh.lqp_torque(e, 2, r["dump"])
+    for b in range(B):
+        hq, ok, tau_ref, _ = _lqp_oracle(q[b], fs[b])
+        assert ok == 1
+        for lv, h in enumerate(hq.hqp_hs_):
+            assert eh.status(lv)[b] == 1 and eh.null_size(lv)[b] == h.null_space_size_
+            if h.ineq_const_size_:
+                assert np.abs(eh.block(lv, 0, (h.ineq_const_size_, 51))[b] - h.A_).max() < 1e-9
+                assert np.abs(eh.block(lv, 1, (h.ineq_const_size_,))[b] - h.a_).max() < 1e-9
+            assert np.abs(eh.block(lv, 2, (h.eq_const_size_, 51))[b] - h.B_).max() < 1e-9
+            assert (np.abs(eh.block(lv, 5, (51,))[b] - h.y_ans_) / (1.0 + np.abs(h.y_ans_))).max() < TOL, (b, lv)
+        assert np.abs(tau[b] - tau_ref).max() < 1e-5  # |A| ~ 1e2 amplifies the 1e-7 of y
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_hqp_class_generic_hierarchy_matches_oracle():
+    import libdwbc_amd as D
+
+    rng = np.random.default_rng(12)
+    B, nv = 48, 14
+    probs = [_random_hierarchy(rng) for _ in range(B)]
+    lv_sizes = [(d["m"], d["e"]) for d in probs[0]]
+    hq = D.HQP(B, nv, 0, 0)
+    for m, e in lv_sizes:
+        hq.addHierarchy(m, e)
+    for lv, (m, e) in enumerate(lv_sizes):
+        hq.updateConstraintMatrix(lv, np.array([p[lv]["A"] for p in probs]) if m else None, np.array([p[lv]["a"] for p in probs]) if m else None,
+                                  np.array([p[lv]["B"] for p in probs]), np.array([p[lv]["b"] for p in probs]))
+        if "H" in probs[0][lv]:
+            hq.updateCostMatrix(lv, np.array([p[lv]["H"] for p in probs]))
+        hq.normalizeConstraintMatrix(lv)
+    hq.prepare()
+    hq.solvefirst()
+    hq.solveSequential()
+    from libdwbc_amd import hqp as Hq
+
+    nact = 0
+    for b in range(B):
+        ref, ok = _oracle_generic(probs[b], nv)
+        assert ok == 1
+        for lv, h in enumerate(ref.hqp_hs_):
+            assert hq.get(lv, Hq.STATUS)[b] == 1 and hq.get(lv, Hq.NULL_SIZE)[b] == h.null_space_size_
+            assert np.abs(hq.y_ans(lv)[b] - h.y_ans_).max() < TOL, (b, lv)
+            assert np.abs(hq.w_ans(lv)[b] - h.w_ans_).max() < TOL
+            if h.ineq_const_size_:
+                assert np.abs(hq.v_ans(lv)[b] - h.v_ans_).max() < TOL
+            nact += len(h.working_set_)
+    assert nact > B  # the inequalities bite
+
+
+@pytest.mark.gpu
+def test_gpu_lqp_batch_matches_oracle_and_keeps_its_constraints():
+    """RobotData::ConfigureLQP + CalcControlTorqueLQP at B = 1024 (BASELINE configs[1] shape) on the device: a seeded subset
+    against the restatement, the whole batch through the properties of the formulation."""
+    import libdwbc_amd as D
+    from libdwbc_amd import hqp as Hq
+
+    B, NS = 1024, 12
+    q, fl, fs = cases.synth_batch(B, seed=31)
+    q[0], q[1] = cases.Q_CASE[1], cases.Q_CASE[2]
+    for i, case in enumerate((1, 2)):
+        fs[i] = list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])
+    fs[2:] *= 3.0
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+    wbc.enable_dump(True)
+    wbc.set_state(q)
+    wbc.set_contact(fl)
+    wbc.set_fstar_all(fs)
+    wbc.solve()
+    hq = D.HQP.for_lqp(wbc, 12)
+    hq.configure_lqp(wbc)
+    hq.solveSequential()
+    tau = hq.lqp_torque(wbc)
+    assert hq.num_levels() == 4
+    for lv in range(4):
+        assert (hq.get(lv, Hq.STATUS) == 1).all()
+    assert (hq.get(0, Hq.NULL_SIZE) == 45).all() and (hq.get(3, Hq.NULL_SIZE) == 24).all()
+    y = hq.y_ans(3)
+    for b in range(NS):
+        ref, ok, tau_ref, _ = _lqp_oracle(q[b], fs[b])
+        assert ok == 1
+        for lv, h in enumerate(ref.hqp_hs_):
+            assert (np.abs(hq.y_ans(lv)[b] - h.y_ans_) / (1.0 + np.abs(h.y_ans_))).max() < TOL, (b, lv)
+        assert np.abs(tau[b] - tau_ref).max() < 1e-5
+    # whole batch: floating-base dynamics (level-0 equality) hold for the final answer, torque inside the LQP's own limit,
+    # level-1 rows hold with their slack, contact forces unilateral
+    B0, b0 = hq.get(0, Hq.MAT_B).reshape(B, 6, 51), hq.get(0, Hq.VEC_b)
+    assert np.abs(np.einsum("bij,bj->bi", B0, y) + b0).max() < 1e-8
+    assert np.abs(tau).max() < 200.0 + 1e-6
+    A1, a1, v1 = hq.get(1, Hq.MAT_A).reshape(B, 86, 51), hq.get(1, Hq.VEC_a), hq.v_ans(1)
+    assert (np.einsum("bij,bj->bi", A1, y) + a1 - v1).max() < 1e-7
+    assert (y[:, 39 + 2] < 1e-6).all() and (y[:, 39 + 8] < 1e-6).all()  # unilateral contact (f_z <= 0 in the reference's convention)
+    # a second configure + solve on a new state reuses the object (CalcControlTorqueLQP per cycle)
+    q2 = q.copy()
+    q2[:, 6:39] += 0.01
+    wbc.set_state(q2)
+    wbc.solve()
+    hq.configure_lqp(wbc)
+    hq.solveSequential(init=False)
+    assert np.abs(hq.y_ans(3) - y).max() > 1e-6 and (hq.get(3, Hq.STATUS) == 1).all()

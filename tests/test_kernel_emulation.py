@@ -155,6 +155,74 @@ def test_emulated_kernel_custom_task_level():
     assert np.abs(tau[:, 1]).max() > 1.0 and np.abs(r["tau"] - tau).max() < 1e-6
 
 
+def _redundant_custom_case(B, seed):
+    """level 0 = pelvis 6D; level 1 = TASK_CUSTOM whose Jacobian is the pelvis' linear Jacobian, i.e. a level that asks again
+    for what level 0 already controls (the reference refuses a second TASK_LINK level on the same link, src/dwbc.cpp:536-546,
+    so a redundant / conflicting stack can only be written with TASK_CUSTOM)."""
+    from oracle import dwbc_np as Dn
+
+    m = cases.tocabi_model()
+    q, fl, _ = cases.synth_batch(B, seed=seed, yaw=True)
+    fs = 0.8 * np.random.default_rng(seed).uniform(-1, 1, size=(B, 9))
+    J = np.zeros((B, 3, 39))
+    tau = np.zeros((B, 3, 33))
+    st = np.zeros(B, np.int32)
+    for b in range(B):
+        R, p = Dn.forward_kinematics(m, q[b])
+        J[b] = Dn.point_jacobian(m, R, p, 0, np.zeros(3))[:3]
+        c = Dn.Cycle(m)
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.add_task(0, 0, 0)
+        c.add_custom_task(1, 3)
+        c.set_custom_J(1, J[b])
+        c.set_torque_limit(cases.TAU_LIM)
+        c.run(q[b], [1, 1], [fs[b, :6], fs[b, 6:]])
+        st[b] = c.status
+        tau[b] = [c.tau_grav, c.tau_task, c.tau_contact]
+    return q, fl, fs, J, tau, st
+
+
+def test_emulated_kernel_redundant_task_levels_match_oracle():
+    """A redundant (conflicting) lower level does not abort the cascade: its own Lambda_task and Q W^+ Q^T are full rank
+    (they are built from its own Jacobian, src/wbd.cpp:207-213), its null-space-projected torque map is numerically zero,
+    and the QP rows it contributes are the zero rows of the QP canon.  Kernel and restatement agree."""
+    B = 5
+    q, fl, fs, J, tau, st = _redundant_custom_case(B, 9)
+    e = Emu(cases.URDF, cases.CONTACTS_2, [cases.TASKS_2LEVEL[0], 3], cases.TAU_LIM)
+    Jpad = np.zeros((B, 1, 6, 39))
+    Jpad[:, 0, :3] = J
+    r = e.run(q, fl, fs, custom_J=Jpad)
+    assert (r["status"] == st).all() and st.all()
+    assert np.abs(r["tau"] - tau).max() < 1e-6
+
+
+def test_task_blocks_are_nonsingular_whenever_lambda_task_exists():
+    """Why the device inverts Q W^+ Q^T with an SPD factorisation where the reference calls a rank-revealing pseudo-inverse
+    (src/wbd.cpp:212): with M = A^-1 N_c (symmetric PSD), W = M[6:,6:] and Q = Lambda J M[:,6:], a null vector n of W gives
+    M [0; n] = 0, so Q^T v is orthogonal to null(W) for every v; and M J^T v with zero joint part would be a pure base
+    acceleration, which a 6D contact forbids (J_C a = 0).  Hence Q W^+ Q^T is singular only if Lambda_task itself does not
+    exist -- where the reference's own .inverse() (src/wbd.cpp:210) is already undefined.  Checked numerically on the golden
+    fixtures with random task Jacobians."""
+    rng = np.random.default_rng(0)
+    for case in (1, 2):
+        Ainv, JC = cases.golden(case, "A_inv_"), cases.golden(case, "J_C")
+        Lam = np.linalg.inv(JC @ Ainv @ JC.T)
+        M = Ainv - Ainv @ JC.T @ Lam @ JC @ Ainv
+        W = M[6:, 6:]
+        Wp = np.linalg.pinv(W, rcond=1e-6)
+        ns = np.linalg.svd(W)[0][:, 27:]  # null space of W (rank 27)
+        assert np.abs(M[:6, 6:] @ ns).max() < 1e-9  # M [0; n] = 0
+        for t in (3, 6):
+            J = rng.standard_normal((t, 39))
+            Lt = np.linalg.inv(J @ M @ J.T)
+            Q = (Lt @ J @ M)[:, 6:]
+            assert np.abs(Q @ ns).max() < 1e-7 * np.abs(Q).max()  # rows of Q lie in range(W)
+            S = Q @ Wp @ Q.T
+            ev = np.linalg.eigvalsh(0.5 * (S + S.T))
+            assert ev.min() > 1e-8 * ev.max()
+
+
 def test_emulated_zmp_and_contact_frames():
     """getZMP(getContactForce(tau_total)) and cc_[i].xc_pos / rotm (reference src/dwbc.cpp:898-939) from the dump record"""
     from oracle.dwbc_np import Cycle
