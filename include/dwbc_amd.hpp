@@ -3,8 +3,11 @@
 // control loop (reference example/main.cpp:62-108, tests/dwbc_test.cpp:61-130) compiles against it with
 //     using DWBC::RobotData;     // from this header instead of the reference's dwbc.h
 // Differences that are deliberate and visible:
-//   * vectors / matrices are dwbc_amd::Vec / dwbc_amd::Mat (std::vector<double> based, row-major); when Eigen is
-//     available define DWBC_AMD_WITH_EIGEN before including to get Eigen::VectorXd / MatrixXd overloads and getters;
+//   * vectors / matrices are dwbc_amd::Vec / dwbc_amd::Mat (std::vector<double> based, row-major).  Every entry point that
+//     takes a vector is also a template over any type with data() / size() (Eigen::VectorXd, std::array, ...), and
+//     dwbc_amd::to_vector<V>(vec) / to_matrix<M>(mat) build the caller's own types from the results (M needs a
+//     (rows, cols) constructor and operator()(i, j): Eigen::MatrixXd qualifies) -- so code written with Eigen types compiles
+//     against this header without this header including Eigen;
 //   * every Calc* call launches the fused kernel (CalcContactConstraint .. CalcContactRedistribute are one launch on the
 //     device) and refreshes all public fields, so the reference's call order yields the reference's values; a loop that
 //     only needs the final torque should call CalcAll() once per tick;
@@ -16,6 +19,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dwbc_batch.h"
@@ -33,8 +37,20 @@ struct Mat {  // row-major dense matrix
 struct Vec3 {
     double v[3];
     Vec3(double x = 0, double y = 0, double z = 0) : v{x, y, z} {}
+    template <class V3, class = decltype(std::declval<const V3 &>().data()), class = decltype(std::declval<const V3 &>().size())>
+    Vec3(const V3 &o) : v{o.data()[0], o.data()[1], o.data()[2]} {}  // Eigen::Vector3d and the like
     const double *data() const { return v; }
+    size_t size() const { return 3; }
 };
+// any contiguous vector-like (data(), size()) -> Vec
+template <class V>
+inline Vec as_vec(const V &x) { return Vec(x.data(), x.data() + x.size()); }
+inline const Vec &as_vec(const Vec &x) { return x; }
+// results into the caller's own types
+template <class V>
+inline V to_vector(const Vec &x) { V o(x.size()); for (size_t i = 0; i < x.size(); i++) o[i] = x[i]; return o; }
+template <class M>
+inline M to_matrix(const Mat &x) { M o(x.rows, x.cols); for (int i = 0; i < x.rows; i++) for (int j = 0; j < x.cols; j++) o(i, j) = x(i, j); return o; }
 }  // namespace dwbc_amd
 
 namespace DWBC {
@@ -85,6 +101,68 @@ struct ContactView {  // include/dwbc_contact_constraint.h:27-80
     Mat rotm;
     bool contact = false;
     int contact_dof_ = 6;
+};
+
+// DWBC::HQP / HQP_Hierarch (include/dwbc_hqp.h:8-141): the fields callers read after a solve, one instance
+struct HQP_Hierarch {
+    int ineq_const_size_ = 0, eq_const_size_ = 0, null_space_size_ = 0, variable_size_ = 0;
+    int qp_status_ = 1, qp_iter_ = 0;
+    Vec y_ans_, v_ans_, w_ans_;
+};
+class RobotData;
+class HQP {
+  public:
+    int acceleration_size_ = 0, torque_size_ = 0, contact_size_ = 0;
+    std::vector<HQP_Hierarch> hqp_hs_;
+    HQP() {}
+    ~HQP() { if (h_) dwbc_hqp_destroy(h_); }
+    HQP(const HQP &) = delete;
+    HQP &operator=(const HQP &) = delete;
+    void initialize(int acceleration_size, int torque_size, int contact_size, int device = 0) {  // dwbc_hqp.cpp:16-21
+        if (h_) dwbc_hqp_destroy(h_);
+        acceleration_size_ = acceleration_size; torque_size_ = torque_size; contact_size_ = contact_size;
+        h_ = dwbc_hqp_create(1, device, acceleration_size, torque_size, contact_size);
+        if (!h_) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;
+        hqp_hs_.clear();
+    }
+    void addHierarchy(int ineq_const_size, int eq_const_size) {  // dwbc_hqp.cpp:425-434
+        if (dwbc_hqp_add_hierarchy(h_, ineq_const_size, eq_const_size) < 0) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        HQP_Hierarch hh;
+        hh.ineq_const_size_ = ineq_const_size; hh.eq_const_size_ = eq_const_size;
+        hh.variable_size_ = acceleration_size_ + torque_size_ + contact_size_;
+        hqp_hs_.push_back(hh);
+    }
+    // hqp_hs_[level].updateConstraintMatrix / updateCostMatrix / normalizeConstraintMatrix (dwbc_hqp.cpp:483-581)
+    void updateConstraintMatrix(int level, const Mat &A, const Vec &a, const Mat &B, const Vec &b) {
+        check(dwbc_hqp_update_constraint_matrix(h_, level, A.d.empty() ? nullptr : A.d.data(), a.empty() ? nullptr : a.data(), B.d.empty() ? nullptr : B.d.data(), b.empty() ? nullptr : b.data()));
+    }
+    void updateCostMatrix(int level, const Mat &H, const Vec &g) { check(dwbc_hqp_update_cost_matrix(h_, level, H.d.data(), g.data())); }
+    void normalizeConstraintMatrix(int level) { check(dwbc_hqp_normalize_constraint_matrix(h_, level)); }
+    void prepare(bool = false) { check(dwbc_hqp_prepare(h_)); }  // dwbc_hqp.cpp:23-85
+    void solvefirst(bool init = true) { if (check(dwbc_hqp_solve_first(h_, init))) fetch(); }       // dwbc_hqp.cpp:222-289
+    void solveSequential(bool init = true, bool = false) { if (check(dwbc_hqp_solve_sequential(h_, init))) fetch(); }  // :397-403
+    dwbc_hqp *handle() { return h_; }
+    void fetch() {  // answers of every level into hqp_hs_
+        const int n = dwbc_hqp_num_levels(h_);
+        if ((int)hqp_hs_.size() != n) hqp_hs_.resize(n);
+        for (int lv = 0; lv < n; lv++) {
+            HQP_Hierarch &hh = hqp_hs_[lv];
+            hh.variable_size_ = acceleration_size_ + torque_size_ + contact_size_;
+            hh.ineq_const_size_ = (int)(dwbc_hqp_field_bytes(h_, lv, DWBC_HQP_V_ANS) / 8);
+            hh.eq_const_size_ = (int)(dwbc_hqp_field_bytes(h_, lv, DWBC_HQP_W_ANS) / 8);
+            hh.y_ans_.assign(hh.variable_size_, 0.0); hh.v_ans_.assign(hh.ineq_const_size_, 0.0); hh.w_ans_.assign(hh.eq_const_size_, 0.0);
+            dwbc_hqp_get(h_, lv, DWBC_HQP_Y_ANS, hh.y_ans_.data(), hh.y_ans_.size() * 8);
+            if (hh.ineq_const_size_) dwbc_hqp_get(h_, lv, DWBC_HQP_V_ANS, hh.v_ans_.data(), hh.v_ans_.size() * 8);
+            if (hh.eq_const_size_) dwbc_hqp_get(h_, lv, DWBC_HQP_W_ANS, hh.w_ans_.data(), hh.w_ans_.size() * 8);
+            dwbc_hqp_get(h_, lv, DWBC_HQP_STATUS, &hh.qp_status_, sizeof(int));
+            dwbc_hqp_get(h_, lv, DWBC_HQP_ITER, &hh.qp_iter_, sizeof(int));
+            dwbc_hqp_get(h_, lv, DWBC_HQP_NULL_SIZE, &hh.null_space_size_, sizeof(int));
+        }
+    }
+
+  private:
+    dwbc_hqp *h_ = nullptr;
+    bool check(int ok) { if (!ok) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return ok != 0; }
 };
 
 class RobotData {
@@ -144,6 +222,12 @@ class RobotData {
         dwbc_batch_set_state(batch_, q_system_.data(), q_dot_system_.data(), q_ddot_system_.data());
         dirty_ = true;
     }
+    template <class V, class = decltype(std::declval<const V &>().data())>
+    void UpdateKinematics(const V &q_virtual, const V &q_dot_virtual, const V &q_ddot_virtual, bool update = true) {
+        UpdateKinematics(dwbc_amd::as_vec(q_virtual), dwbc_amd::as_vec(q_dot_virtual), dwbc_amd::as_vec(q_ddot_virtual), update);
+    }
+    template <class V, class = decltype(std::declval<const V &>().data())>
+    void SetTorqueLimit(const V &torque_limit) { SetTorqueLimit(dwbc_amd::as_vec(torque_limit)); }
     // ---- contacts (dwbc.h:259-291)
     void AddContactConstraint(int link_number, int contact_type, Vec3 contact_point, Vec3 /*contact_vector*/, double contact_x = 0, double contact_y = 0, bool verbose = false) {
         for (auto &c : cc_) if (c.link_number_ == link_number) { std::cout << "Contact Constraint Already Exist for Link : " << link_number << std::endl; return; }
@@ -193,6 +277,8 @@ class RobotData {
         dwbc_batch_set_fstar(batch_, heirarchy, f_star.data());
         dirty_ = true;
     }
+    template <class V, class = decltype(std::declval<const V &>().data())>
+    void SetTaskSpace(int heirarchy, const V &f_star) { SetTaskSpace(heirarchy, dwbc_amd::as_vec(f_star)); }
     // ---- the cycle (dwbc.h:280, 246, 349, 298, 303)
     int CalcContactConstraint() { return refresh() ? diag_[0] : 0; }
     Vec CalcGravCompensation() { refresh(); return torque_grav_; }
@@ -255,7 +341,28 @@ class RobotData {
         }
         return Vec3(z[0], z[1], z[2]);
     }
+    // ---- LQP formulation on the generic HQP class (dwbc.h:365-371; src/dwbc.cpp:4304-4452): y = [qddot; f_c]
+    int ConfigureLQP(HQP &hqp, bool = true) {
+        if (!refresh()) return 0;
+        if (!hqp.handle() || hqp.acceleration_size_ != (int)system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(system_dof_, 0, contact_dof_);
+        if (!dwbc_batch_configure_lqp(batch_, hqp.handle())) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        hqp.fetch();
+        return 1;
+    }
+    int CalcControlTorqueLQP(HQP &hqp, bool init = true) {
+        hqp.solveSequential(init);
+        for (auto &hh : hqp.hqp_hs_) if (!hh.qp_status_) return 0;
+        return 1;
+    }
+    // torque of the LQP answer, as the reference's harness forms it (tests/sp_test/jacc_compare.cpp:416-418)
+    Vec LQPTorque(HQP &hqp) {
+        Vec tau(model_dof_, 0.0);
+        if (!dwbc_batch_lqp_torque(batch_, hqp.handle(), tau.data())) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;
+        return tau;
+    }
     int CalcAll(bool init = true) { int ok = refresh(init); torque_contact_ = tau_contact_final_; return ok && diag_[0] && diag_[1] && diag_[2]; }
+    template <class V, class = decltype(std::declval<const V &>().data()), class = decltype(std::declval<const V &>().rows())>
+    Vec getContactForce(const V &command_torque) { return getContactForce(dwbc_amd::as_vec(command_torque)); }
     Vec getContactForce(const Vec &command_torque) {  // wbd.cpp:268-271: J_C_INV_T[:,6:] tau - P_C
         Vec f(contact_dof_, 0.0);
         for (unsigned c = 0; c < contact_dof_; c++) {

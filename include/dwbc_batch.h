@@ -39,7 +39,13 @@ enum { DWBC_F64 = 0, DWBC_F32 = 1 };
  * plain hierarchy and the closed-form two-contact redistribution run (src/dwbc.cpp:856-873, 1570-1619), full model only.
  * DWBC_SOLVE_REDUCED: the Reduced* call sequence (ReducedDynamicsCalculate, ReducedCalcContactConstraint,
  * ReducedCalcGravCompensation, ReducedCalcTaskSpace, ReducedCalcTaskControlTorque, ReducedCalcContactRedistribute --
- * reference include/dwbc.h:411-416, tests/sp_test/redu_dyn_test.cpp:263-298) instead of the full-model sequence */
+ * reference include/dwbc.h:411-416, tests/sp_test/redu_dyn_test.cpp:263-298) instead of the full-model sequence.
+ * DWBC_SOLVE_INIT: the `init` argument of CalcTaskControlTorque / CalcContactRedistribute.  Set: cold start (qpOASES init).
+ * Clear: hot start (qpOASES hotstart, src/qp_wrapper.cpp:249-296) -- every QP of the full-model path first visits the rows of
+ * its working set from the previous dwbc_batch_solve on this batch (kept in HBM); the returned point is the same canonical
+ * point, only the number of active-set steps changes.  The first solve of a batch always runs cold.  The failure fallback of
+ * SolveQPoases (fresh problem, setToReliable, nWSR x 10, src/qp_wrapper.cpp:298-339) has no counterpart to switch to: the
+ * device solver has no heuristic options, its step budget is the reference's nWSR + 10 nWSR. */
 enum { DWBC_SOLVE_HQP = 1, DWBC_SOLVE_INIT = 2, DWBC_SOLVE_REDUCED = 4 };
 
 /* fields for dwbc_batch_get / dwbc_batch_bind_device.  Shapes are per instance, row-major. */

@@ -23,6 +23,15 @@ __global__ void dwbc_cvt_d2f(const double *__restrict__ in, float *__restrict__ 
     if (i < n) out[i] = (float)in[i];
 }
 
+// part of [torque_grav_ | torque_task_ | torque_contact_] (sel 0..2) or their sum (sel 3), B x m
+__global__ void dwbc_tau_select(const double *__restrict__ tau, double *__restrict__ out, int m, size_t cnt, int sel) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const size_t inst = i / m, j = i - inst * m;
+    const double *s = tau + inst * 3 * m;
+    out[i] = sel == 3 ? s[j] + s[m + j] + s[2 * m + j] : s[sel * m + j];
+}
+
 namespace dwbc {
 std::string &capi_err() {
     static thread_local std::string e;
@@ -167,6 +176,7 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     if (b->own_wrench) hipFree(b->d_wrench);
     if (b->own_status) hipFree(b->d_status);
     hipFree(b->d_diag);
+    hipFree(b->d_total);
     hipFree(b->d_dump);
     hipFree(b->d_body);
     hipFree(b->d_topo);
@@ -396,7 +406,7 @@ static int upload_inputs(dwbc_batch *b) {
 
 // the lean instantiation (EXTRAS = false) serves every launch that uses none of the optional paths
 static bool lean_ok(const dwbc_batch *b) {
-    return b->hqp && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !b->dump_on && !getenv("DWBC_NO_LEAN");
+    return b->hqp && !b->warm && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !b->dump_on && !getenv("DWBC_NO_LEAN");
 }
 
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
@@ -437,7 +447,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
         float *dump;
         const float *body;
         const int *topo;
-        int hqp;
+        int hqp, warm;
     } io{};
     static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
     io.B = b->B;
@@ -456,6 +466,8 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     io.body = b->f_body;
     io.topo = b->d_topo;
     io.hqp = b->hqp;
+    io.warm = (b->warm && b->ws_valid) ? 1 : 0;
+    b->ws_valid = !lean;  // the full build leaves every QP's working set in the diagnostics record
     const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     void *args[] = {(void *)&b->su, (void *)&io};
     HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, b->f32_lds, b->stream));
@@ -487,6 +499,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.body = b->d_body;
     io.topo = b->d_topo;
     io.hqp = b->hqp;
+    io.warm = (b->warm && b->ws_valid) ? 1 : 0;
     if (!b->attr_set) {
         for (auto fn : {b->kern->fn, b->kern->fn_wide, b->kern->fn_lean, b->kern->fn_wide_lean})
             if (fn) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
@@ -497,6 +510,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     }
     const bool wide = b->kern->fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     const bool lean = b->kern->fn_lean && lean_ok(b);
+    b->ws_valid = !lean && !reduced;  // the full build leaves every QP's working set in the diagnostics record (DG_QP_ACT)
     auto fn = wide ? (lean ? b->kern->fn_wide_lean : b->kern->fn_wide) : (lean ? b->kern->fn_lean : b->kern->fn);
     hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
     HIP_OK(hipGetLastError());
@@ -505,6 +519,9 @@ static int launch(dwbc_batch *b, bool reduced = false) {
 
 int dwbc_batch_solve(dwbc_batch *b, unsigned flags) {
     b->hqp = (flags & DWBC_SOLVE_HQP) ? 1 : 0;
+    // init = false (DWBC_SOLVE_INIT clear): hot start from the working sets of the previous solve (src/dwbc.cpp:1064-1074).  The
+    // first solve of a batch, and the first after the lean kernel ran, has no working set to start from and runs cold.
+    b->warm = (flags & DWBC_SOLVE_INIT) ? 0 : 1;
     if (!b->hqp && (flags & DWBC_SOLVE_REDUCED)) return fail("hqp=false is not built on the reduced dynamics path");
     if (b->su.n_levels < 1) return fail("no task space");
     if (b->su.n_contacts < 1) return fail("no contact constraint");
@@ -528,7 +545,7 @@ int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src) {
     if (dst->B != src->B || dst->n != src->n || dst->su.nb != src->su.nb) return fail("CopyKinematicsData: batch size / model mismatch");
     HIP_OK(hipSetDevice(dst->device));
     dst->su = src->su;
-    auto clone = [&](double *&dd, bool &own, const double *sd, size_t count, std::vector<double> &hd, const std::vector<double> &hs, bool &dirty,
+    auto clone = [&](double *&dd, bool &own, const double *sd, size_t count, PinnedVec<double> &hd, const PinnedVec<double> &hs, bool &dirty,
                      bool src_own) -> int {
         hd = hs;
         if (count == 0) return 1;
@@ -638,8 +655,12 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
     HIP_OK(hipSetDevice(b->device));
     HIP_OK(hipStreamSynchronize(b->stream));
     const size_t B = b->B, m = b->m;
+    // device -> page-locked staging (asynchronous on the batch's stream, PCIe rate) -> the caller's memory
     auto d2h = [&](const void *src, size_t nbytes) -> int {
-        HIP_OK(hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost));
+        if (b->h_stage.size() < nbytes) b->h_stage.resize(nbytes);
+        HIP_OK(hipMemcpyAsync(b->h_stage.data(), src, nbytes, hipMemcpyDeviceToHost, b->stream));
+        HIP_OK(hipStreamSynchronize(b->stream));
+        memcpy(out, b->h_stage.data(), nbytes);
         return 1;
     };
     switch (field) {
@@ -651,15 +672,13 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
         case DWBC_STATUS: return d2h(b->d_status, need);
         case DWBC_DIAG: return d2h(b->d_diag, need);
         case DWBC_TAU_GRAV: case DWBC_TAU_TASK: case DWBC_TAU_CONTACT: case DWBC_TAU_TOTAL: {
-            std::vector<double> t(B * 3 * m);
-            HIP_OK(hipMemcpy(t.data(), b->d_tau, t.size() * 8, hipMemcpyDeviceToHost));
-            double *o = (double *)out;
-            for (size_t i = 0; i < B; i++)
-                for (size_t j = 0; j < m; j++) {
-                    const double *s = t.data() + i * 3 * m;
-                    o[i * m + j] = field == DWBC_TAU_GRAV ? s[j] : field == DWBC_TAU_TASK ? s[m + j] : field == DWBC_TAU_CONTACT ? s[2 * m + j] : s[j] + s[m + j] + s[2 * m + j];
-                }
-            return 1;
+            // one third of the bytes over PCIe: the part (or the sum, getTorqueCommand-style) is formed on the device
+            if (!b->d_total) HIP_OK(hipMalloc(&b->d_total, B * m * sizeof(double)));
+            const int sel = field == DWBC_TAU_GRAV ? 0 : field == DWBC_TAU_TASK ? 1 : field == DWBC_TAU_CONTACT ? 2 : 3;
+            const size_t cnt = B * m;
+            hipLaunchKernelGGL(dwbc_tau_select, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, b->stream, (const double *)b->d_tau, b->d_total, (int)m, cnt, sel);
+            HIP_OK(hipGetLastError());
+            return d2h(b->d_total, need);
         }
         default: break;
     }

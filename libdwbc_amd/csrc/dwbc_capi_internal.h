@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <new>
 #include <string>
 #include <vector>
 
@@ -11,6 +12,27 @@
 #include "dwbc_types.h"
 
 namespace dwbc {
+// host mirrors of the per-cycle inputs and the read-back staging live in page-locked memory: hipMemcpyAsync on the batch's stream
+// then really is asynchronous and runs at PCIe rate (pageable memory goes through the runtime's own staging, synchronously)
+template <class T>
+struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U>
+    PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+    template <class U>
+    bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <class T>
+using PinnedVec = std::vector<T, PinnedAlloc<T>>;
 struct KernelEntry;
 std::string &capi_err();  // thread-local last error (dwbc_last_error)
 inline int capi_fail(const std::string &s) {
@@ -42,7 +64,7 @@ struct dwbc_batch {
     bool dirty_custom = false;
     std::vector<double> h_traj, h_ctime;
     bool dirty_traj = false, dirty_ctime = false;
-    std::vector<double> h_qdot;
+    dwbc::PinnedVec<double> h_qdot;
     bool dirty_qdot = false;
     double *d_q = nullptr, *d_fstar = nullptr, *d_tau = nullptr, *d_wrench = nullptr, *d_dump = nullptr, *d_body = nullptr;
     unsigned char *d_flags = nullptr;
@@ -55,10 +77,14 @@ struct dwbc_batch {
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
     int f32_lds = 0, f32_key = -1, f32_topo = 0;
     int hqp = 1;
+    int warm = 0;           // last solve flags had DWBC_SOLVE_INIT clear
+    bool ws_valid = false;  // diag holds the working sets of a full-build launch
     bool last_reduced = false;  // mode of the most recent dwbc_batch_solve (kernel_name / launch_info report it)
     // host mirrors of the inputs
-    std::vector<double> h_q, h_fstar;
-    std::vector<unsigned char> h_flags;
+    dwbc::PinnedVec<double> h_q, h_fstar;
+    dwbc::PinnedVec<unsigned char> h_flags;
+    dwbc::PinnedVec<unsigned char> h_stage;  // read-back staging of dwbc_batch_get
+    double *d_total = nullptr;                // B x m scratch of the DWBC_TAU_* getters
     bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
     bool attr_set = false;
     int n_cu = 0;

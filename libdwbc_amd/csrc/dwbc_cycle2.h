@@ -263,6 +263,78 @@ DWBC_WDEV int sweep_inverse_tree(PLA_REF(real_t, s, NN), PL_REF(real_t, dg)) {
     return ok;
 }
 
+// The dense sweep with the pivot column fed through LDS instead of v_readlane (fp64 device build; W^+, 33 x 33).  The swept
+// matrix stays symmetric, so column K is row K across the lanes: ONE ds_write_b64 per pivot publishes it and broadcast
+// ds_read_b128 bring it back, two rows per instruction.  Issue cost per row update (tools/ubench/ubench3): 2 v_readlane + s_nop
+// + v_fma = 21 cycles against 8 (half a ds_read_b128) + 5.75; the compiler keeps only 2-3 such reads in flight, so all reads of
+// a column are issued back to back by hand and waited for once (profiles/r02_sweep_prototypes.txt: 24.9 k -> 16.3 k cycles).
+// The diagonal is carried shifted (dg - 2, next to the s[j][j] - 1 of the register sweep): with it the multiplier and the
+// diagonal update of the pivot lane are the same FMAs as every other lane's -- no per-pivot selects.
+#if !defined(DWBC_HOST_EMU)
+typedef double dwbc_d2v __attribute__((ext_vector_type(2)));
+template <int P, int NP>
+__device__ __forceinline__ void lds_col_issue(dwbc_d2v (&c)[NP], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[P]) : "v"(addr), "n"(16 * P));
+    if constexpr (P + 1 < NP) lds_col_issue<P + 1, NP>(c, addr);
+}
+template <int NP>
+__device__ __forceinline__ void lds_col_wait(dwbc_d2v (&c)[NP]) {
+    static_assert(NP == 17, "33-wide sweep");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]),
+                 "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(c[16]));
+}
+template <int NN, int K>
+__device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
+    constexpr int NP = (NN + 1) / 2;
+    dwbc_d2v col[NP];
+    asm volatile("ds_write_b64 %0, %1" ::"v"(cb + 8 * lane), "v"(s[K]) : "memory");
+    lds_col_issue<0, NP>(col, cb);
+    double d = readlane_f64(dg2, K) + 2.0;
+    int pos = d > 0.0 ? 1 : 0;
+    DWBC_FLAG_VGPR(pos);
+    ok &= pos;
+    if (!(d > 0.0)) d = 1.0;
+    const double rp = fast_rcp(d);
+    const double cj = s[K];     // pivot lane: d - 1
+    const double h = cj * rp;   // pivot lane: 1 - 1/d, the multiplier of the pivot column itself
+    lds_col_wait<NP>(col);
+#pragma unroll
+    for (int i = 0; i < NN; i++) s[i] -= col[i / 2][i & 1] * h;
+    dg2 -= cj * h;              // pivot lane: (d - 2) - (d - 2 + 1/d) = -1/d
+    if constexpr (K > 0) lds_pivot<NN, K - 1>(s, dg2, ok, cb, lane);
+}
+#endif
+
+template <int NN>
+DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
+#if defined(DWBC_HOST_EMU)
+    (void)colbuf;
+    return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
+#else
+    if constexpr (sizeof(real_t) != 8 || NN != 33) {
+        return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
+    } else {
+        const int lane = (int)threadIdx.x;
+        int ok = 1;
+        {
+            DWBC_LANE_OPAQUE(lp);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == lp) ? dg - 1.0 : s[i];
+        }
+        double dg2 = dg - 2.0;
+        lds_pivot<NN, NN - 1>(s, dg2, ok, (unsigned)(size_t)colbuf, lane);
+        ok = DWBC_FLAG_UNIFORM(ok);
+        {
+            DWBC_LANE_OPAQUE(le);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == le) ? -dg2 : -s[i];
+            dg = -dg2;
+        }
+        return ok;
+    }
+#endif
+}
+
 // inverse of a small SPD matrix (n <= 12) held in LDS: column per lane in registers + the sweep above.  Used for
 // Lambda_c^-1 = J A^-1 J^T, the null-space Gram matrix, Lambda_task^-1 and Q W^+ Q^T (all symmetric positive definite),
 // where the reference calls Eigen's general inverse / COD pseudo-inverse (src/wbd.cpp:115,210,212).  Returns 0 when a
@@ -586,7 +658,13 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     }
     DWBC_FSTAMP(18);  // W + alpha P assembled
     // dense, but with compile-time pivots (TopoDense): no selector chain for the lane's own pivot-row element, 126.3 -> 125.3 us
+#ifdef DWBC_W_SWEEP_READLANE
     if (!sweep_inverse_tree<TopoDense<M>, M>(w, dw)) st_contact = 0;
+#else
+    DWBC_SYNC();
+    if (!sweep_inverse_lds<M>(w, dw, L + S::c_s1)) st_contact = 0;  // c_s1: 72 doubles, free between alpha and the small inverses
+    DWBC_SYNC();
+#endif
     DWBC_FSTAMP(19);  // W sweep
     LANES {
         if (k > 0) {
@@ -795,7 +873,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const int ldw1 = is_task ? kQpLd : 6;
             qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
                                      is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, 6, fv, base, n1,
-                                     is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x);
+                                     is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x,
+                                     (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {

@@ -70,7 +70,11 @@ DWBC_WDEV real_t upick12(const real_t *a, int idx) {
 // NV >= nv: compile-time bound of the variable count (12, 9 or 6); every dot product, rank-one update and QR step runs over NV
 // entries instead of the maximum 12 (the padded entries are exact zeros, so the result does not depend on NV).
 template <int WS, int NV = kQpN>
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */) {
+// warm: reference row indices of the previous solve's working set (kQpN entries, -1 = empty) or nullptr.  Hot start in the sense of
+// SolveQPoases(init = false): the search visits those rows first -- each is added as soon as it is violated -- before it falls
+// back to the most-violated rule.  The Tikhonov problem is strictly convex, so the point the search ends at does not depend on
+// the order of the picks; only the path (and the iteration count, when the cold path adds rows it later drops) does.
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */, const int *warm = nullptr) {
     DWBC_LANE_DECL;
     const int k = nv - t;
     PLA(real_t, Mx, NV);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
@@ -122,7 +126,40 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     int used = 0, q = 0, it = 0, status = 1, p = 0, side = 0, kmin = 0;
     bool pick = true;
     real_t up = real_t(0.0), worst = real_t(0.0);
+    int wid[kQpN], wpos = kQpN;
+    if (WS && warm) {
+#pragma unroll
+        for (int a = 0; a < kQpN; a++) wid[a] = warm[a];
+        wpos = 0;
+    }
     for (;;) {
+        bool got = false;
+        if (WS && pick) {
+            while (wpos < kQpN && !got) {  // rows of the previous working set first
+                int id = -1;
+#pragma unroll
+                for (int a = 0; a < kQpN; a++) id = (a == wpos) ? wid[a] : id;
+                wpos++;
+                if (id < 0) continue;
+                LANES {
+                    const bool mh = LV(R.id_hi) == id && !(LV(actf) & 1) && LV(R.hi) < DWBC_QP_INF;
+                    const bool ml = LV(R.id_lo) == id && !(LV(actf) & 2) && LV(R.lo) < DWBC_QP_INF;
+                    LV(val) = mh ? LV(R.hi) - LV(d) : (ml ? LV(R.lo) + LV(d) : DWBC_QP_INF);
+                    LV(key) = (lane << 1) | (ml ? 1 : 0);
+                }
+                int pl;
+                WAVE_ARGMIN_F32(val, pl);
+                worst = BCAST(val, pl);
+                kmin = BCASTI(key, pl);
+                if (worst < -kQpTol) got = true;
+            }
+            if (got) {
+                p = kmin >> 1;
+                side = kmin & 1;
+                up = real_t(0.0);
+                pick = false;
+            }
+        }
         if (pick) {
             LANES {
                 const real_t sh = ((LV(actf) & 1) || LV(R.hi) >= DWBC_QP_INF) ? DWBC_QP_INF : LV(R.hi) - LV(d);

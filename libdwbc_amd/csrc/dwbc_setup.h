@@ -14,8 +14,10 @@ inline void setup_init(Setup &su, int nb, int ndof, int maxdepth) {
     su.nb = nb;
     su.ndof = ndof;
     su.maxdepth = maxdepth;
-    su.qp_max_iter_task = 1000;    // reference src/dwbc.cpp:1080
-    su.qp_max_iter_contact = 300;  // reference src/dwbc.cpp:1546
+    // nWSR of the first attempt + the 10 x nWSR of SolveQPoases' retry leg (src/qp_wrapper.cpp:298-339): the device solver has no
+    // "reliable" option set to fall back to, so the two budgets add up
+    su.qp_max_iter_task = 1000 + 10000;   // reference src/dwbc.cpp:1080
+    su.qp_max_iter_contact = 300 + 3000;  // reference src/dwbc.cpp:1546
     for (int l = 0; l < kMaxLevels; l++)
         for (int j = 0; j < kMaxTaskLinks; j++) su.t_traj_slot[l][j] = -1;
     for (int l = 0; l < kMaxLevels; l++) su.t_custom_slot[l] = -1;

@@ -77,6 +77,24 @@ int main(int argc, char **argv) {
         print_vec("reduced_torque_task_", rd_.torque_task_);
         print_vec("reduced_torque_contact_", rd_.torque_contact_);
     }
+    if (argc > 3 && std::string(argv[3]) == "lqp") {
+        // reference tests/sp_test/jacc_compare.cpp:386-418: ConfigureLQP, CalcControlTorqueLQP, torque of the answer
+        DWBC::HQP hqp_;
+        int ok_cfg = rd_.ConfigureLQP(hqp_);
+        int ok_lqp = rd_.CalcControlTorqueLQP(hqp_, true);
+        printf("\"lqp_ok\": [%d, %d, %d],\n", ok_cfg, ok_lqp, (int)hqp_.hqp_hs_.size());
+        print_vec("lqp_y", hqp_.hqp_hs_.back().y_ans_);
+        print_vec("lqp_torque", rd_.LQPTorque(hqp_));
+        printf("\"lqp_null\": [%d, %d, %d, %d],\n", hqp_.hqp_hs_[0].null_space_size_, hqp_.hqp_hs_[1].null_space_size_, hqp_.hqp_hs_[2].null_space_size_, hqp_.hqp_hs_[3].null_space_size_);
+    }
+    {
+        // a caller's own vector type (anything with data() / size(), e.g. Eigen::VectorXd) goes through the same entry points
+        struct MyVec { std::vector<double> s; const double *data() const { return s.data(); } size_t size() const { return s.size(); } };
+        MyVec f2{fstar_2};
+        rd_.SetTaskSpace(1, f2);
+        std::vector<float> back = dwbc_amd::to_vector<std::vector<float>>(rd_.torque_grav_);
+        printf("\"generic\": [%zu],\n", back.size());
+    }
     print_vec("contact_qp_last", rd_.ts_.back().contact_qp_, true);
     printf("}\n");
     return 0;

@@ -70,7 +70,7 @@ class Emu:
         g = np.ascontiguousarray(gains15, np.float64)
         self.L.emu_set_traj(C.c_void_p(self.h), level, link_index, slot, C.c_void_p(g.ctypes.data))
 
-    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None, custom_J=None, hqp=True, dense=False):
+    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None, custom_J=None, hqp=True, dense=False, warm_diag=None):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -80,6 +80,9 @@ class Emu:
         wr = np.zeros((B, 12))
         st = np.zeros(B, np.int32)
         diag = np.zeros((B, 90), np.int32)
+        if warm_diag is not None:  # init = false: the working sets of a previous run (its "diag") seed the QPs
+            diag[:] = warm_diag
+        self.L.emu_set_warm(1 if warm_diag is not None else 0)
         dmp = np.zeros((B, self.D)) if dump else None
         qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
         self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))

@@ -126,6 +126,8 @@ void emu_set_traj(EmuCtx *c, int level, int link_index, int slot, const double *
     for (int a = 0; a < 15; a++) c->su.t_gain[level][link_index][a] = gains15[a];
 }
 void emu_set_traj_data(const double *traj, const double *ctime) { g_emu_traj = traj; g_emu_ctime = ctime; }
+static int g_emu_warm = 0;
+void emu_set_warm(int on) { g_emu_warm = on; }
 static const double *g_emu_qdot = nullptr;
 void emu_set_qdot(const double *qd) { g_emu_qdot = qd; }
 
@@ -154,6 +156,7 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.body = rb.data();
     io.topo = c->topo.data();
     io.hqp = g_emu_hqp;
+    io.warm = g_emu_warm;
     std::vector<real_t> lds(Lds2<39, 34, 4>::total + 64);
     std::vector<int> ilds(64);
     for (int b = 0; b < B; b++) {

@@ -61,3 +61,22 @@ def test_facade_reduced_sequence():
     assert e(r["reduced_torque_task_"], r["torque_task_"]) < 1e-6
     assert e(r["reduced_torque_grav_"], cases.golden(1, "torque_grav_")) < 1e-6
     assert np.abs(np.asarray(r["reduced_torque_contact_"])[12:]).max() == 0.0  # only the contact-chain joints (dwbc.cpp:3766)
+
+
+@pytest.mark.gpu
+def test_facade_lqp_sequence():
+    """ConfigureLQP + CalcControlTorqueLQP + the torque of the answer (reference tests/sp_test/jacc_compare.cpp:386-418) through
+    the facade's DWBC::HQP, against the numpy restatement on the CASE 1 state."""
+    from tests.test_hqp import _lqp_oracle
+
+    _build()
+    out = subprocess.check_output([EXE, cases.URDF, "1", "lqp"], text=True)
+    r = json.loads(out[out.index("{"):])
+    assert r["lqp_ok"] == [1, 1, 4] and r["lqp_null"] == [45, 33, 27, 24] and r["generic"] == [33]
+    q = np.array(cases.Q_CASE[1])
+    fs = np.array(list(cases.FSTAR_CASE[1][0]) + list(cases.FSTAR_CASE[1][1]))
+    hq, ok, tau, _ = _lqp_oracle(q, fs)
+    assert ok == 1
+    y = np.asarray(r["lqp_y"])
+    assert (np.abs(y - hq.hqp_hs_[-1].y_ans_) / (1 + np.abs(y))).max() < 1e-6
+    assert np.abs(np.asarray(r["lqp_torque"]) - tau).max() < 1e-5

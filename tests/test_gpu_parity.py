@@ -503,3 +503,30 @@ def test_redundant_task_levels_do_not_abort_the_cascade():
     wbc.solve()
     assert (wbc.get("status") == st).all() and st.all()
     assert np.abs(wbc.get("tau") - tau).max() < TOL
+
+
+def test_warm_start_sequence_on_device():
+    """dwbc_batch_solve without DWBC_SOLVE_INIT (init = false): working sets carried over in HBM between launches.  A short
+    sequence of correlated states: every warm solve equals the cold solve of the same state; active-set steps do not grow."""
+    B = 256
+    q, fl, fs = cases.synth_batch(B, seed=78, yaw=True)
+    rng = np.random.default_rng(2)
+    wbc, ref = _make(B), _make(B)
+    steps_w = steps_c = 0
+    for k in range(4):
+        qk = q.copy()
+        qk[:, 6:39] += 0.002 * k * rng.standard_normal((B, 33))
+        fk = fs + 0.01 * k
+        wbc.set_state(qk); wbc.set_contact(fl); wbc.set_fstar_all(fk)
+        wbc.solve(init=(k == 0))
+        tw, sw, dw = wbc.get("tau"), wbc.get("status"), wbc.get("diag")
+        ref.set_state(qk); ref.set_contact(fl); ref.set_fstar_all(fk)
+        ref.solve(init=True)
+        tc, sc, dc = ref.get("tau"), ref.get("status"), ref.get("diag")
+        assert (sw == sc).all() and sc.mean() > 0.9
+        assert np.abs(tw - tc).max() < 1e-8
+        if k > 0:
+            steps_w += int(dw[:, 4:9].sum())
+            steps_c += int(dc[:, 4:9].sum())
+    assert 0 < steps_w <= steps_c
+    assert "false" in ref.kernel_name() and "true" in wbc.kernel_name()  # cold = lean build, warm = full build (carries the sets)

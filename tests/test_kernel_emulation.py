@@ -223,6 +223,26 @@ def test_task_blocks_are_nonsingular_whenever_lambda_task_exists():
             assert ev.min() > 1e-8 * ev.max()
 
 
+def test_emulated_warm_start_same_point_fewer_steps():
+    """init = false (reference src/dwbc.cpp:1064-1074, src/qp_wrapper.cpp:249-296: qpOASES hotstart from the previous working
+    set): the QPs visit the rows of the previous cycle's working sets first.  Same canonical point, no more active-set steps
+    than the cold start on a correlated state sequence."""
+    B = 24
+    q, fl, fs = cases.synth_batch(B, seed=77, yaw=True)
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r0 = e.run(q, fl, fs)
+    q2 = q.copy()
+    q2[:, 6:39] += 0.002 * np.random.default_rng(1).standard_normal((B, 33))
+    fs2 = fs + 0.01
+    cold = e.run(q2, fl, fs2)
+    warm = e.run(q2, fl, fs2, warm_diag=r0["diag"])
+    assert (cold["status"] == warm["status"]).all() and cold["status"].all()
+    assert np.abs(cold["tau"] - warm["tau"]).max() < 1e-9
+    assert (warm["diag"][:, 9:14] == cold["diag"][:, 9:14]).all()          # same working-set sizes
+    assert warm["diag"][:, 4:9].sum() <= cold["diag"][:, 4:9].sum()        # not more steps
+    assert cold["diag"][:, 4:6].sum() > 0
+
+
 def test_emulated_zmp_and_contact_frames():
     """getZMP(getContactForce(tau_total)) and cc_[i].xc_pos / rotm (reference src/dwbc.cpp:898-939) from the dump record"""
     from oracle.dwbc_np import Cycle
