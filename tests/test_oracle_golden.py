@@ -158,3 +158,47 @@ def test_cmm_angular_momentum_identity(tocabi):
         Psum += model["mass"][i] * vi
     assert np.abs(h[:3] - Psum).max() < 1e-6
     assert np.abs(h[3:] - Lsum).max() / max(1.0, np.abs(Lsum).max()) < 1e-5
+
+
+def _cycle(case):
+    from oracle import dwbc_np as Dn
+
+    c = Dn.Cycle(cases.tocabi_model())
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    c.add_task(0, 0, 0)
+    c.add_task(1, 6, 15)
+    c.set_torque_limit(cases.TAU_LIM)
+    c.run(np.array(cases.Q_CASE[case]), [1, 1], [np.array(cases.FSTAR_CASE[case][0]), np.array(cases.FSTAR_CASE[case][1])])
+    return c
+
+
+def test_case2_contact_fixture_is_qpoases_noise_on_a_flat_face():
+    """Why torque_contact_ of CASE 2 matches the reference fixture to 8.5e-4 only.  The last level's QP has
+    H = diag(I_3, 0_6): the contact-null variable c carries no cost and is fixed by qpOASES' Hessian regularisation alone
+    (epsRegularisation = 1e3 * EPS [ext]).  In CASE 2 only two cone rows are active, so four directions of c are decided by that
+    2.2e-13 weight: the fixture's c and the canonical least-norm c
+      * are feasible for the fixture's own QP (A1mat / ubA1mat) and active on the SAME rows {68, 70},
+      * differ by 8e-4 ALONG that face while their norms agree to 1e-9 relative, i.e. in the regularised objective they differ
+        by ~1e-19 -- thirteen orders below qpOASES' termination tolerance (1e9 * EPS): any point of that neighbourhood is
+        "optimal" for it, which one comes out is round-off of its factorisations at condition number 1/eps ~ 1e12.
+    CASE 1 has six active rows on the six c variables (a vertex): no flat direction, and the same comparison gives 4e-10."""
+    out = {}
+    for case in (1, 2):
+        g = lambda n: cases.golden(case, n)
+        NwJw, tc = g("NwJw"), g("torque_contact_")[:, 0]
+        c_fix = np.linalg.lstsq(NwJw, tc, rcond=None)[0]
+        assert np.abs(NwJw @ c_fix - tc).max() < 1e-12
+        A1, ub1 = g("A1mat"), g("ubA1mat")[:, 0]
+        c = _cycle(case)
+        c_can = np.linalg.lstsq(NwJw, c.tau_contact, rcond=None)[0]
+        sl_fix = ub1 - A1 @ np.concatenate([np.zeros(3), c_fix])
+        sl_can = ub1 - A1 @ np.concatenate([np.zeros(3), c_can])
+        assert sl_fix.min() > -1e-8 and sl_can.min() > -1e-8
+        assert set(np.where(sl_fix < 1e-6)[0]) == set(np.where(sl_can < 1e-6)[0])
+        out[case] = (np.abs(c_fix - c_can).max(), abs(np.linalg.norm(c_fix) - np.linalg.norm(c_can)) / np.linalg.norm(c_can),
+                     len(np.where(sl_can < 1e-6)[0]))
+    assert out[1][2] == 6 and out[1][0] < 1e-8
+    assert out[2][2] == 2 and 1e-4 < out[2][0] < 1e-3 and out[2][1] < 1e-8
+    assert np.linalg.norm(np.linalg.lstsq(cases.golden(2, "NwJw"), cases.golden(2, "torque_contact_")[:, 0], rcond=None)[0]) >= \
+        np.linalg.norm(np.linalg.lstsq(cases.golden(2, "NwJw"), _cycle(2).tau_contact, rcond=None)[0]) - 1e-12  # canonical = the smaller norm

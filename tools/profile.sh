@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel-trace stats + PMC passes for bench.py's workload.  Outputs under gpurun_out/.
-#   tools/profile_r1.sh <name> [trace|full] [extra bench.py args...]
+#   tools/profile.sh <name> [trace|full] [extra bench.py args...]
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 NAME=${1:-prof}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of tools/profile_r1.sh into the files kept under profiles/.
+"""Condense the rocprofv3 outputs of tools/profile.sh into the files kept under profiles/.
 
     python tools/summarize_profile.py gpurun_out/<name> profiles/<prefix>
 
