@@ -157,6 +157,11 @@ int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar);
  * limit and control time of `src` into `dst` (same model and batch size); the hand-off the reference uses between threads */
 int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src);
 
+/* page-locked host mirror of an input field (DWBC_IN_Q, DWBC_IN_CONTACT, DWBC_IN_FSTAR; NULL for anything else or before the
+ * field has a size): a caller that assembles its states directly in this memory and passes the same pointer to
+ * dwbc_batch_set_state / set_contact (or calls dwbc_batch_set_fstar with pointers into it -- level l starts at column
+ * fstar offset of l) skips the host-side copy; the upload is one asynchronous PCIe transfer on the batch's stream */
+void *dwbc_batch_host_ptr(dwbc_batch *b, int field);
 /* zero-copy: use a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr) for an input or output field */
 int dwbc_batch_bind_device(dwbc_batch *b, int field, void *device_ptr);
 int dwbc_batch_set_stream(dwbc_batch *b, void *hip_stream);
@@ -214,6 +219,14 @@ int dwbc_hqp_get(dwbc_hqp *h, int level, int field, void *host_out, size_t bytes
 int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h);
 /* torque of the LQP answer, tau = A[6:] qddot + J_C^T[6:] f_c + B_[6:] (tests/sp_test/jacc_compare.cpp:416-418): B x m */
 int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau);
+/* RobotData::CalcSingleTaskTorqueWithJACC_QP(ts_[level], init) src/dwbc.cpp:3772-3945: the joint-acceleration QP of one task level
+ * (variables qddot, tau, f_c and the task slack; dynamics, contact and the earlier levels' tasks as equalities; contact cones,
+ * |qddot_joint| <= 10, |tau| <= 200) from the batch's last solve (dump on, one contact state per batch), solved exactly on `h`
+ * (which is rebuilt for it).  Levels must be solved in order: level i uses f*_qp of the levels before it.  Results per instance:
+ * ts_[level].acc_qp_ (ndof), torque_qp_ (m), contact_qp_ (12, zero padded), f_star_qp_ (6, zero padded), status (i32) */
+enum dwbc_jacc_field { DWBC_JACC_ACC = 0, DWBC_JACC_TORQUE = 1, DWBC_JACC_CONTACT = 2, DWBC_JACC_FSTAR_QP = 3, DWBC_JACC_STATUS = 4 };
+int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level);
+int dwbc_batch_get_jacc(dwbc_batch *b, int level, int field, void *host_out, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,9 @@ SYMBOLS = [
     ("dwbc_hqp_get", _i, [_vp, _i, _i, _vp, C.c_size_t]),
     ("dwbc_batch_configure_lqp", _i, [_vp, _vp]),
     ("dwbc_batch_lqp_torque", _i, [_vp, _vp, _vp]),
+    ("dwbc_batch_solve_jacc", _i, [_vp, _vp, _i]),
+    ("dwbc_batch_get_jacc", _i, [_vp, _i, _i, _vp, C.c_size_t]),
+    ("dwbc_batch_host_ptr", _vp, [_vp, _i]),
 ]
 
 _lib = None

@@ -193,6 +193,15 @@ class Batch:
         _check(self._L.dwbc_batch_set_fstar(self._h, int(level), f.ctypes.data))
 
     def set_fstar_all(self, fstar):
+        if fstar.flags["C_CONTIGUOUS"] and fstar.dtype == np.float64 and fstar.ctypes.data == (self._L.dwbc_batch_host_ptr(self._h, FIELDS["in_fstar"]) or 0):
+            # the mirror itself (host_view("in_fstar")), filled in place: mark every level as new without copying
+            off = 0
+            for lv in range(64):
+                if off >= fstar.shape[1]:
+                    break
+                _check(self._L.dwbc_batch_set_fstar(self._h, lv, C.c_void_p(fstar.ctypes.data + 8 * off)))
+                off += self.task_dof(lv)
+            return
         off = 0
         lv = 0
         while off < fstar.shape[1]:
@@ -200,6 +209,18 @@ class Batch:
             self.set_fstar(lv, fstar[:, off : off + t])
             off += t
             lv += 1
+
+    def host_view(self, field):
+        """numpy view of the page-locked host mirror of an input field ("in_q", "in_contact", "in_fstar"): fill it in place and pass
+        it to set_state / set_contact / set_fstar_all -- the host-side copy is skipped, the upload is one asynchronous transfer"""
+        shape = (self.B,) + tuple(self._SHAPES[field](self))
+        dt = np.uint8 if field == "in_contact" else np.float64
+        p = self._L.dwbc_batch_host_ptr(self._h, FIELDS[field])
+        if not p:
+            raise DwbcError(f"{field} has no host mirror yet (add the contacts / tasks first)")
+        n = int(np.prod(shape))
+        buf = (C.c_uint8 * n if dt == np.uint8 else C.c_double * n).from_address(p)
+        return np.frombuffer(buf, dtype=dt).reshape(shape)
 
     # ---- zero-copy device plumbing (torch owns the memory / stream)
     def bind_tensor(self, field, tensor):

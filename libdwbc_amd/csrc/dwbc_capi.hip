@@ -177,6 +177,8 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     if (b->own_status) hipFree(b->d_status);
     hipFree(b->d_diag);
     hipFree(b->d_total);
+    for (int l = 0; l < kMaxLevels; l++) hipFree(b->d_jacc[l]);
+    hipFree(b->d_jacc_status);
     hipFree(b->d_dump);
     hipFree(b->d_body);
     hipFree(b->d_topo);
@@ -305,7 +307,7 @@ int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, con
     (void)qddot;  // the reference hands it to RBDL's UpdateKinematicsCustom only; nothing on this path reads accelerations
     if (!q) return fail("q is NULL");
     if (!b->own_q) return fail("q is bound to a device buffer");
-    memcpy(b->h_q.data(), q, b->h_q.size() * sizeof(double));
+    if (q != b->h_q.data()) memcpy(b->h_q.data(), q, b->h_q.size() * sizeof(double));  // (dwbc_batch_host_ptr: already in place)
     b->dirty_q = true;
     if (qdot) {  // B_, link velocities (dump record) and the on-device task reference need it; the torque path does not
         b->h_qdot.assign(qdot, qdot + (size_t)b->B * b->n);
@@ -325,7 +327,7 @@ int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags) {
         for (int c = 0; c < ncn; c++) on += flags[(size_t)i * ncn + c] ? 1 : 0;
         if (on > kMaxActiveContacts) return fail("more than 2 simultaneously active contacts in one instance: not supported by the device path");
     }
-    memcpy(b->h_flags.data(), flags, b->h_flags.size());
+    if (flags != b->h_flags.data()) memcpy(b->h_flags.data(), flags, b->h_flags.size());
     b->dirty_flags = true;
     return 1;
 }
@@ -334,9 +336,19 @@ int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar) {
     if (level < 0 || level >= b->su.n_levels) return fail("ERROR : task space size overflow");  // src/dwbc.cpp:668-671
     if (b->d_fstar && !b->own_fstar) return fail("f* is bound to a device buffer");
     const int t = b->su.t_dof[level], off = b->su.fstar_off[level], F = b->su.fstar_total;
-    for (int i = 0; i < b->B; i++) memcpy(b->h_fstar.data() + (size_t)i * F + off, fstar + (size_t)i * t, sizeof(double) * t);
+    if (fstar != b->h_fstar.data() + off)  // (a caller that filled the mirror in place passes host_ptr + off)
+        for (int i = 0; i < b->B; i++) memcpy(b->h_fstar.data() + (size_t)i * F + off, fstar + (size_t)i * t, sizeof(double) * t);
     b->dirty_fstar = true;
     return 1;
+}
+
+void *dwbc_batch_host_ptr(dwbc_batch *b, int field) {
+    switch (field) {
+        case DWBC_IN_Q: return b->h_q.empty() ? nullptr : b->h_q.data();
+        case DWBC_IN_CONTACT: return b->h_flags.empty() ? nullptr : b->h_flags.data();
+        case DWBC_IN_FSTAR: return b->h_fstar.empty() ? nullptr : b->h_fstar.data();
+        default: return nullptr;
+    }
 }
 
 int dwbc_batch_bind_device(dwbc_batch *b, int field, void *p) {

@@ -85,6 +85,8 @@ struct dwbc_batch {
     dwbc::PinnedVec<unsigned char> h_flags;
     dwbc::PinnedVec<unsigned char> h_stage;  // read-back staging of dwbc_batch_get
     double *d_total = nullptr;                // B x m scratch of the DWBC_TAU_* getters
+    double *d_jacc[dwbc::kMaxLevels] = {nullptr, nullptr, nullptr, nullptr};  // per task level: B x jacc_rec_size (dwbc_batch_solve_jacc)
+    int *d_jacc_status = nullptr;             // kMaxLevels x B
     bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
     bool attr_set = false;
     int n_cu = 0;

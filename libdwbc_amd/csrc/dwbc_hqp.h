@@ -32,13 +32,15 @@ namespace dwbc {
 
 constexpr int kHqpMaxLevels = 8;
 constexpr int kHqpMaxQ = 32;   // working-set capacity of one level's QP
-constexpr int kHqpMaxEq = 16;  // equality rows of one level
+constexpr int kHqpMaxEq = 32;  // equality rows of one level
 constexpr int kHqpMaxVar = 64; // y size (acceleration + torque + contact)
 
 struct HqpDesc {
     int nv, n_levels, solve_first, max_iter;
     double eps, tol;
     int m[kHqpMaxLevels], e[kHqpMaxLevels], has_cost[kHqpMaxLevels];
+    int exact[kHqpMaxLevels];  // 1: the level's equalities hold EXACTLY (least-norm step in the current null space), its inequalities are
+                               // only declared (slack 0) and become hard rows of the later levels -- the JACC formulation's constraints
     // offsets (doubles) inside one instance's record
     int oA[kHqpMaxLevels], oa[kHqpMaxLevels], oB[kHqpMaxLevels], ob[kHqpMaxLevels], oH[kHqpMaxLevels];
     int oy[kHqpMaxLevels], ov[kHqpMaxLevels], ow[kHqpMaxLevels];
@@ -120,7 +122,7 @@ inline void hqp_layout(HqpDesc &d, bool share_cost) {
 // Z: nv x nv row-major (HBM), view = columns [off, nv).  Bm: e x nv.  Returns the rank.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>
-DWBC_DEV int hqp_null_update(Thr th, double *Z, int nv, int off, const double *Bm, int e, double *Bz, double *vh) {
+DWBC_DEV int hqp_null_update(Thr th, double *Z, int nv, int off, const double *Bm, int e, double *Bz, double *vh, double *rr = nullptr) {
     const int k = nv - off;
     if (e == 0 || k == 0) return 0;
     HQP_SYNC();
@@ -145,8 +147,10 @@ DWBC_DEV int hqp_null_update(Thr th, double *Z, int nv, int off, const double *B
             if (n2 > best) { best = n2; jp = i; }
         }
         HQP_SYNC();
-        if (jp != s)
+        if (jp != s) {
             for (int c = th.tid; c < k; c += NT) { const double t = Bz[s * k + c]; Bz[s * k + c] = Bz[jp * k + c]; Bz[jp * k + c] = t; }
+            if (rr && th.tid == 0) { const double t = rr[s]; rr[s] = rr[jp]; rr[jp] = t; }  // the right-hand side follows its row
+        }
         HQP_SYNC();
         const double nx = sqrt(best > 0.0 ? best : 0.0);
         if (nx == 0.0) break;
@@ -175,6 +179,8 @@ DWBC_DEV int hqp_null_update(Thr th, double *Z, int nv, int off, const double *B
                 for (int c = s; c < k; c++) Z[i * nv + off + c] -= dd * vh[c];
             }
         }
+        HQP_SYNC();
+        if (th.tid == 0) Bz[s * k + s] = alpha;  // Bz now holds L of (B Z) = Pi L Q^T: rows 0..s final in columns 0..s
         const double ap = fabs(alpha);
         if (s == 0) maxp = ap;
         // pivots come out in non-increasing magnitude: the first one below the threshold ends the rank
@@ -228,9 +234,54 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
     int off = 0;
     for (int lv = 0; lv < d.n_levels; lv++) {
         const int k = nv - off;
-        const bool solve = lv > 0 || d.solve_first;
+        const bool solve = (lv > 0 || d.solve_first) && !d.exact[lv];
         const double *Bm = rec + d.oB[lv], *bv = rec + d.ob[lv];
         const int e = d.e[lv], mo = d.m[lv];
+        if (d.exact[lv]) {
+            // ---- hard equalities: y = y_prev + Z_new[:, :rank] w with L w = -Pi^T (B y_prev + b), (B Z) = Pi L Q^T from the same
+            //      Householder steps that extend the null-space chain (Z_new = Z Q); the level's own inequality rows keep slack 0
+            double *yp = L + l.yp, *rr = L + l.rr, *u = L + l.u, *Bz = L + l.Bz;
+            HQP_SYNC();
+            for (int i = th.tid; i < nv; i += NT) yp[i] = lv > 0 ? rec[d.oy[lv - 1] + i] : 0.0;
+            HQP_SYNC();
+            for (int i = th.tid; i < e; i += NT) {
+                double acc = bv[i];
+                for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * yp[c];
+                rr[i] = acc;
+            }
+            HQP_SYNC();
+            const int rank = hqp_null_update<NT>(th, Z, nv, off, Bm, e, Bz, L + l.zu, rr);
+            int status = 1;
+            if (th.tid == 0)
+                for (int i = 0; i < rank; i++) {  // forward substitution, serial (rank <= 32)
+                    double acc = -rr[i];
+                    for (int c = 0; c < i; c++) acc -= Bz[i * k + c] * u[c];
+                    u[i] = acc / Bz[i * k + i];
+                }
+            HQP_SYNC();
+            // rows beyond the rank must be consistent with the rows kept: |residual| of the dependent rows
+            for (int i = rank; i < e; i++) {
+                double acc = rr[i];
+                for (int c = 0; c < rank; c++) acc += Bz[i * k + c] * u[c];
+                if (fabs(acc) > 1.0e-6) status = 0;
+            }
+            for (int i = th.tid; i < nv; i += NT) {
+                double acc = yp[i];
+                for (int c = 0; c < rank; c++) acc += Z[i * nv + off + c] * u[c];
+                rec[d.oy[lv] + i] = acc;
+            }
+            for (int i = th.tid; i < mo; i += NT) rec[d.ov[lv] + i] = 0.0;
+            HQP_SYNC();
+            for (int i = th.tid; i < e; i += NT) {
+                double acc = bv[i];
+                for (int c = 0; c < nv; c++) acc += Bm[i * nv + c] * rec[d.oy[lv] + c];
+                rec[d.ow[lv] + i] = acc;
+            }
+            off += rank;
+            if (th.tid == 0) { stat[HQS_STATUS + lv] = status; stat[HQS_ITER + lv] = 0; stat[HQS_NULL + lv] = nv - off; }
+            HQP_SYNC();
+            continue;
+        }
         if (solve) {
             double *Hinv = L + l.Hinv, *T = L + l.T, *Mm = L + l.Mm, *Lc = L + l.Lc, *Bz = L + l.Bz;
             double *u = L + l.u, *g = L + l.g, *zu = L + l.zu, *tp = L + l.tp, *yp = L + l.yp, *cp = L + l.cp, *hy = L + l.hy;
@@ -378,8 +429,9 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
                     HQP_SYNC();
                     double nz = psoft ? 1.0 : 0.0, sp = dd[p] + (psoft ? vv[p] : 0.0), full = psoft ? 1.0 : 0.0;
                     for (int c = 0; c < k; c++) { nz += cp[c] * zu[c]; sp -= cp[c] * u[c]; full += cp[c] * tp[c]; }
-                    // independent of the working set only if a fraction > 1e-9 of its H^-1-norm survives the projection
-                    const double t2 = nz > 1.0e-9 * full ? -sp / nz : 1.0e300;
+                    // independent of the working set only if more than round-off (1e-12) of its H^-1-norm survives the projection
+                    if (!(sp < 0.0)) break;  // a dual-only step (a row left the working set) has already satisfied it
+                    const double t2 = nz > 1.0e-12 * full ? -sp / nz : 1.0e300;  // HQP_DEP
                     double t1 = 1.0e300;
                     int drop = -1;
                     for (int a = 0; a < nw; a++)
@@ -592,6 +644,123 @@ DWBC_DEV void lqp_configure_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d
         hqp_normalize_rows<NT>(th, Bt, bt, t, nv);
     }
     HQP_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RobotData::CalcSingleTaskTorqueWithJACC_QP (src/dwbc.cpp:3772-3945) for task level `level`, on the same solver.  The reference
+// poses ONE QP over x = [qddot (n); tau (m); f_c (cd); s (t)]:
+//     min 1/2 qddot^T A qddot + 50 |s|^2
+//     s.t. A qddot - S^T tau + J_C^T f_c = -G ;  J_C qddot = 0 ;  J_i qddot = f*_i + f*_qp,i (i < level) ;  J qddot - s = f*
+//          C f_c <= 0 (getContactConstraintMatrix) ;  |qddot_joint| <= 10 ;  |tau| <= 200
+// tau and s are eliminated (tau = (A qddot + J_C^T f_c + G)[6:], s = J qddot - f*), leaving y = [qddot; f_c] with
+//   level 0 (exact): floating-base rows of the dynamics, contact constraint, earlier tasks; its inequality rows (cones,
+//                    acceleration bounds, torque bounds through the dynamics) are hard rows of level 1
+//   level 1:         1/2 |10 (J qddot - f*)|^2 + 1/2 qddot^T A qddot
+// Level-0 rows are normalised (scaling a hard row changes nothing); level 1 keeps the reference's weights.
+// fqp_prev: per earlier level i, B x JACC_REC records ([acc n | torque m | contact 12 | f*_qp 6]) of its JACC solve.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kJaccAccLim = 10, kJaccTauLim = 200;
+struct JaccPrev { const double *rec[kMaxLevels]; };
+__host__ __device__ inline int jacc_rec_size(int n) { return n + (n - 6) + 12 + kMaxTaskDof; }
+
+template <int NT>
+DWBC_DEV void jacc_configure_instance(Thr th, const LqpCfg &cfg, int level, const JaccPrev &prev, const HqpDesc &d, const HqpIO &io, const double *dump,
+                                      const io_t *fstar, int inst) {
+    const int n = cfg.n, m = n - 6, cd = cfg.cd, nv = d.nv, ncc = 10 * cfg.nc;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *JC = dm + dl.J_C, *G = dm + dl.G, *Rc = dm + dl.contact_rot;
+    const io_t *fs = fstar + (size_t)inst * cfg.fstar_total;
+    double *rec = io.rec + (size_t)inst * d.rec;
+    for (int idx = th.tid; idx < d.rec; idx += NT) rec[idx] = 0.0;
+    HQP_SYNC();
+    double *A0 = rec + d.oA[0], *a0 = rec + d.oa[0], *B0 = rec + d.oB[0], *b0 = rec + d.ob[0];
+    // ---- level-0 inequality rows: cones | +-qddot_joint <= 10 | +-tau <= 200
+    for (int idx = th.tid; idx < ncc * 6; idx += NT) {
+        const int rr_ = idx / 6, j = idx - rr_ * 6, a = rr_ / 10, r10 = rr_ - 10 * a;
+        real_t w[6] = {0, 0, 0, 0, 0, 0};
+        const double *R = Rc + a * 9;
+        const int h = j / 3, x = j % 3;
+        for (int y = 0; y < 3; y++) w[3 * h + y] = (real_t)R[x * 3 + y];
+        A0[rr_ * nv + n + 6 * a + j] = -(double)cone_row(r10, (real_t)cfg.lx[a], (real_t)cfg.ly[a], (real_t)cfg.mu[a], (real_t)cfg.muz[a], w);
+    }
+    for (int i = th.tid; i < m; i += NT) {
+        A0[(ncc + i) * nv + 6 + i] = 1.0;
+        A0[(ncc + m + i) * nv + 6 + i] = -1.0;
+        a0[ncc + i] = -(double)kJaccAccLim;
+        a0[ncc + m + i] = -(double)kJaccAccLim;
+        a0[ncc + 2 * m + i] = -(double)kJaccTauLim + G[6 + i];
+        a0[ncc + 3 * m + i] = -(double)kJaccTauLim - G[6 + i];
+    }
+    for (int idx = th.tid; idx < m * nv; idx += NT) {
+        const int i = idx / nv, c = idx - i * nv;
+        const double v = c < n ? A[(6 + i) * n + c] : JC[(c - n) * n + 6 + i];
+        A0[(ncc + 2 * m + i) * nv + c] = v;
+        A0[(ncc + 3 * m + i) * nv + c] = -v;
+    }
+    // ---- level-0 equalities: floating-base dynamics | contact | earlier tasks
+    for (int idx = th.tid; idx < 6 * nv; idx += NT) {
+        const int i = idx / nv, c = idx - i * nv;
+        B0[idx] = c < n ? A[i * n + c] : JC[(c - n) * n + i];
+    }
+    for (int i = th.tid; i < 6; i += NT) b0[i] = G[i];
+    for (int idx = th.tid; idx < cd * n; idx += NT) B0[(6 + idx / n) * nv + idx % n] = JC[idx];
+    int row = 6 + cd;
+    for (int i = 0; i < level; i++) {
+        const int t = cfg.t_dof[i];
+        const double *Jt = dm + dl.J_task + i * kMaxTaskDof * n;
+        const double *pr = prev.rec[i] + (size_t)inst * jacc_rec_size(n) + n + m + 12;
+        for (int idx = th.tid; idx < t * n; idx += NT) B0[(row + idx / n) * nv + idx % n] = Jt[idx];
+        for (int j = th.tid; j < t; j += NT) b0[row + j] = -((double)fs[cfg.fstar_off[i] + j] + pr[j]);
+        row += t;
+    }
+    HQP_SYNC();
+    hqp_normalize_rows<NT>(th, A0, a0, d.m[0], nv);
+    hqp_normalize_rows<NT>(th, B0, b0, d.e[0], nv);
+    // ---- level 1: 10 (J qddot - f*), cost A on qddot
+    {
+        const int t = cfg.t_dof[level];
+        double *B1 = rec + d.oB[1], *b1 = rec + d.ob[1], *Hc = rec + d.oH[1];
+        const double *Jt = dm + dl.J_task + level * kMaxTaskDof * n;
+        for (int idx = th.tid; idx < t * n; idx += NT) B1[(idx / n) * nv + idx % n] = 10.0 * Jt[idx];
+        for (int j = th.tid; j < t; j += NT) b1[j] = -10.0 * (double)fs[cfg.fstar_off[level] + j];
+        for (int idx = th.tid; idx < n * n; idx += NT) Hc[(idx / n) * nv + idx % n] = A[idx];
+    }
+    HQP_SYNC();
+}
+
+// acc_qp_, torque_qp_, contact_qp_, f_star_qp_ (src/dwbc.cpp:3932-3942) from the level-1 answer
+template <int NT>
+DWBC_DEV void jacc_extract_instance(Thr th, const LqpCfg &cfg, int level, const HqpDesc &d, const HqpIO &io, const double *dump, const io_t *fstar,
+                                    double *out, int *status, int inst) {
+    const int n = cfg.n, m = n - 6, cd = cfg.cd;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *JC = dm + dl.J_C, *G = dm + dl.G;
+    const double *y = io.rec + (size_t)inst * d.rec + d.oy[1];
+    const int *st = io.stat + (size_t)inst * HQS_COUNT;
+    const int ok = st[HQS_STATUS + 0] && st[HQS_STATUS + 1];
+    double *o = out + (size_t)inst * jacc_rec_size(n);
+    const io_t *fs = fstar + (size_t)inst * cfg.fstar_total;
+    for (int i = th.tid; i < n; i += NT) o[i] = ok ? y[i] : 0.0;
+    for (int i = th.tid; i < m; i += NT) {
+        double acc = G[6 + i];
+        for (int c = 0; c < n; c++) acc += A[(6 + i) * n + c] * y[c];
+        for (int c = 0; c < cd; c++) acc += JC[c * n + 6 + i] * y[n + c];
+        o[n + i] = ok ? acc : 0.0;
+    }
+    for (int i = th.tid; i < 12; i += NT) o[n + m + i] = (ok && i < cd) ? y[n + i] : 0.0;
+    const int t = cfg.t_dof[level];
+    const double *Jt = dm + dl.J_task + level * kMaxTaskDof * n;
+    for (int j = th.tid; j < kMaxTaskDof; j += NT) {
+        double acc = 0.0;
+        if (j < t && ok) {
+            acc = -(double)fs[cfg.fstar_off[level] + j];
+            for (int c = 0; c < n; c++) acc += Jt[j * n + c] * y[c];
+        }
+        o[n + m + 12 + j] = acc;
+    }
+    if (th.tid == 0) status[inst] = ok;
 }
 
 // tau = A[6:] qddot + J_C^T[6:] f_c + B_[6:]   (tests/sp_test/jacc_compare.cpp:416-418) from the last level's answer

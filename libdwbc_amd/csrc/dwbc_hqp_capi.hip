@@ -41,6 +41,19 @@ __global__ __launch_bounds__(kNT) void dwbc_lqp_torque_kernel(const LqpCfg cfg, 
     lqp_torque_instance<kNT>(Thr{(int)threadIdx.x}, cfg, d, io, dump, tau, inst);
 }
 
+__global__ __launch_bounds__(kNT) void dwbc_jacc_configure_kernel(const LqpCfg cfg, int level, const JaccPrev prev, const HqpDesc d, const HqpIO io, const double *dump,
+                                                                  const double *fstar) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    jacc_configure_instance<kNT>(Thr{(int)threadIdx.x}, cfg, level, prev, d, io, dump, fstar, inst);
+}
+__global__ __launch_bounds__(kNT) void dwbc_jacc_extract_kernel(const LqpCfg cfg, int level, const HqpDesc d, const HqpIO io, const double *dump, const double *fstar,
+                                                                double *out, int *status) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    jacc_extract_instance<kNT>(Thr{(int)threadIdx.x}, cfg, level, d, io, dump, fstar, out, status, inst);
+}
+
 struct dwbc_hqp {
     int B = 0, device = 0;
     int acc = 0, torque = 0, contact = 0;
@@ -144,7 +157,7 @@ int dwbc_hqp_add_hierarchy(dwbc_hqp *h, int ineq, int eq) {
     if (h->d.n_levels >= kHqpMaxLevels) { fail("HQP: too many levels"); return -1; }
     if (ineq < 0 || eq < 0 || eq > kHqpMaxEq) { fail("HQP: bad constraint sizes (equalities per level <= " + std::to_string(kHqpMaxEq) + ")"); return -1; }
     const int lv = h->d.n_levels++;
-    h->d.m[lv] = ineq; h->d.e[lv] = eq; h->d.has_cost[lv] = 0;
+    h->d.m[lv] = ineq; h->d.e[lv] = eq; h->d.has_cost[lv] = 0; h->d.exact[lv] = 0;
     h->stage.emplace_back();
     return lv;
 }
@@ -277,29 +290,30 @@ int dwbc_hqp_get(dwbc_hqp *h, int level, int field, void *out, size_t bytes) {
     return 1;
 }
 
-int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
+// what both formulations read from a solved cycle: checks + the contact / task description of the (uniform) batch
+static int formulation_cfg(dwbc_batch *b, dwbc_hqp *h, LqpCfg &cfg) {
     if (!b || !h) return fail("NULL handle");
-    if (b->dtype != DWBC_F64) return fail("LQP: fp64 batches only");
-    if (h->B != b->B || h->device != b->device) return fail("LQP: the HQP object must have the batch's size and device");
-    if (!b->dump_on || !b->d_dump) return fail("LQP: needs dwbc_batch_enable_dump(b, 1) and a solved cycle (A_, A_inv_, J_C, B_, J_task come from it)");
-    if (b->last_reduced) return fail("LQP: run the full-model cycle first (ConfigureLQP_R is not built)");
-    if (b->su.n_custom > 0 || b->su.has_com_task) return fail("LQP: link task levels only");
-    if (b->h_flags.empty() || (b->d_flags && !b->own_flags)) return fail("LQP: contact flags must be set through dwbc_batch_set_contact (the host checks that they are uniform)");
+    if (b->dtype != DWBC_F64) return fail("LQP / JACC: fp64 batches only");
+    if (h->B != b->B || h->device != b->device) return fail("LQP / JACC: the HQP object must have the batch's size and device");
+    if (!b->dump_on || !b->d_dump) return fail("LQP / JACC: needs dwbc_batch_enable_dump(b, 1) and a solved cycle (A_, A_inv_, J_C, B_, J_task come from it)");
+    if (b->last_reduced) return fail("LQP / JACC: run the full-model cycle first (the reduced variants are not built)");
+    if (b->su.n_custom > 0 || b->su.has_com_task) return fail("LQP / JACC: link task levels only");
+    if (b->h_flags.empty() || (b->d_flags && !b->own_flags)) return fail("LQP / JACC: contact flags must be set through dwbc_batch_set_contact (the host checks that they are uniform)");
     const int ncn = b->su.n_contacts;
-    LqpCfg cfg{};
+    cfg = LqpCfg{};
     cfg.n = b->n;
     cfg.nc = 0;
     for (int c = 0; c < ncn; c++)
         if (b->h_flags[c]) {
-            if (cfg.nc >= kMaxActiveContacts) return fail("LQP: more than 2 active contacts");
+            if (cfg.nc >= kMaxActiveContacts) return fail("LQP / JACC: more than 2 active contacts");
             cfg.act[cfg.nc] = c;
             cfg.lx[cfg.nc] = b->su.c_lx[c]; cfg.ly[cfg.nc] = b->su.c_ly[c]; cfg.mu[cfg.nc] = b->su.c_mu[c]; cfg.muz[cfg.nc] = b->su.c_muz[c];
             cfg.nc++;
         }
     for (int i = 1; i < b->B; i++)
         if (memcmp(&b->h_flags[(size_t)i * ncn], &b->h_flags[0], ncn) != 0)
-            return fail("LQP: every instance of the batch must be in the same contact state (the level sizes depend on it)");
-    if (cfg.nc < 1) return fail("LQP: no active contact");
+            return fail("LQP / JACC: every instance of the batch must be in the same contact state (the level sizes depend on it)");
+    if (cfg.nc < 1) return fail("LQP / JACC: no active contact");
     cfg.cd = 6 * cfg.nc;
     cfg.n_tasks = b->su.n_levels;
     for (int i = 0; i < b->su.n_levels; i++) { cfg.t_dof[i] = b->su.t_dof[i]; cfg.fstar_off[i] = b->su.fstar_off[i]; }
@@ -307,6 +321,12 @@ int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
     cfg.oBn = b->d_qdot ? b->dl.B : b->dl.G;  // B_(q, qdot = 0) = G_
     cfg.tlim = 200.0;  // `tlim`, src/dwbc.cpp:4360
     cfg.alim = 5.0;    // `alim`, src/dwbc.cpp:4398
+    return 1;
+}
+
+int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
+    LqpCfg cfg{};
+    if (!formulation_cfg(b, h, cfg)) return 0;
     if (h->acc != b->n || h->torque != 0 || h->contact != cfg.cd)
         return fail("LQP: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(b->n) + ", 0, " + std::to_string(cfg.cd) + ")");
     if (2 + cfg.n_tasks > kHqpMaxLevels) return fail("LQP: too many task levels");
@@ -347,6 +367,71 @@ int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau) {
     if (e == hipSuccess) e = hipMemcpy(tau, d_tau, (size_t)b->B * b->m * 8, hipMemcpyDeviceToHost);
     hipFree(d_tau);
     if (e != hipSuccess) return fail(std::string("lqp torque: ") + hipGetErrorString(e));
+    return 1;
+}
+
+int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level) {
+    LqpCfg cfg{};
+    if (!formulation_cfg(b, h, cfg)) return 0;
+    if (level < 0 || level >= cfg.n_tasks) return fail("JACC: bad task level");
+    if (h->acc != b->n || h->torque != 0 || h->contact != cfg.cd)
+        return fail("JACC: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(b->n) + ", 0, " + std::to_string(cfg.cd) + ")");
+    int e0 = 6 + cfg.cd;
+    for (int i = 0; i < level; i++) {
+        if (!b->d_jacc[i]) return fail("JACC: solve the levels in order (level " + std::to_string(i) + " has no result yet)");
+        e0 += cfg.t_dof[i];
+    }
+    if (e0 > kHqpMaxEq) return fail("JACC: too many equality rows");
+    // two levels: the exact constraint level and the task level
+    dwbc_hqp_clear(h);
+    if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 4 * b->m, e0) < 0) return 0;
+    if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[level]) < 0) return 0;
+    h->d.exact[0] = 1;
+    h->d.exact[1] = 0;
+    h->d.has_cost[1] = 1;
+    if (!layout_and_alloc(h)) return 0;
+    h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+    h->stream = b->stream;
+    HIP_OK(hipSetDevice(b->device));
+    const size_t rs = (size_t)jacc_rec_size(b->n);
+    if (!b->d_jacc[level]) HIP_OK(hipMalloc(&b->d_jacc[level], (size_t)b->B * rs * 8));
+    if (!b->d_jacc_status) {
+        HIP_OK(hipMalloc(&b->d_jacc_status, (size_t)kMaxLevels * b->B * sizeof(int)));
+        HIP_OK(hipMemset(b->d_jacc_status, 0, (size_t)kMaxLevels * b->B * sizeof(int)));
+    }
+    JaccPrev prev{};
+    for (int i = 0; i < level; i++) prev.rec[i] = b->d_jacc[i];
+    hipLaunchKernelGGL(dwbc_jacc_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, prev, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar);
+    HIP_OK(hipGetLastError());
+    if (!launch_solve(h, 0)) return 0;
+    hipLaunchKernelGGL(dwbc_jacc_extract_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar,
+                       b->d_jacc[level], b->d_jacc_status + (size_t)level * b->B);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_batch_get_jacc(dwbc_batch *b, int level, int field, void *out, size_t bytes) {
+    if (level < 0 || level >= kMaxLevels || !b->d_jacc[level]) return fail("JACC: no result for this level");
+    const int n = b->n, m = b->m;
+    const size_t rs = (size_t)jacc_rec_size(n);
+    int off = 0, len = 0;
+    switch (field) {
+        case DWBC_JACC_ACC: off = 0; len = n; break;
+        case DWBC_JACC_TORQUE: off = n; len = m; break;
+        case DWBC_JACC_CONTACT: off = n + m; len = 12; break;
+        case DWBC_JACC_FSTAR_QP: off = n + m + 12; len = kMaxTaskDof; break;
+        case DWBC_JACC_STATUS:
+            if (bytes != (size_t)b->B * sizeof(int)) return fail("JACC: size mismatch");
+            HIP_OK(hipSetDevice(b->device));
+            HIP_OK(hipStreamSynchronize(b->stream));
+            HIP_OK(hipMemcpy(out, b->d_jacc_status + (size_t)level * b->B, bytes, hipMemcpyDeviceToHost));
+            return 1;
+        default: return fail("JACC: unknown field");
+    }
+    if (bytes != (size_t)b->B * len * 8) return fail("JACC: size mismatch");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipStreamSynchronize(b->stream));
+    HIP_OK(hipMemcpy2D(out, (size_t)len * 8, b->d_jacc[level] + off, rs * 8, (size_t)len * 8, b->B, hipMemcpyDeviceToHost));
     return 1;
 }
 

@@ -94,6 +94,26 @@ class HQP:
         _check(self._L.dwbc_batch_lqp_torque(wbc._h, self._h, tau.ctypes.data))
         return tau
 
+    # ---- RobotData::CalcSingleTaskTorqueWithJACC_QP(ts_[level], init) (src/dwbc.cpp:3772-3945); levels in order 0, 1, ...
+    def solve_jacc(self, wbc, level):
+        _check(self._L.dwbc_batch_solve_jacc(wbc._h, self._h, int(level)))
+        self._sizes = []
+
+    @staticmethod
+    def jacc_result(wbc, level):
+        """dict(acc_qp, torque_qp, contact_qp, f_star_qp, status) of ts_[level] after solve_jacc"""
+        L = _lib.load()
+        B = wbc.B
+        out = {}
+        for name, fid, width in (("acc_qp", 0, wbc.n), ("torque_qp", 1, wbc.m), ("contact_qp", 2, 12), ("f_star_qp", 3, 6)):
+            a = np.zeros((B, width))
+            _check(L.dwbc_batch_get_jacc(wbc._h, int(level), fid, a.ctypes.data, a.nbytes))
+            out[name] = a
+        st = np.zeros(B, np.int32)
+        _check(L.dwbc_batch_get_jacc(wbc._h, int(level), 4, st.ctypes.data, st.nbytes))
+        out["status"] = st
+        return out
+
     def num_levels(self):
         return self._L.dwbc_hqp_num_levels(self._h)
 

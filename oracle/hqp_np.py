@@ -35,7 +35,7 @@ HQP_EPS = 1.0e-6       # Tikhonov weight of the canon (conditioning 1e6: answers
 HQP_TOL = 1.0e-6       # constraint violation tolerance of the active-set solver (rows are normalised by the configurator)
 HQP_TOL_DEP = 1.0e-5   # a violated row that depends on the working set and has nothing to trade against is let go below this
 HQP_MAX_ITER = 400
-HQP_DEP = 1.0e-9      # linear-dependence threshold of the active-set step (relative curvature)
+HQP_DEP = 1.0e-12      # linear-dependence threshold of the active-set step (relative curvature)
 COD_EPS = np.finfo(float).eps
 
 
@@ -152,6 +152,9 @@ def solve_level_qp(H, g, As, ds, Ah, dh, max_iter=HQP_MAX_ITER, tol=HQP_TOL):
         # curvature along the violated normal: n_p . z
         nz = cp @ zu - (zv[p] if soft[p] else 0.0)
         slack_p = d[p] - cp @ u + (v[p] if soft[p] else 0.0)  # negative
+        if not slack_p < 0.0:  # a dual-only step (a row left the working set) has already satisfied it
+            p = -1
+            continue
         # the violated normal counts as independent of the working set only if a fraction > HQP_DEP of its H^-1-norm survives
         # the projection (a dependent row gives a dual-only step: some active row leaves first)
         full = cp @ Hinv(cp) + (1.0 if soft[p] else 0.0)
@@ -204,6 +207,7 @@ class HQP_Hierarch:
         self.null_space_size_ = 0
         self.qp_iter_ = 0
         self.qp_status_ = 1
+        self.exact_ = False  # JACC: equalities hold exactly (least-norm step), inequalities only declared (slack 0)
 
     def updateConstraintMatrix(self, A, a, B, b):  # dwbc_hqp.cpp:530-547
         if self.ineq_const_size_ > 0:
@@ -244,8 +248,22 @@ class HQP:
             hs[i].Z_ = hs[i - 1].Z_ @ nullB
             hs[i].null_space_size_ = hs[i].Z_.shape[1]
 
+    def _solve_exact(self, i, y_prev, Z):
+        h = self.hqp_hs_[i]
+        BZ = h.B_ @ Z
+        r = h.B_ @ y_prev + h.b_
+        u = -np.linalg.lstsq(BZ, r, rcond=1e-12)[0]  # least-norm solution of B Z u = -r
+        h.y_ans_ = y_prev + Z @ u
+        h.v_ans_ = np.zeros(h.ineq_const_size_)
+        h.w_ans_ = h.B_ @ h.y_ans_ + h.b_
+        h.qp_iter_, h.working_set_ = 0, []
+        h.qp_status_ = int(np.abs(h.w_ans_).max() < 1e-6) if h.eq_const_size_ else 1
+        return h.qp_status_
+
     def _solve(self, i, y_prev, Z):
         h = self.hqp_hs_[i]
+        if h.exact_:
+            return self._solve_exact(i, y_prev, Z)
         Bz = h.B_ @ Z
         r = h.B_ @ y_prev + h.b_
         k = Z.shape[1]
@@ -278,8 +296,10 @@ class HQP:
         prev = self.hqp_hs_[level - 1]
         return self._solve(level, prev.y_ans_, prev.Z_)
 
-    def solveSequential(self):  # dwbc_hqp.cpp:397-403
+    def solveSequential(self):  # dwbc_hqp.cpp:397-403 (an exact level 0 is evaluated here as well)
         ok = 1
+        if self.hqp_hs_[0].exact_:
+            ok &= self.solvefirst()
         for i in range(1, len(self.hqp_hs_)):
             ok &= self.solveSequentialSingle(i)
         return ok
@@ -356,3 +376,64 @@ def lqp_torque(c, B_nle, y):
     """tests/sp_test/jacc_compare.cpp:416-418: tau = A[6:] qdd + J_C^T[6:] f_c + B_[6:]"""
     n = c.n
     return c.A[6:] @ y[:n] + c.J_C.T[6:] @ y[n:] + B_nle[6:]
+
+
+# ----------------------------------------------------------------------------------------------
+# RobotData::CalcSingleTaskTorqueWithJACC_QP (src/dwbc.cpp:3772-3945) on the same machinery: tau and the task slack are
+# eliminated from the reference's single QP over [qddot; tau; f_c; s] (see libdwbc_amd/csrc/dwbc_hqp.h, jacc_configure_instance)
+# ----------------------------------------------------------------------------------------------
+JACC_ACC_LIM, JACC_TAU_LIM = 10.0, 200.0
+
+
+def jacc_qp(c, level, J_tasks, f_stars, fqp_prev):
+    """c: dwbc_np.Cycle after update_kinematics / set_contact.  Returns (ok, acc_qp, torque_qp, contact_qp, f_star_qp, hqp)"""
+    n, m, cd = c.n, c.m, c.cdof
+    nv = n + cd
+    JCt = c.J_C.T
+    ncc = 10 * len(c.act_contacts)
+    hq = HQP()
+    hq.initialize(n, 0, cd)
+    e0 = 6 + cd + sum(J_tasks[i].shape[0] for i in range(level))
+    hq.addHierarchy(ncc + 4 * m, e0)
+    A = np.zeros((ncc + 4 * m, nv))
+    a = np.zeros(ncc + 4 * m)
+    A[:ncc, n:] = -c.cone_matrix()
+    A[ncc : ncc + m, 6 : 6 + m] = np.eye(m)
+    A[ncc + m : ncc + 2 * m, 6 : 6 + m] = -np.eye(m)
+    a[ncc : ncc + 2 * m] = -JACC_ACC_LIM
+    D = np.hstack([c.A[6:], JCt[6:]])
+    A[ncc + 2 * m : ncc + 3 * m] = D
+    A[ncc + 3 * m :] = -D
+    a[ncc + 2 * m : ncc + 3 * m] = -JACC_TAU_LIM + c.G[6:]
+    a[ncc + 3 * m :] = -JACC_TAU_LIM - c.G[6:]
+    B = np.zeros((e0, nv))
+    b = np.zeros(e0)
+    B[:6, :n] = c.A[:6]
+    B[:6, n:] = JCt[:6]
+    b[:6] = c.G[:6]
+    B[6 : 6 + cd, :n] = c.J_C
+    row = 6 + cd
+    for i in range(level):
+        t = J_tasks[i].shape[0]
+        B[row : row + t, :n] = J_tasks[i]
+        b[row : row + t] = -(np.asarray(f_stars[i]) + np.asarray(fqp_prev[i]))
+        row += t
+    h0 = hq.hqp_hs_[0]
+    h0.updateConstraintMatrix(A, a, B, b)
+    h0.normalizeConstraintMatrix()
+    h0.exact_ = True
+    J = J_tasks[level]
+    t = J.shape[0]
+    hq.addHierarchy(0, t)
+    B1 = np.zeros((t, nv))
+    B1[:, :n] = 10.0 * J
+    H = np.zeros((nv, nv))
+    H[:n, :n] = c.A
+    h1 = hq.hqp_hs_[1]
+    h1.updateConstraintMatrix(None, None, B1, -10.0 * np.asarray(f_stars[level], float))
+    h1.updateCostMatrix(H, np.zeros(nv))
+    hq.prepare()
+    ok = hq.solveSequential()
+    y = h1.y_ans_
+    tau = c.A[6:] @ y[:n] + JCt[6:] @ y[n:] + c.G[6:]
+    return ok, y[:n].copy(), tau, y[n:].copy(), J @ y[:n] - np.asarray(f_stars[level], float), hq

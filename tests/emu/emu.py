@@ -155,6 +155,27 @@ class EmuHQP:
         self.L.emu_lqp_torque(self.h, emu.h, nc, 1 if use_B else 0, dump.ctypes.data, tau.ctypes.data)
         return tau
 
+    def set_exact(self, level, on=True):
+        self.L.emu_hqp_set_exact.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.emu_hqp_set_exact(self.h, level, 1 if on else 0)
+
+    def jacc_solve(self, emu, act, level, dump, fstar, prev):
+        """CalcSingleTaskTorqueWithJACC_QP for one level; prev = list of (B, rec) arrays of the earlier levels"""
+        L = self.L
+        L.emu_jacc_rec.restype = C.c_int
+        L.emu_jacc_rec.argtypes = [C.c_void_p]
+        L.emu_jacc_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rs = L.emu_jacc_rec(emu.h)
+        act = np.asarray(act, np.int32)
+        dump = np.ascontiguousarray(dump, np.float64)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        prev = [np.ascontiguousarray(p, np.float64) for p in prev]
+        ptrs = (C.c_void_p * max(1, len(prev)))(*[p.ctypes.data for p in prev])
+        out = np.zeros((self.B, rs))
+        st = np.zeros(self.B, np.int32)
+        L.emu_jacc_solve(self.h, emu.h, len(act), act.ctypes.data, level, dump.ctypes.data, fstar.ctypes.data, ptrs, out.ctypes.data, st.ctypes.data)
+        return out, st
+
     def status(self, level):
         return self.stat[:, level]
 

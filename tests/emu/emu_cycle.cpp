@@ -178,6 +178,7 @@ struct EmuHqp {
     std::vector<int> stat;
     int B;
 };
+void emu_hqp_set_exact(EmuHqp *h, int level, int on);
 EmuHqp *emu_hqp_create(int B, int nv, int n_levels, const int *m, const int *e, const int *has_cost, int share_cost, int solve_first) {
     auto *h = new EmuHqp();
     h->d = HqpDesc{};
@@ -204,6 +205,33 @@ void emu_hqp_solve(EmuHqp *h) {
     HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
     std::vector<double> lds(h->d.lds + 16);
     for (int b = 0; b < h->B; b++) hqp_instance<1>(Thr{0}, h->d, io, b, lds.data());
+}
+void emu_hqp_set_exact(EmuHqp *h, int level, int on) { h->d.exact[level] = on; }
+static LqpCfg emu_cfg(EmuCtx *c, int nc, const int *act) {
+    LqpCfg cfg{};
+    cfg.n = c->model.ndof; cfg.nc = nc; cfg.cd = 6 * nc; cfg.n_tasks = c->su.n_levels;
+    const DumpLayout dl = DumpLayout::make(cfg.n);
+    for (int i = 0; i < c->su.n_levels; i++) { cfg.t_dof[i] = c->su.t_dof[i]; cfg.fstar_off[i] = c->su.fstar_off[i]; }
+    cfg.fstar_total = c->su.fstar_total;
+    for (int a = 0; a < nc; a++) { cfg.act[a] = act[a]; cfg.lx[a] = c->su.c_lx[act[a]]; cfg.ly[a] = c->su.c_ly[act[a]]; cfg.mu[a] = c->su.c_mu[act[a]]; cfg.muz[a] = c->su.c_muz[act[a]]; }
+    cfg.oBn = dl.G;
+    cfg.tlim = 200.0; cfg.alim = 5.0;
+    return cfg;
+}
+int emu_jacc_rec(EmuCtx *c) { return jacc_rec_size(c->model.ndof); }
+// CalcSingleTaskTorqueWithJACC_QP for one level: h must have been created with the two levels (152 | e0, 0 | t) and exact level 0;
+// prev: level x (B x jacc_rec) results of the earlier levels; out: B x jacc_rec
+void emu_jacc_solve(EmuHqp *h, EmuCtx *c, int nc, const int *act, int level, const double *dump, const double *fstar, const double *const *prev, double *out, int *status) {
+    const LqpCfg cfg = emu_cfg(c, nc, act);
+    JaccPrev pv{};
+    for (int i = 0; i < level; i++) pv.rec[i] = prev[i];
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    std::vector<double> lds(h->d.lds + 16);
+    for (int b = 0; b < h->B; b++) {
+        jacc_configure_instance<1>(Thr{0}, cfg, level, pv, h->d, io, dump, fstar, b);
+        hqp_instance<1>(Thr{0}, h->d, io, b, lds.data());
+        jacc_extract_instance<1>(Thr{0}, cfg, level, h->d, io, dump, fstar, out, status, b);
+    }
 }
 // RobotData::ConfigureLQP from a dump record (B x DumpLayout::total doubles) + f*, then the cascade and the LQP torque
 void emu_lqp_configure(EmuHqp *h, EmuCtx *c, int nc, const int *act, int use_B, const double *dump, const double *fstar) {

@@ -302,3 +302,165 @@ def test_gpu_lqp_batch_matches_oracle_and_keeps_its_constraints():
     hq.configure_lqp(wbc)
     hq.solveSequential(init=False)
     assert np.abs(hq.y_ans(3) - y).max() > 1e-6 and (hq.get(3, Hq.STATUS) == 1).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------ JACC
+def _jacc_oracle(q, fstar, tasks=cases.TASKS_2LEVEL):
+    """CalcSingleTaskTorqueWithJACC_QP level after level (reference tests/sp_test/dof_comparison_jacc.cpp:296-300)"""
+    m = cases.tocabi_model()
+    c = Dn.Cycle(m)
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    for lv, links in enumerate(tasks):
+        for mode, link, pt in links:
+            c.add_task(lv, mode, link, pt)
+    c.update_kinematics(q)
+    c.set_contact([1, 1])
+    Js = [c.task_jacobian(i) for i in range(len(tasks))]
+    fs, off = [], 0
+    for J in Js:
+        fs.append(np.asarray(fstar[off : off + J.shape[0]], float))
+        off += J.shape[0]
+    res, fqp = [], []
+    for lv in range(len(tasks)):
+        ok, acc, tau, f, s, hq = H.jacc_qp(c, lv, Js, fs, fqp)
+        fqp.append(s)
+        res.append(dict(ok=ok, acc=acc, tau=tau, f=f, s=s, hq=hq))
+    return c, Js, fs, res
+
+
+def _check_jacc_kkt(c, Js, fs, res, lv, tol=1e-6):
+    """KKT of the reference's ORIGINAL QP over x = [qddot; tau; f_c; s] (src/dwbc.cpp:3806-3905) at the answer -- the elimination of
+    tau and s used by the solver is checked by going back to the form the reference writes down."""
+    n, m, cd = c.n, c.m, c.cdof
+    r = res[lv]
+    J, t = Js[lv], Js[lv].shape[0]
+    x = np.concatenate([r["acc"], r["tau"], r["f"], r["s"]])
+    nx = x.size
+    Hq = np.zeros((nx, nx))
+    Hq[:n, :n] = c.A
+    Hq[n + m + cd :, n + m + cd :] = 100.0 * np.eye(t)
+    ST = np.zeros((n, m))
+    ST[6:] = np.eye(m)
+    rows, rhs = [np.hstack([c.A, -ST, c.J_C.T, np.zeros((n, t))])], [-c.G]
+    rows.append(np.hstack([c.J_C, np.zeros((cd, m + cd + t))])); rhs.append(np.zeros(cd))
+    for i in range(lv):
+        ti = Js[i].shape[0]
+        rows.append(np.hstack([Js[i], np.zeros((ti, m + cd + t))])); rhs.append(fs[i] + res[i]["s"])
+    rows.append(np.hstack([J, np.zeros((t, m + cd)), -np.eye(t)])); rhs.append(fs[lv])
+    Aeq, beq = np.vstack(rows), np.concatenate(rhs)
+    assert np.abs(Aeq @ x - beq).max() < 1e-8
+    # inequalities G x <= h: cones, joint acceleration bounds, torque bounds
+    Cm = -c.cone_matrix()
+    G = [np.hstack([np.zeros((Cm.shape[0], n + m)), Cm, np.zeros((Cm.shape[0], t))])]
+    hh = [np.zeros(Cm.shape[0])]
+    Ia = np.zeros((m, nx)); Ia[:, 6:n] = np.eye(m)
+    It = np.zeros((m, nx)); It[:, n : n + m] = np.eye(m)
+    for Mx, lim in ((Ia, H.JACC_ACC_LIM), (It, H.JACC_TAU_LIM)):
+        G += [Mx, -Mx]; hh += [np.full(m, lim), np.full(m, lim)]
+    G, hh = np.vstack(G), np.concatenate(hh)
+    sl = hh - G @ x
+    assert sl.min() > -1e-6
+    act = sl < 1e-6
+    # stationarity: H x + Aeq^T nu + G_act^T lam = 0 for SOME lam >= 0 (the active rows are degenerate: bounds, cones and the
+    # equalities are linearly dependent at these points, so existence is checked by non-negative least squares; the Tikhonov term of
+    # the canon enters at 1e-6 |y|)
+    from scipy.optimize import nnls
+
+    Mk = np.hstack([Aeq.T, -Aeq.T, G[act].T])
+    sol, rn = nnls(Mk, -Hq @ x, maxiter=20000)
+    assert rn < 1e-3 * (1 + np.abs(Hq @ x).max()), rn
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_oracle_jacc_qp_satisfies_the_reference_qp(case):
+    q = np.array(cases.Q_CASE[case])
+    fs = np.array(list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1]))
+    c, Js, fsl, res = _jacc_oracle(q, fs)
+    for lv in range(2):
+        assert res[lv]["ok"] == 1
+        _check_jacc_kkt(c, Js, fsl, res, lv)
+    # the second level keeps the first level's task at f* + f*_qp (hard equality)
+    assert np.abs(Js[0] @ res[1]["acc"] - fsl[0] - res[0]["s"]).max() < 1e-9
+
+
+def test_emulated_jacc_matches_oracle():
+    from tests.emu.emu import Emu, EmuHQP
+
+    B = 4
+    q, fl, fs = cases.synth_batch(B, seed=29, yaw=True)
+    q[0], q[1] = cases.Q_CASE[1], cases.Q_CASE[2]
+    for i, case in enumerate((1, 2)):
+        fs[i] = list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, dump=True)
+    prev = []
+    outs = []
+    for lv, (e0, t) in enumerate(((18, 6), (24, 3))):
+        eh = EmuHQP(B, 51, [152, 0], [e0, t], [0, 1])
+        eh.set_exact(0)
+        out, st = eh.jacc_solve(e, [0, 1], lv, r["dump"], fs, prev)
+        assert st.all()
+        prev.append(out)
+        outs.append(out)
+    for b in range(B):
+        c, Js, fsl, res = _jacc_oracle(q[b], fs[b])
+        for lv in range(2):
+            o = outs[lv][b]
+            rel = lambda a, ref: (np.abs(a - ref) / (1 + np.abs(ref))).max()
+            # rows within the 1e-6 row tolerance of their bound may or may not enter the working set: answers agree to that scale
+            # ... and the internal-wrench part of f_c has no cost in this formulation: it is set by the Tikhonov weight alone and
+            # moves by 1e-5 relative with such a choice, tau = A qddot + J_C^T f_c + G with it
+            assert rel(o[:39], res[lv]["acc"]) < 1e-5 and rel(o[39:72], res[lv]["tau"]) < 1e-3
+            assert rel(o[72:84], res[lv]["f"]) < 1e-3
+            t = Js[lv].shape[0]
+            assert rel(o[84 : 84 + t], res[lv]["s"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_jacc_matches_oracle_and_keeps_its_constraints():
+    """CalcSingleTaskTorqueWithJACC_QP for both task levels of a batch on the device, against the restatement on a subset and
+    through the constraints of the formulation on the whole batch."""
+    import libdwbc_amd as D
+
+    B, NS = 256, 6
+    q, fl, fs = cases.synth_batch(B, seed=33)
+    q[0], q[1] = cases.Q_CASE[1], cases.Q_CASE[2]
+    for i, case in enumerate((1, 2)):
+        fs[i] = list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])
+    fs[NS:] *= 2.0  # beyond the compared subset: many rows active (vertex solutions), checked through the constraints only
+    wbc = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+    for c in cases.CONTACTS_2:
+        wbc.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+    wbc.set_torque_limit(np.array(cases.TAU_LIM))
+    wbc.enable_dump(True)
+    wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
+    wbc.solve()
+    hq = D.HQP.for_lqp(wbc, 12)
+    with pytest.raises(D.DwbcError, match="in order"):
+        hq.solve_jacc(wbc, 1)
+    out = []
+    for lv in range(2):
+        hq.solve_jacc(wbc, lv)
+        out.append(D.HQP.jacc_result(wbc, lv))
+        assert out[lv]["status"].all()
+    rel = lambda a, ref: (np.abs(a - ref) / (1 + np.abs(ref))).max()
+    for b in range(NS):
+        c, Js, fsl, res = _jacc_oracle(q[b], fs[b])
+        for lv in range(2):
+            assert rel(out[lv]["acc_qp"][b], res[lv]["acc"]) < 1e-5
+            assert rel(out[lv]["torque_qp"][b], res[lv]["tau"]) < 1e-3  # (see test_emulated_jacc_matches_oracle)
+            assert rel(out[lv]["contact_qp"][b], res[lv]["f"]) < 1e-3
+            t = Js[lv].shape[0]
+            assert rel(out[lv]["f_star_qp"][b][:t], res[lv]["s"]) < 1e-5
+    A, JC, G = wbc.get("A"), wbc.get("J_C"), wbc.get("G")
+    for lv in range(2):
+        acc, tau, f = out[lv]["acc_qp"], out[lv]["torque_qp"], out[lv]["contact_qp"]
+        dyn = np.einsum("bij,bj->bi", A, acc) + np.einsum("bji,bj->bi", JC, f) + G
+        dyn[:, 6:] -= tau
+        assert np.abs(dyn).max() < 1e-7                                   # rigid-body dynamics
+        assert np.abs(np.einsum("bij,bj->bi", JC, acc)).max() < 1e-8      # contact constraint
+        assert np.abs(acc[:, 6:]).max() < 10 + 1e-6 and np.abs(tau).max() < 200 + 1e-6
+        assert (f[:, 2] < 1e-4).all() and (f[:, 8] < 1e-4).all()  # unilateral (implied by the cone rows, each held to 1e-6 on the normalised row)
