@@ -333,3 +333,40 @@ def test_tree_sweep_matches_dense_sweep_and_mass_matrix_pattern():
     assert (rt["status"] == rd["status"]).all()
     ok = rt["status"] == 1
     assert np.abs(rt["tau"][ok] - rd["tau"][ok]).max() < 1e-7
+
+
+@pytest.mark.parametrize("hqp", [True, False])
+def test_redistribution_torque_is_an_internal_wrench(hqp):
+    """First-principles check of the two reference-unpinned redistributions (the QP branch and the closed-form two-foot split,
+    src/dwbc.cpp:1372-1619, src/wbd.cpp:273-404), independent of either restatement: torque_contact_ = NwJw c lies in null(W), so
+      * it produces no joint acceleration under the contact constraint:  W torque_contact_ = 0  (the tasks are untouched), and
+      * the contact wrench it adds, J_C_INV_T[:, 6:] torque_contact_, is an INTERNAL wrench: zero resultant force, zero resultant
+        moment about any point -- it only moves load between the two feet.
+    W, J_C_INV_T and the contact points come from the golden-pinned algebra of the numpy Cycle, tau from the kernel emulation."""
+    from oracle.dwbc_np import Cycle
+
+    B = 6
+    q, fl, fs = cases.synth_batch(B, seed=91, yaw=True)
+    fs = fs * 2.0  # make the redistribution do something
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM if hqp else None)
+    r = e.run(q, fl, fs, hqp=hqp)
+    moved = 0
+    for b in range(B):
+        if not r["status"][b]:
+            continue
+        c = Cycle(cases.tocabi_model())
+        for cc in cases.CONTACTS_2:
+            c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        c.update_kinematics(q[b])
+        c.set_contact([1, 1])
+        c.calc_contact_constraint()
+        tc = r["tau"][b, 2]
+        scale = 1.0 + np.abs(tc).max()
+        assert np.abs(c.W @ tc).max() < 1e-9 * scale * np.abs(c.W).max()
+        dF = c.J_C_INV_T[:, 6:] @ tc
+        p = [c.p[cc["link"]] + c.R[cc["link"]] @ np.asarray(cc["point"]) for cc in cases.CONTACTS_2]
+        assert np.abs(dF[0:3] + dF[6:9]).max() < 1e-7 * scale
+        mom = dF[3:6] + dF[9:12] + np.cross(p[1] - p[0], dF[6:9])
+        assert np.abs(mom).max() < 1e-7 * scale
+        moved += int(np.abs(tc).max() > 1e-6)
+    assert moved > 0
