@@ -1,13 +1,11 @@
-// dwbc_cycle.h -- the fused per-instance OSF/HQP control cycle as block-cooperative device code.
+// dwbc_cycle.h -- helpers shared by the fused cycle kernels (dwbc_cycle2.h: full model, dwbc_reduced.h: reduced dynamics,
+// dwbc_nohqp.h, dwbc_hqp.h): synchronisation and stage-stamp macros, QP constants, small dense products on LDS operands, the
+// contact-cone rows, point Jacobians, the centroidal outputs and the assembly of the QP rows into lanes.
 //
-// One workgroup (NT threads, normally one 64-lane wavefront) owns ONE robot instance for the whole
-// cycle; every intermediate (M, M^-1, J_C, Lambda_c, J̄_c^T, A^-1 N_c, W^+, NwJw, per-level J_kt/Lambda_t,
-// the QP rows and the active-set state) lives in LDS and never touches HBM.  Only q, flags, f* are read
-// and tau / wrench / status written (about 1.4 KB per instance).
-//
-// The code is written NT-generic with strided loops and explicit barriers so that the SAME source can be
-// compiled by g++ with NT = 1 (tests/emu) to check the arithmetic on a machine without a GPU.  That build
-// is a test harness only; the product library has no CPU path.
+// One workgroup (one 64-lane wavefront) owns ONE robot instance for the whole cycle; the kernels that include this keep every
+// intermediate in registers / LDS.  The helpers are NT-generic (strided loops, explicit synchronisation points) so that the SAME
+// source compiles with g++ for one host thread (tests/emu) to check the arithmetic without a GPU.  That build is a test
+// harness only; the product library has no CPU path.
 //
 // Reference functions restated here (file:line in the reference tree):
 //   RobotData::UpdateKinematics          src/dwbc.cpp:279-371   (FK, A_, A_inv_, G_)
@@ -19,7 +17,7 @@
 //   RobotData::CalcSingleTaskTorqueWithQP src/dwbc.cpp:941-1127 (QP rows)  + cascade :818-873
 //   RobotData::CalcContactRedistribute   src/dwbc.cpp:1372-1568
 //   CalculateContactForce                src/wbd.cpp:268-271
-//   CQuadraticProgram::SolveQPoases      src/qp_wrapper.cpp:192-380 -> replaced by qp_solve() below
+//   CQuadraticProgram::SolveQPoases      src/qp_wrapper.cpp:192-380 -> replaced by qp_solve_wave() (dwbc_qp_wave.h)
 #pragma once
 #include <math.h>
 

@@ -1,13 +1,12 @@
 // dwbc_cycle2.h -- fused OSF/HQP control cycle, register-resident version (one wavefront = one robot instance).
 //
-// Same arithmetic as cycle_instance() in dwbc_cycle.h (kept as the readable NT-generic reference kernel), but the
-// three big symmetric matrices never live in LDS: lane j holds column j of A -> A^-1 -> A^-1 N_c (39 doubles) and later
+// The three big symmetric matrices never live in LDS: lane j holds column j of A -> A^-1 -> A^-1 N_c (39 doubles) and later
 // column j of W^+ (33 doubles) in registers.  Every large product is then "own column . uniform operand": one FMA per
 // term, operands fetched with broadcast LDS reads (no bank conflicts, no index arithmetic), and the inverses are
-// symmetric sweeps whose pivot column is published through 39 doubles of LDS.  LDS holds only the thin matrices
-// (J_C, J̄_c^T, task blocks, QP inputs): ~47 KB per instance => 3 instances per CU (v1: 78 KB => 2).
+// symmetric sweeps whose pivot column is broadcast with v_readlane (A^-1, tree-sparse) or through LDS (W^+).  LDS holds only
+// the thin matrices (J_C, J̄_c^T, task blocks, QP inputs): 31.6 KB per instance for two task levels => 5 instances per CU.
 //
-// Reference functions restated: see the table at the top of dwbc_cycle.h.
+// Reference functions restated: see the table at the top of dwbc_cycle.h (shared helpers, QP row assembly).
 #pragma once
 #include <type_traits>
 
@@ -99,45 +98,10 @@ struct Lds2 {
     static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
 };
 
-// symmetric Gauss-Jordan sweep on a column-per-lane register matrix: on exit s / dg hold the inverse (see
-// spd_inverse_wave in dwbc_cycle.h for the derivation of the single-FMA update).  Returns 0 on a non-positive pivot.
-template <int NN>
-DWBC_WDEV int sweep_inverse_regs(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
-    DWBC_LANE_DECL;
-    int ok = 1;
-    for (int k = 0; k < NN; k++) {
-        real_t d = BCAST(dg, k);
-        if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
-        const real_t rp = fast_rcp(d);
-        // lane k publishes its column; its own slot k gets c_k - 1 (LDS ops of one wave execute in order, so the second
-        // store to colbuf[k] needs no barrier; reads of the previous step were consumed by the FMAs that precede these stores)
-        LANES {
-            if (lane == k) {
-#pragma unroll
-                for (int i = 0; i < NN; i++) colbuf[i] = LV(s)[i];
-                colbuf[k] = d - real_t(1.0);
-            }
-        }
-        DWBC_SYNC();
-        LANES {
-            const real_t cj = colbuf[lane < NN ? lane : 0];
-            const real_t h = (lane == k) ? (real_t(1.0) - rp) : cj * rp;
-#pragma unroll
-            for (int i = 0; i < NN; i++) LV(s)[i] -= colbuf[i] * h;
-            LV(dg) = (lane == k) ? -rp : LV(dg) - cj * h;
-        }
-        DWBC_SYNC();
-    }
-    LANES {
-        DWBC_LANE_OPAQUE(le);  // own compares: the prologue's masks are not kept alive (spilled) across the sweep
-#pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le) ? -LV(dg) : -LV(s)[i];
-        LV(dg) = -LV(dg);
-    }
-    DWBC_SYNC();
-    return ok;
-}
-
+// Symmetric Gauss-Jordan sweep on a column-per-lane register matrix.  Per pivot k every lane j applies
+//     S[i][j] -= (c_i - delta_ik) * h_j,   c = column k,   h_j = c_j / d  (h_k = 1 - 1/d)
+// to its own column: one FMA per element, the row-k and column-k special cases of the sweep fall out of the modified multiplier;
+// on exit -S is the inverse.  Same arithmetic role as Eigen's llt().solve(I) (reference src/dwbc.cpp:307).
 // The sweep without LDS.  The pivot column is broadcast with v_readlane (lane select = the uniform pivot index k).  Each
 // lane's own element of the pivot ROW, S[k][lane] = S[lane][k], would be a dynamic register index; the pivot loop is
 // therefore unrolled by 8 with k = 8*kb + kr: kr is static, and the element is picked from the five candidates

@@ -50,13 +50,6 @@ struct QpResult {
 
 #define DWBC_QP_INF (dwbc::kF32 ? dwbc::real_t(1.0e30) : dwbc::real_t(1.0e300))
 
-// uniform 12-array element with a uniform dynamic index
-DWBC_WDEV real_t upick12(const real_t *a, int idx) {
-    real_t v = real_t(0.0);
-#pragma unroll
-    for (int i = 0; i < kQpN; i++) v = (i == idx) ? a[i] : v;
-    return v;
-}
 
 
 // scaled-variable iterate -> position order of the final solve: contact variables first (the heavy rows of the

@@ -130,11 +130,6 @@ DWBC_WDEV real_t pick12(const real_t *a, int lane) {
     for (int i = 0; i < 12; i++) v = (lane == i) ? a[i] : v;
     return v;
 }
-// arr[q] = v for a per-lane 12-array with a (uniform or per-lane) dynamic index
-DWBC_WDEV void setidx12(real_t *arr, int q, real_t v) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) arr[i] = (i == q) ? v : arr[i];
-}
 
 }  // namespace dwbc
 
