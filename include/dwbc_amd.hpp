@@ -88,6 +88,7 @@ struct TaskSpaceView {  // the fields of DWBC::TaskSpace callers read (include/d
     int task_dof_ = 0;
     std::vector<TaskLinkView> task_link_;
     Vec f_star_, f_star_qp_, contact_qp_;
+    Vec acc_qp_, torque_qp_, gacc_qp_;  // CalcSingleTaskTorqueWithJACC_QP* results (include/dwbc_task.h)
     Mat J_task_, Lambda_task_, J_kt_;
     int qp_error = 0;
 };
@@ -178,6 +179,10 @@ class RobotData {
     Mat CMM_, J_com_, com_inertia_;  // include/dwbc.h:114, link_.back().jac_com_, link_.back().inertia
     Vec3 com_pos;                    // include/dwbc.h:141
     Vec P_C, cf_redis_qp_;
+    // reduced (centroidal) model, filled after ReducedDynamicsCalculate() (include/dwbc.h:150-200; src/dwbc.cpp:2818-2988)
+    unsigned int vc_dof = 0, nc_dof = 0, co_dof = 0, reduced_model_dof_ = 0, reduced_system_dof_ = 0;
+    Mat A_R, A_R_inv, J_I_nc_, J_I_nc_inv_T;
+    Vec G_R;
     bool torque_limit_set_ = false;
     std::vector<TaskSpaceView> ts_;
     std::vector<ContactView> cc_;
@@ -355,10 +360,64 @@ class RobotData {
         return 1;
     }
     // torque of the LQP answer, as the reference's harness forms it (tests/sp_test/jacc_compare.cpp:416-418)
-    Vec LQPTorque(HQP &hqp) {
-        Vec tau(model_dof_, 0.0);
+    Vec LQPTorque(HQP &hqp) {  // model_dof_ torques; after ConfigureLQP_R: reduced_model_dof_ (chain torques | centroidal wrench)
+        Vec tau(hqp.acceleration_size_ - 6, 0.0);
         if (!dwbc_batch_lqp_torque(batch_, hqp.handle(), tau.data())) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;
         return tau;
+    }
+    // CalcSingleTaskTorqueWithJACC_QP(ts_[level], init) (src/dwbc.cpp:3772-3945); levels in order
+    int CalcSingleTaskTorqueWithJACC_QP(int level, bool = true) {
+        if (!refresh()) return 0;
+        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(system_dof_, 0, contact_dof_);
+        if (!dwbc_batch_solve_jacc(batch_, jacc_h_.handle(), level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        return fetch_jacc(level, system_dof_);
+    }
+    // ---- the same formulations on the reduced model (dwbc.h; src/dwbc.cpp:4455-4760): after ReducedDynamicsCalculate().
+    //      hqp: y = [qddot_R (reduced_system_dof_); f_c];  hqp_nc: y = accelerations of the nc_dof non-contact joints
+    int ConfigureLQP_R(HQP &hqp, bool = true) {
+        reduced_on();
+        if (!refresh()) return 0;
+        if (!hqp.handle() || hqp.acceleration_size_ != (int)reduced_system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(reduced_system_dof_, 0, contact_dof_);
+        if (!dwbc_batch_configure_lqp_r(batch_, hqp.handle())) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        hqp.fetch();
+        return 1;
+    }
+    int CalcControlTorqueLQP_R(HQP &hqp, bool init = true) { return CalcControlTorqueLQP(hqp, init); }
+    // q_acc of the reference (= hqp_r.hqp_hs_.back().y_ans_.head(acceleration_size_)) is read on the device from hqp_r itself;
+    // nc_level: the 6-D task level on a non-contact link (the reference reads ts_[1])
+    int ConfigureLQP_R_NC(HQP &hqp_nc, HQP &hqp_r, int nc_level = 1, bool = true) {
+        if (!hqp_nc.handle() || hqp_nc.acceleration_size_ != (int)nc_dof) hqp_nc.initialize(nc_dof, 0, 0);
+        if (!dwbc_batch_configure_lqp_r_nc(batch_, hqp_nc.handle(), hqp_r.handle(), nc_level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        hqp_nc.fetch();
+        return 1;
+    }
+    int CalcControlTorqueLQP_R_NC(HQP &hqp_nc, bool init = true) {
+        hqp_nc.solvefirst(init);
+        hqp_nc.solveSequential(init);
+        for (auto &hh : hqp_nc.hqp_hs_) if (!hh.qp_status_) return 0;
+        return 1;
+    }
+    // CalcSingleTaskTorqueWithJACC_QP_R(ts_[level]) / _R_NC(ts_[level], acc_qp_ of the reduced level src_level): results in
+    // ts_[level].acc_qp_ / torque_qp_ / contact_qp_ (gacc_qp_ for _R_NC) / f_star_qp_
+    int CalcSingleTaskTorqueWithJACC_QP_R(int level, bool = true) {
+        reduced_on();
+        if (!refresh()) return 0;
+        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)reduced_system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(reduced_system_dof_, 0, contact_dof_);
+        if (!dwbc_batch_solve_jacc_r(batch_, jacc_h_.handle(), level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        return fetch_jacc(level, reduced_system_dof_);
+    }
+    int CalcSingleTaskTorqueWithJACC_QP_R_NC(int level, int src_level, bool = true) {
+        if (!jacc_nc_h_.handle() || jacc_nc_h_.acceleration_size_ != (int)nc_dof) jacc_nc_h_.initialize(nc_dof, 0, 0);
+        if (!dwbc_batch_solve_jacc_r_nc(batch_, jacc_nc_h_.handle(), level, src_level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
+        TaskSpaceView &t = ts_[level];
+        t.acc_qp_.assign(nc_dof, 0.0); t.torque_qp_.assign(nc_dof, 0.0); t.gacc_qp_.assign(6, 0.0); t.f_star_qp_.assign(6, 0.0);
+        int st = 0;
+        dwbc_batch_get_jacc_nc(batch_, DWBC_JACC_ACC, t.acc_qp_.data(), nc_dof * 8);
+        dwbc_batch_get_jacc_nc(batch_, DWBC_JACC_TORQUE, t.torque_qp_.data(), nc_dof * 8);
+        dwbc_batch_get_jacc_nc(batch_, DWBC_JACC_CONTACT, t.gacc_qp_.data(), 6 * 8);
+        dwbc_batch_get_jacc_nc(batch_, DWBC_JACC_FSTAR_QP, t.f_star_qp_.data(), 6 * 8);
+        dwbc_batch_get_jacc_nc(batch_, DWBC_JACC_STATUS, &st, sizeof(int));
+        return st;
     }
     int CalcAll(bool init = true) { int ok = refresh(init); torque_contact_ = tau_contact_final_; return ok && diag_[0] && diag_[1] && diag_[2]; }
     template <class V, class = decltype(std::declval<const V &>().data()), class = decltype(std::declval<const V &>().rows())>
@@ -378,6 +437,19 @@ class RobotData {
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
     bool dirty_ = true, redistributed_ = false, reduced_ = false, hqp_ = true, contact_ok_ = true;
+    HQP jacc_h_, jacc_nc_h_;  // solver objects of the JACC entry points
+    int fetch_jacc(int level, int n) {
+        TaskSpaceView &t = ts_[level];
+        t.acc_qp_.assign(n, 0.0); t.torque_qp_.assign(n - 6, 0.0); t.contact_qp_.assign(12, 0.0); t.f_star_qp_.assign(6, 0.0);
+        int st = 0;
+        dwbc_batch_get_jacc(batch_, level, DWBC_JACC_ACC, t.acc_qp_.data(), n * 8);
+        dwbc_batch_get_jacc(batch_, level, DWBC_JACC_TORQUE, t.torque_qp_.data(), (n - 6) * 8);
+        dwbc_batch_get_jacc(batch_, level, DWBC_JACC_CONTACT, t.contact_qp_.data(), 12 * 8);
+        dwbc_batch_get_jacc(batch_, level, DWBC_JACC_FSTAR_QP, t.f_star_qp_.data(), 6 * 8);
+        dwbc_batch_get_jacc(batch_, level, DWBC_JACC_STATUS, &st, sizeof(int));
+        t.contact_qp_.resize(contact_dof_); t.f_star_qp_.resize(t.task_dof_);
+        return st;
+    }
     double sent_time_ = -1.0e300;
     void reduced_on() { if (!reduced_) { reduced_ = true; dirty_ = true; } }
     int diag_[96] = {0};
@@ -457,7 +529,24 @@ class RobotData {
             for (int c = 0; c < cd; c++) s -= J_C(c, i) * J_C_INV_T(c, j);
             N_C(i, j) = s;
         }
-        if (reduced_) { dirty_ = false; return 1; }  // W_inv, NwJw, ts_[i].J_kt_ ... are full-model fields
+        if (reduced_) {  // W_inv, NwJw, ts_[i].J_kt_ ... are full-model fields; the reduced model's own:
+            int vc = 0, ncd = 0;
+            if (dwbc_batch_reduced_dims(batch_, &vc, &ncd)) {
+                vc_dof = vc; nc_dof = ncd; co_dof = vc - 6; reduced_model_dof_ = vc; reduced_system_dof_ = vc + 6;
+                const int rs = vc + 6;
+                A_R = fetch(DWBC_A_R, rs, rs, 24); A_R_inv = fetch(DWBC_A_R_INV, rs, rs, 24);
+                { Mat gr = fetch(DWBC_G_R, 1, rs, 24); G_R = gr.d; }
+                J_I_nc_ = fetch(DWBC_J_I_NC, 6, ncd, n - 12); J_I_nc_inv_T = fetch(DWBC_J_I_NC_INV_T, 6, ncd, n - 12);
+                const Mat jt = fetch(DWBC_J_TASK, 4 * 6, n);
+                for (size_t l = 0; l < ts_.size(); l++) {
+                    ts_[l].J_task_ = Mat(ts_[l].task_dof_, n);
+                    for (int r = 0; r < ts_[l].task_dof_; r++)
+                        for (int c = 0; c < n; c++) ts_[l].J_task_(r, c) = jt((int)l * 6 + r, c);
+                }
+            }
+            dirty_ = false;
+            return 1;
+        }
         Mat fq = fetch(DWBC_FSTAR_QP, 4, 6), cq = fetch(DWBC_CONTACT_QP, 4, 6), cr = fetch(DWBC_CF_REDIS, 1, 6);
         cf_redis_qp_.assign(cr.d.begin(), cr.d.begin() + k);
         std::vector<double> jt(dwbc_batch_field_bytes(batch_, DWBC_J_TASK) / 8), lt(dwbc_batch_field_bytes(batch_, DWBC_LAMBDA_TASK) / 8), jk(dwbc_batch_field_bytes(batch_, DWBC_J_KT) / 8);

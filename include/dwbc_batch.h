@@ -92,7 +92,13 @@ enum dwbc_field {
     DWBC_LINK_W = 56,     /* (48, 3)  link_[i].w                (src/link.cpp:88) */
     DWBC_CONTACT_POS = 57,/* (2, 3)   cc_[i].xc_pos of the active contacts (src/contact_constraint.cpp:53) */
     DWBC_CONTACT_ROT = 58,/* (2, 9)   cc_[i].rotm */
-    DWBC_ZMP = 59         /* (3, 3)   getZMP(getContactForce(tau_total)) then cc_[i].zmp_pos (src/dwbc.cpp:898-939) */
+    DWBC_ZMP = 59,        /* (3, 3)   getZMP(getContactForce(tau_total)) then cc_[i].zmp_pos (src/dwbc.cpp:898-939) */
+    /* the reduced (centroidal) model, after a solve with DWBC_SOLVE_REDUCED (src/dwbc.cpp:2932-2988); RS = vc_dof + 6 <= 24 */
+    DWBC_A_R = 60,        /* (24, 24) A_R, row stride 24, zero beyond RS */
+    DWBC_A_R_INV = 61,    /* (24, 24) A_R_inv */
+    DWBC_G_R = 62,        /* (24)     G_R */
+    DWBC_J_I_NC = 63,     /* (6, n-12) J_I_nc_, row stride n - 12, zero beyond nc_dof */
+    DWBC_J_I_NC_INV_T = 64 /* (6, n-12) J_I_nc_inv_T */
 };
 
 const char *dwbc_last_error(void);
@@ -227,6 +233,31 @@ int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau);
 enum dwbc_jacc_field { DWBC_JACC_ACC = 0, DWBC_JACC_TORQUE = 1, DWBC_JACC_CONTACT = 2, DWBC_JACC_FSTAR_QP = 3, DWBC_JACC_STATUS = 4 };
 int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level);
 int dwbc_batch_get_jacc(dwbc_batch *b, int level, int field, void *host_out, size_t bytes);
+
+/* ---- the same formulations on the REDUCED system, after a cycle solved with DWBC_SOLVE_REDUCED (dump on, one contact state per
+ * batch).  RS = vc_dof + 6 (24 for TOCABI double support): contact-chain coordinates + 6 centroidal coordinates of the other bodies.
+ * The contact-chain task levels (`!noncont_task`) are taken in level order; `level` below counts THEM.
+ *   RobotData::ConfigureLQP_R(hqp)            src/dwbc.cpp:4504-4632  (A_R, J_CR, G_R, J_task J_R_INV_T^T; cost scaled by |A_|_F of
+ *                                              the full model; torque limit 200, 600 on row RS-6-4).  HQP sizes (RS, 0, contact dof).
+ *   RobotData::CalcControlTorqueLQP_R(hqp)    :4455-4477 = dwbc_hqp_solve_sequential.  dwbc_batch_lqp_torque then returns
+ *                                              B x (RS-6): the 12 / 6 chain torques and the wrench on the centroidal coordinates.
+ *   CalcSingleTaskTorqueWithJACC_QP_R         :3946-4122 (|tau| <= 200 on the chain joints only); results through dwbc_batch_get_jacc
+ *                                              with acc_qp_ (RS) and torque_qp_ (RS-6).
+ * The non-contact halves take ONE 6-D task level on a non-contact link (the reference reads ts_[1] as such); `level` is the task level
+ * as registered.  HQP sizes (nc_dof, 0, 0), nc_dof = ndof - vc_dof.
+ *   RobotData::ConfigureLQP_R_NC(hqp_nc, q_acc) :4634-4760: q_acc = the last level's answer of the solved reduced LQP `hr`.  Then
+ *                                              CalcControlTorqueLQP_R_NC :4479-4502 = dwbc_hqp_solve_first + dwbc_hqp_solve_sequential.
+ *   CalcSingleTaskTorqueWithJACC_QP_R_NC(ts, prev_acc) :4124-4302: prev_acc = acc_qp_ of the reduced JACC level `src_level`.  Results
+ *                                              (dwbc_batch_get_jacc_nc): acc_qp_ (nc_dof), torque_qp_ (nc_dof), gacc_qp_ (6, under
+ *                                              DWBC_JACC_CONTACT), f_star_qp_ (6), status. */
+/* vc_dof and nc_dof of the contact state set through dwbc_batch_set_contact (src/dwbc.cpp:2818-2823); 0 if the contact chains
+ * do not occupy the leading joint dofs (the reduced path's scope) */
+int dwbc_batch_reduced_dims(dwbc_batch *b, int *vc_dof, int *nc_dof);
+int dwbc_batch_configure_lqp_r(dwbc_batch *b, dwbc_hqp *h);
+int dwbc_batch_configure_lqp_r_nc(dwbc_batch *b, dwbc_hqp *h_nc, const dwbc_hqp *hr, int level);
+int dwbc_batch_solve_jacc_r(dwbc_batch *b, dwbc_hqp *h, int level);
+int dwbc_batch_solve_jacc_r_nc(dwbc_batch *b, dwbc_hqp *h_nc, int level, int src_level);
+int dwbc_batch_get_jacc_nc(dwbc_batch *b, int field, void *host_out, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,12 @@ SYMBOLS = [
     ("dwbc_batch_lqp_torque", _i, [_vp, _vp, _vp]),
     ("dwbc_batch_solve_jacc", _i, [_vp, _vp, _i]),
     ("dwbc_batch_get_jacc", _i, [_vp, _i, _i, _vp, C.c_size_t]),
+    ("dwbc_batch_reduced_dims", _i, [_vp, _vp, _vp]),
+    ("dwbc_batch_configure_lqp_r", _i, [_vp, _vp]),
+    ("dwbc_batch_configure_lqp_r_nc", _i, [_vp, _vp, _vp, _i]),
+    ("dwbc_batch_solve_jacc_r", _i, [_vp, _vp, _i]),
+    ("dwbc_batch_solve_jacc_r_nc", _i, [_vp, _vp, _i, _i]),
+    ("dwbc_batch_get_jacc_nc", _i, [_vp, _i, _vp, C.c_size_t]),
     ("dwbc_batch_host_ptr", _vp, [_vp, _i]),
 ]
 

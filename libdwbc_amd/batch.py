@@ -31,6 +31,7 @@ FIELDS = dict(
     A=30, A_inv=31, J_C=32, Lambda_c=33, J_C_INV_T=34, A_inv_N_C=35, W_inv=36, NwJw=37, G=38, P_C=39,
     link_R=40, link_p=41, fstar_qp=42, contact_qp=43, cf_redis=44, J_task=45, Lambda_task=46, J_kt=47, qp_viol=48,
     CMM=50, com=51, com_inertia=52, J_com=53, B=54, link_v=55, link_w=56, contact_pos=57, contact_rot=58, zmp=59,
+    A_R=60, A_R_inv=61, G_R=62, J_I_nc=63, J_I_nc_inv_T=64,
 )
 
 
@@ -268,6 +269,7 @@ class Batch:
         CMM=lambda s: (6, s.n), com=lambda s: (3,), com_inertia=lambda s: (3, 3), J_com=lambda s: (6, s.n),
         B=lambda s: (s.n,), link_v=lambda s: (48, 3), link_w=lambda s: (48, 3),
         contact_pos=lambda s: (2, 3), contact_rot=lambda s: (2, 3, 3), zmp=lambda s: (3, 3),
+        A_R=lambda s: (24, 24), A_R_inv=lambda s: (24, 24), G_R=lambda s: (24,), J_I_nc=lambda s: (6, s.n - 12), J_I_nc_inv_T=lambda s: (6, s.n - 12),
         in_q=lambda s: (s.n + 1,), in_contact=lambda s: (s.n_contacts,), in_fstar=lambda s: (s.fstar_size,),
     )
 

@@ -179,6 +179,9 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     hipFree(b->d_total);
     for (int l = 0; l < kMaxLevels; l++) hipFree(b->d_jacc[l]);
     hipFree(b->d_jacc_status);
+    hipFree(b->d_rrec);
+    hipFree(b->d_jacc_nc);
+    hipFree(b->d_jacc_nc_status);
     hipFree(b->d_dump);
     hipFree(b->d_body);
     hipFree(b->d_topo);
@@ -656,6 +659,9 @@ size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
         case DWBC_CONTACT_ROT: return B * kMaxActiveContacts * 9 * 8;
         case DWBC_ZMP: return B * (3 + kMaxActiveContacts * 3) * 8;
         case DWBC_LINK_V: case DWBC_LINK_W: return B * kMaxBodies * 3 * 8;
+        case DWBC_A_R: case DWBC_A_R_INV: return B * kMaxReducedDof * kMaxReducedDof * 8;
+        case DWBC_G_R: return B * kMaxReducedDof * 8;
+        case DWBC_J_I_NC: case DWBC_J_I_NC_INV_T: return B * 6 * (n - 12) * 8;
         default: return 0;
     }
 }
@@ -729,6 +735,11 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
         case DWBC_J_KT: off = dl.J_kt; len = L * (int)m * T; break;
         case DWBC_QP_VIOL: off = dl.qp_viol; len = L + 1; break;
         case DWBC_DUMP_RAW: off = 0; len = dl.total; break;
+        case DWBC_A_R: off = dl.A_R; len = kMaxReducedDof * kMaxReducedDof; break;
+        case DWBC_A_R_INV: off = dl.A_R_inv; len = kMaxReducedDof * kMaxReducedDof; break;
+        case DWBC_G_R: off = dl.G_R; len = kMaxReducedDof; break;
+        case DWBC_J_I_NC: off = dl.J_I_nc; len = 6 * (n - 12); break;
+        case DWBC_J_I_NC_INV_T: off = dl.J_I_nc_inv_T; len = 6 * (n - 12); break;
         default: return fail("unknown field");
     }
     HIP_OK(hipMemcpy2D(out, (size_t)len * 8, b->d_dump + off, (size_t)dl.total * 8, (size_t)len * 8, B, hipMemcpyDeviceToHost));

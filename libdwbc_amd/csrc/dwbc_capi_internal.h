@@ -87,6 +87,11 @@ struct dwbc_batch {
     double *d_total = nullptr;                // B x m scratch of the DWBC_TAU_* getters
     double *d_jacc[dwbc::kMaxLevels] = {nullptr, nullptr, nullptr, nullptr};  // per task level: B x jacc_rec_size (dwbc_batch_solve_jacc)
     int *d_jacc_status = nullptr;             // kMaxLevels x B
+    int jacc_n[dwbc::kMaxLevels] = {0, 0, 0, 0};  // system size each record was written with (n, or RS for dwbc_batch_solve_jacc_r)
+    double *d_rrec = nullptr;                 // B x DumpLayout::make(RS).total: the reduced system in dump-record layout (dwbc_hqp.h)
+    int rrec_n = 0;
+    double *d_jacc_nc = nullptr;              // B x jacc_nc_rec_size (dwbc_batch_solve_jacc_r_nc)
+    int *d_jacc_nc_status = nullptr;
     bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
     bool attr_set = false;
     int n_cu = 0;

@@ -31,10 +31,17 @@
         if (diag && th.tid == 0) diag[DG_TIME + (i)] = (int)(clock64() - t_start_);     \
     } while (0)
 #define DWBC_STAMP_INIT() const long long t_start_ = clock64()
+// every stamp is a fence plus a store and moves the register allocation: a build with all 40 fine stamps spills in the
+// sweeps.  -DDWBC_FINE_MASK=0x...ull keeps only the stamps whose bit is set (a handful per build reads true)
+#ifndef DWBC_FINE_MASK
+#define DWBC_FINE_MASK 0ull
+#endif
 #define DWBC_FSTAMP(i)                                                                  \
     do {                                                                                \
-        DWBC_SYNC();                                                                    \
-        if (dump && th.tid == 0) dump[dl.stamps + (i)] = (real_t)(clock64() - t_start_); \
+        if ((DWBC_FINE_MASK >> (i)) & 1ull) {                                           \
+            DWBC_SYNC();                                                                \
+            if (diag && th.tid == 0) diag[DG_FTIME + (i)] = (int)(clock64() - t_start_); \
+        }                                                                               \
     } while (0)
 #else
 #define DWBC_FSTAMP(i) ((void)0)

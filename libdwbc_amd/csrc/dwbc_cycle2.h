@@ -849,8 +849,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
-        if (dump && th.tid == 0 && qi == 0)
-            for (int i_ = 0; i_ < 8; i_++) dump[dl.stamps + 23 + i_] = (real_t)qres.tm[i_];
+        if (diag && th.tid == 0 && qi == 0)
+            for (int i_ = 0; i_ < 8; i_++) diag[DG_FTIME + 23 + i_] = (int)qres.tm[i_];
 #endif
         if (is_task) DWBC_STAMP(8 + 3 * qi);
         const real_t *x = L + S::qp_x;

@@ -544,6 +544,11 @@ struct LqpCfg {
     int oBn;  // offset of B_ inside the dump record (DumpLayout::B, or ::G when no qdot was supplied: B_(q, 0) = G_)
     int fstar_off[kMaxLevels], fstar_total;
     double tlim, alim;
+    // what the reduced variants change (ConfigureLQP_R src/dwbc.cpp:4504-4632, JACC_QP_R :3946-4122); the full model leaves the defaults
+    int oNorm;         // >= 0: offset of the Frobenius norm that scales the cost (the FULL A_'s, dwbc.cpp:4533); -1: |A| of this system
+    int tlim_idx;      // >= 0: this torque row is bounded by tlim_special (`tlim(tlim_size - 4) = 600`, dwbc.cpp:4552)
+    double tlim_special;
+    int jacc_mt;       // JACC: torque rows that carry the +-200 bound (JACC_QP_R: all but the six centroidal ones, dwbc.cpp:4096)
 };
 
 template <int NT>
@@ -579,7 +584,11 @@ DWBC_DEV void lqp_configure_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d
             A0[i * nv + c] = v;
             A0[(m + i) * nv + c] = -v;
         }
-        for (int i = th.tid; i < m; i += NT) { a0[i] = -cfg.tlim + Bn[6 + i]; a0[m + i] = -cfg.tlim - Bn[6 + i]; }
+        for (int i = th.tid; i < m; i += NT) {
+            const double tl = i == cfg.tlim_idx ? cfg.tlim_special : cfg.tlim;
+            a0[i] = -tl + Bn[6 + i];
+            a0[m + i] = -tl - Bn[6 + i];
+        }
         for (int idx = th.tid; idx < 6 * nv; idx += NT) {
             const int i = idx / nv, c = idx - i * nv;
             B0[idx] = c < n ? A[i * n + c] : JC[(c - n) * n + i];
@@ -598,7 +607,9 @@ DWBC_DEV void lqp_configure_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d
     // ---- shared cost 5 A / |A|_F on the acceleration block
     {
         double f2 = 0.0;
-        for (int idx = 0; idx < n * n; idx++) f2 += A[idx] * A[idx];
+        if (cfg.oNorm >= 0) f2 = dm[cfg.oNorm] * dm[cfg.oNorm];
+        else
+            for (int idx = 0; idx < n * n; idx++) f2 += A[idx] * A[idx];
         const double sc = 5.0 / sqrt(f2);
         double *Hc = rec + d.oH[1];
         for (int idx = th.tid; idx < n * n; idx += NT) Hc[(idx / n) * nv + idx % n] = A[idx] * sc;
@@ -666,7 +677,7 @@ __host__ __device__ inline int jacc_rec_size(int n) { return n + (n - 6) + 12 + 
 template <int NT>
 DWBC_DEV void jacc_configure_instance(Thr th, const LqpCfg &cfg, int level, const JaccPrev &prev, const HqpDesc &d, const HqpIO &io, const double *dump,
                                       const io_t *fstar, int inst) {
-    const int n = cfg.n, m = n - 6, cd = cfg.cd, nv = d.nv, ncc = 10 * cfg.nc;
+    const int n = cfg.n, m = n - 6, cd = cfg.cd, nv = d.nv, ncc = 10 * cfg.nc, mt = cfg.jacc_mt;
     const DumpLayout dl = DumpLayout::make(n);
     const double *dm = dump + (size_t)inst * dl.total;
     const double *A = dm + dl.A, *JC = dm + dl.J_C, *G = dm + dl.G, *Rc = dm + dl.contact_rot;
@@ -689,14 +700,16 @@ DWBC_DEV void jacc_configure_instance(Thr th, const LqpCfg &cfg, int level, cons
         A0[(ncc + m + i) * nv + 6 + i] = -1.0;
         a0[ncc + i] = -(double)kJaccAccLim;
         a0[ncc + m + i] = -(double)kJaccAccLim;
-        a0[ncc + 2 * m + i] = -(double)kJaccTauLim + G[6 + i];
-        a0[ncc + 3 * m + i] = -(double)kJaccTauLim - G[6 + i];
+        if (i < mt) {
+            a0[ncc + 2 * m + i] = -(double)kJaccTauLim + G[6 + i];
+            a0[ncc + 2 * m + mt + i] = -(double)kJaccTauLim - G[6 + i];
+        }
     }
-    for (int idx = th.tid; idx < m * nv; idx += NT) {
+    for (int idx = th.tid; idx < mt * nv; idx += NT) {
         const int i = idx / nv, c = idx - i * nv;
         const double v = c < n ? A[(6 + i) * n + c] : JC[(c - n) * n + 6 + i];
         A0[(ncc + 2 * m + i) * nv + c] = v;
-        A0[(ncc + 3 * m + i) * nv + c] = -v;
+        A0[(ncc + 2 * m + mt + i) * nv + c] = -v;
     }
     // ---- level-0 equalities: floating-base dynamics | contact | earlier tasks
     for (int idx = th.tid; idx < 6 * nv; idx += NT) {
@@ -777,6 +790,186 @@ DWBC_DEV void lqp_torque_instance(Thr th, const LqpCfg &cfg, const HqpDesc &d, c
         for (int c = 0; c < cd; c++) acc += JC[c * n + 6 + i] * y[n + c];
         tau[(size_t)inst * m + i] = acc;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The reduced variants (ConfigureLQP_R src/dwbc.cpp:4504-4632, CalcSingleTaskTorqueWithJACC_QP_R :3946-4122) are the full-model
+// formulations with (A_, A_inv_, J_C, G_ / B_, J_task) replaced by (A_R, A_R_inv, J_CR, G_R, J_task J_R_INV_T^T).  After a REDUCED
+// cycle with the dump record on, this builds, per instance, a record in the layout of DumpLayout::make(RS) that holds exactly
+// those matrices, so that lqp_configure_instance / jacc_configure_instance / *_extract / *_torque run on it unchanged (cfg.n = RS).
+//   J_CR = [J_C[:, :vc], 0] (dwbc.cpp:3081-3083);  J_R_INV_T = [I_vc 0; 0 J_I_nc_inv_T] (dwbc.cpp:2976-2980)
+// The record's `com` slot carries |A_|_F of the full model (the cost scale of ConfigureLQP_R).
+// src[i]: task level whose Jacobian becomes slot i (the contact-chain levels, in order).
+// ------------------------------------------------------------------------------------------------------------------
+struct ReducedRecCfg {
+    int n, vcd, cd, n_src;
+    int src[kMaxLevels], t_dof[kMaxLevels];
+};
+
+template <int NT>
+DWBC_DEV void reduced_record_instance(Thr th, const ReducedRecCfg &rc, const double *dump, double *rrec, int inst) {
+    const int n = rc.n, vcd = rc.vcd, RS = vcd + 6, ncd = n - vcd, NCX = n - 12, RSX = kMaxReducedDof, T = kMaxTaskDof;
+    const DumpLayout dl = DumpLayout::make(n), dr = DumpLayout::make(RS);
+    const double *dm = dump + (size_t)inst * dl.total;
+    double *o = rrec + (size_t)inst * dr.total;
+    for (int idx = th.tid; idx < RS * RS; idx += NT) {
+        const int i = idx / RS, j = idx - i * RS;
+        o[dr.A + idx] = dm[dl.A_R + i * RSX + j];
+        o[dr.A_inv + idx] = dm[dl.A_R_inv + i * RSX + j];
+    }
+    for (int idx = th.tid; idx < 12 * RS; idx += NT) {
+        const int p = idx / RS, a = idx - p * RS;
+        o[dr.J_C + idx] = (p < rc.cd && a < vcd) ? dm[dl.J_C + p * n + a] : 0.0;
+    }
+    for (int a = th.tid; a < RS; a += NT) { o[dr.G + a] = dm[dl.G_R + a]; o[dr.B + a] = dm[dl.G_R + a]; }
+    for (int idx = th.tid; idx < kMaxActiveContacts * 9; idx += NT) o[dr.contact_rot + idx] = dm[dl.contact_rot + idx];
+    for (int i = 0; i < rc.n_src; i++) {
+        const double *J = dm + dl.J_task + rc.src[i] * T * n;
+        for (int idx = th.tid; idx < rc.t_dof[i] * RS; idx += NT) {
+            const int r = idx / RS, a = idx - r * RS;
+            double v;
+            if (a < vcd) v = J[r * n + a];
+            else {
+                v = 0.0;
+                for (int c = 0; c < ncd; c++) v += J[r * n + vcd + c] * dm[dl.J_I_nc_inv_T + (a - vcd) * NCX + c];
+            }
+            o[dr.J_task + i * T * RS + idx] = v;
+        }
+    }
+    if (th.tid == 0) {
+        double f2 = 0.0;
+        for (int idx = 0; idx < n * n; idx++) f2 += dm[dl.A + idx] * dm[dl.A + idx];
+        o[dr.com] = sqrt(f2);
+    }
+    HQP_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The non-contact halves: ConfigureLQP_R_NC (src/dwbc.cpp:4634-4760) and CalcSingleTaskTorqueWithJACC_QP_R_NC (:4124-4302), for
+// ONE 6-D task level on a non-contact link (the reference hard-codes ts_[1]).  Unknown: the nc_dof joint accelerations.
+//   fstar_local = Ja (f* - base acceleration of the reduced answer), Ja = [[I, skew(x_link - x_pelvis)], [0, I]]
+//   LQP level 0:  J_I_nc a = centroidal acceleration of the reduced answer ; |A_nn a + G_n| <= 200 ; cost 5 A_nn / |A_nn|_F
+//   LQP level 1:  J_task[:, nc] a = fstar_local ; |a| <= 5 ; same cost              (rows NOT normalised, as in the reference)
+//   JACC:         min 1/2 |J_I_nc a - gacc_prev|^2 + 5/2 |J_task[:, nc] a - fstar_local|^2 -- the bounds the reference prepares are
+//                 deleted again before its solve (`DeleteSubjectToX`, dwbc.cpp:4277); one equality-only level, least-norm canon
+// prev: per instance, the reduced answer [base 6 | chain joints | centroidal 6] (first RS doubles of a record of stride prev_stride).
+// ------------------------------------------------------------------------------------------------------------------
+struct NcCfg {
+    int n, vcd, level, link, t, fstar_off, fstar_total;
+    int prev_stride, prev_off;
+};
+
+template <int NT>
+DWBC_DEV void nc_task_local(Thr th, const NcCfg &c, const double *dm, const DumpLayout &dl, const io_t *fs, const double *prev, double *out6) {
+    // uniform 6-vector, computed by every thread
+    const double *p0 = dm + dl.link_p, *pl = dm + dl.link_p + c.link * 3;
+    const double dx = pl[0] - p0[0], dy = pl[1] - p0[1], dz = pl[2] - p0[2];
+    double e[6];
+    for (int j = 0; j < 6; j++) e[j] = (j < c.t ? (double)fs[c.fstar_off + j] : 0.0) - prev[j];
+    out6[0] = e[0] + (-dz * e[4] + dy * e[5]);
+    out6[1] = e[1] + (dz * e[3] - dx * e[5]);
+    out6[2] = e[2] + (-dy * e[3] + dx * e[4]);
+    out6[3] = e[3]; out6[4] = e[4]; out6[5] = e[5];
+}
+
+template <int NT>
+DWBC_DEV void lqp_nc_configure_instance(Thr th, const NcCfg &c, const HqpDesc &d, const HqpIO &io, const double *dump, const io_t *fstar,
+                                        const double *prev_all, int inst) {
+    const int n = c.n, vcd = c.vcd, ncd = n - vcd, NCX = n - 12, nv = d.nv, T = kMaxTaskDof, RS = vcd + 6;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *G = dm + dl.G, *JI = dm + dl.J_I_nc, *Jt = dm + dl.J_task + c.level * T * n;
+    const io_t *fs = fstar + (size_t)inst * c.fstar_total;
+    const double *prev = prev_all + (size_t)inst * c.prev_stride + c.prev_off;
+    double *rec = io.rec + (size_t)inst * d.rec;
+    for (int idx = th.tid; idx < d.rec; idx += NT) rec[idx] = 0.0;
+    HQP_SYNC();
+    double f2 = 0.0;
+    for (int i = 0; i < ncd; i++)
+        for (int j = 0; j < ncd; j++) f2 += A[(vcd + i) * n + vcd + j] * A[(vcd + i) * n + vcd + j];
+    const double sc = 5.0 / sqrt(f2);
+    double *A0 = rec + d.oA[0], *a0 = rec + d.oa[0], *B0 = rec + d.oB[0], *b0 = rec + d.ob[0], *Hc = rec + d.oH[0];
+    double *A1 = rec + d.oA[1], *a1 = rec + d.oa[1], *B1 = rec + d.oB[1], *b1 = rec + d.ob[1];
+    for (int idx = th.tid; idx < ncd * ncd; idx += NT) {
+        const int i = idx / ncd, j = idx - i * ncd;
+        const double v = A[(vcd + i) * n + vcd + j];
+        A0[i * nv + j] = v;
+        A0[(ncd + i) * nv + j] = -v;
+        Hc[i * nv + j] = v * sc;
+    }
+    for (int i = th.tid; i < ncd; i += NT) {
+        a0[i] = -200.0 + G[vcd + i];
+        a0[ncd + i] = -200.0 - G[vcd + i];
+        A1[i * nv + i] = 1.0;
+        A1[(ncd + i) * nv + i] = -1.0;
+        a1[i] = -5.0;
+        a1[ncd + i] = -5.0;
+    }
+    for (int idx = th.tid; idx < 6 * ncd; idx += NT) {
+        const int r = idx / ncd, j = idx - r * ncd;
+        B0[r * nv + j] = JI[r * NCX + j];
+        B1[r * nv + j] = r < c.t ? Jt[r * n + vcd + j] : 0.0;
+    }
+    double fl[6];
+    nc_task_local<NT>(th, c, dm, dl, fs, prev, fl);
+    for (int r = th.tid; r < 6; r += NT) { b0[r] = -prev[RS - 6 + r]; b1[r] = -fl[r]; }
+    HQP_SYNC();
+}
+
+__host__ __device__ inline int jacc_nc_rec_size(int ncd) { return 2 * ncd + 6 + kMaxTaskDof; }
+
+template <int NT>
+DWBC_DEV void jacc_nc_configure_instance(Thr th, const NcCfg &c, const HqpDesc &d, const HqpIO &io, const double *dump, const io_t *fstar,
+                                         const double *prev_all, int inst) {
+    const int n = c.n, vcd = c.vcd, ncd = n - vcd, NCX = n - 12, nv = d.nv, T = kMaxTaskDof, RS = vcd + 6;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *JI = dm + dl.J_I_nc, *Jt = dm + dl.J_task + c.level * T * n;
+    const io_t *fs = fstar + (size_t)inst * c.fstar_total;
+    const double *prev = prev_all + (size_t)inst * c.prev_stride + c.prev_off;
+    double *rec = io.rec + (size_t)inst * d.rec;
+    for (int idx = th.tid; idx < d.rec; idx += NT) rec[idx] = 0.0;
+    HQP_SYNC();
+    const double w = sqrt(5.0);  // `5 * Identity` on the task slack (dwbc.cpp:4163)
+    double *B0 = rec + d.oB[0], *b0 = rec + d.ob[0];
+    for (int idx = th.tid; idx < (6 + c.t) * ncd; idx += NT) {
+        const int r = idx / ncd, j = idx - r * ncd;
+        B0[r * nv + j] = r < 6 ? JI[r * NCX + j] : w * Jt[(r - 6) * n + vcd + j];
+    }
+    double fl[6];
+    nc_task_local<NT>(th, c, dm, dl, fs, prev, fl);
+    for (int r = th.tid; r < 6 + c.t; r += NT) b0[r] = r < 6 ? -prev[RS - 6 + r] : -w * fl[r - 6];
+    HQP_SYNC();
+}
+
+// acc_qp_ (nc_dof), torque_qp_ = A_nn a + G_n, gacc_qp_ = J_I_nc a - gacc_prev, f_star_qp_ = J_task[:, nc] a - fstar_local (dwbc.cpp:4296-4299)
+template <int NT>
+DWBC_DEV void jacc_nc_extract_instance(Thr th, const NcCfg &c, const HqpDesc &d, const HqpIO &io, const double *dump, const io_t *fstar,
+                                       const double *prev_all, double *out, int *status, int inst) {
+    const int n = c.n, vcd = c.vcd, ncd = n - vcd, NCX = n - 12, T = kMaxTaskDof, RS = vcd + 6;
+    const DumpLayout dl = DumpLayout::make(n);
+    const double *dm = dump + (size_t)inst * dl.total;
+    const double *A = dm + dl.A, *G = dm + dl.G, *JI = dm + dl.J_I_nc, *Jt = dm + dl.J_task + c.level * T * n;
+    const io_t *fs = fstar + (size_t)inst * c.fstar_total;
+    const double *prev = prev_all + (size_t)inst * c.prev_stride + c.prev_off;
+    const double *y = io.rec + (size_t)inst * d.rec + d.oy[0];
+    const int ok = io.stat[(size_t)inst * HQS_COUNT + HQS_STATUS];
+    double *o = out + (size_t)inst * jacc_nc_rec_size(ncd);
+    double fl[6];
+    nc_task_local<NT>(th, c, dm, dl, fs, prev, fl);
+    for (int i = th.tid; i < ncd; i += NT) {
+        o[i] = ok ? y[i] : 0.0;
+        double acc = G[vcd + i];
+        for (int j = 0; j < ncd; j++) acc += A[(vcd + i) * n + vcd + j] * y[j];
+        o[ncd + i] = ok ? acc : 0.0;
+    }
+    for (int r = th.tid; r < 6; r += NT) {
+        double g = -prev[RS - 6 + r], f = -fl[r];
+        for (int j = 0; j < ncd; j++) { g += JI[r * NCX + j] * y[j]; if (r < c.t) f += Jt[r * n + vcd + j] * y[j]; }
+        o[2 * ncd + r] = ok ? g : 0.0;
+        o[2 * ncd + 6 + r] = (ok && r < c.t) ? f : 0.0;
+    }
+    if (th.tid == 0) status[inst] = ok;
 }
 
 }  // namespace dwbc

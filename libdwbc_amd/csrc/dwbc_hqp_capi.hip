@@ -54,6 +54,28 @@ __global__ __launch_bounds__(kNT) void dwbc_jacc_extract_kernel(const LqpCfg cfg
     jacc_extract_instance<kNT>(Thr{(int)threadIdx.x}, cfg, level, d, io, dump, fstar, out, status, inst);
 }
 
+__global__ __launch_bounds__(kNT) void dwbc_reduced_record_kernel(const ReducedRecCfg rc, int B, const double *dump, double *rrec) {
+    const int inst = blockIdx.x;
+    if (inst >= B) return;
+    reduced_record_instance<kNT>(Thr{(int)threadIdx.x}, rc, dump, rrec, inst);
+}
+__global__ __launch_bounds__(kNT) void dwbc_lqp_nc_configure_kernel(const NcCfg c, const HqpDesc d, const HqpIO io, const double *dump, const double *fstar, const double *prev) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    lqp_nc_configure_instance<kNT>(Thr{(int)threadIdx.x}, c, d, io, dump, fstar, prev, inst);
+}
+__global__ __launch_bounds__(kNT) void dwbc_jacc_nc_configure_kernel(const NcCfg c, const HqpDesc d, const HqpIO io, const double *dump, const double *fstar, const double *prev) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    jacc_nc_configure_instance<kNT>(Thr{(int)threadIdx.x}, c, d, io, dump, fstar, prev, inst);
+}
+__global__ __launch_bounds__(kNT) void dwbc_jacc_nc_extract_kernel(const NcCfg c, const HqpDesc d, const HqpIO io, const double *dump, const double *fstar, const double *prev,
+                                                                   double *out, int *status) {
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    jacc_nc_extract_instance<kNT>(Thr{(int)threadIdx.x}, c, d, io, dump, fstar, prev, out, status, inst);
+}
+
 struct dwbc_hqp {
     int B = 0, device = 0;
     int acc = 0, torque = 0, contact = 0;
@@ -66,8 +88,8 @@ struct dwbc_hqp {
     int *d_stat = nullptr;
     hipStream_t stream = nullptr;
     bool attr_set = false;
-    LqpCfg lqp{};  // set by dwbc_batch_configure_lqp
-    bool is_lqp = false;
+    LqpCfg lqp{};  // set by dwbc_batch_configure_lqp / _lqp_r
+    bool is_lqp = false, lqp_reduced = false;
 };
 
 namespace {
@@ -291,23 +313,30 @@ int dwbc_hqp_get(dwbc_hqp *h, int level, int field, void *out, size_t bytes) {
 }
 
 // what both formulations read from a solved cycle: checks + the contact / task description of the (uniform) batch
-static int formulation_cfg(dwbc_batch *b, dwbc_hqp *h, LqpCfg &cfg) {
+// what both formulations read from the batch.  reduced: the cycle that ran was the reduced one; the system handed to the
+// configurators is then the record dwbc_reduced_record_kernel writes (see dwbc_hqp.h) and cfg describes THAT system.
+struct ReducedInfo { int vcd = 0, RS = 0; unsigned long long comask = 0x3full; int kind[kMaxLevels] = {0, 0, 0, 0}; };
+
+static int formulation_cfg(dwbc_batch *b, dwbc_hqp *h, LqpCfg &cfg, bool reduced, ReducedInfo *ri = nullptr) {
     if (!b || !h) return fail("NULL handle");
     if (b->dtype != DWBC_F64) return fail("LQP / JACC: fp64 batches only");
     if (h->B != b->B || h->device != b->device) return fail("LQP / JACC: the HQP object must have the batch's size and device");
     if (!b->dump_on || !b->d_dump) return fail("LQP / JACC: needs dwbc_batch_enable_dump(b, 1) and a solved cycle (A_, A_inv_, J_C, B_, J_task come from it)");
-    if (b->last_reduced) return fail("LQP / JACC: run the full-model cycle first (the reduced variants are not built)");
+    if (reduced && !b->last_reduced) return fail("LQP_R / JACC_R: run the reduced cycle first (DWBC_SOLVE_REDUCED; A_R, G_R, J_I_nc_inv_T come from it)");
+    if (!reduced && b->last_reduced) return fail("LQP / JACC: run the full-model cycle first (or use the _r entry points after a reduced one)");
     if (b->su.n_custom > 0 || b->su.has_com_task) return fail("LQP / JACC: link task levels only");
     if (b->h_flags.empty() || (b->d_flags && !b->own_flags)) return fail("LQP / JACC: contact flags must be set through dwbc_batch_set_contact (the host checks that they are uniform)");
     const int ncn = b->su.n_contacts;
     cfg = LqpCfg{};
     cfg.n = b->n;
     cfg.nc = 0;
+    unsigned long long comask = 0x3full;
     for (int c = 0; c < ncn; c++)
         if (b->h_flags[c]) {
             if (cfg.nc >= kMaxActiveContacts) return fail("LQP / JACC: more than 2 active contacts");
             cfg.act[cfg.nc] = c;
             cfg.lx[cfg.nc] = b->su.c_lx[c]; cfg.ly[cfg.nc] = b->su.c_ly[c]; cfg.mu[cfg.nc] = b->su.c_mu[c]; cfg.muz[cfg.nc] = b->su.c_muz[c];
+            comask |= b->su.c_dofmask[c];
             cfg.nc++;
         }
     for (int i = 1; i < b->B; i++)
@@ -315,29 +344,81 @@ static int formulation_cfg(dwbc_batch *b, dwbc_hqp *h, LqpCfg &cfg) {
             return fail("LQP / JACC: every instance of the batch must be in the same contact state (the level sizes depend on it)");
     if (cfg.nc < 1) return fail("LQP / JACC: no active contact");
     cfg.cd = 6 * cfg.nc;
-    cfg.n_tasks = b->su.n_levels;
-    for (int i = 0; i < b->su.n_levels; i++) { cfg.t_dof[i] = b->su.t_dof[i]; cfg.fstar_off[i] = b->su.fstar_off[i]; }
     cfg.fstar_total = b->su.fstar_total;
-    cfg.oBn = b->d_qdot ? b->dl.B : b->dl.G;  // B_(q, qdot = 0) = G_
     cfg.tlim = 200.0;  // `tlim`, src/dwbc.cpp:4360
     cfg.alim = 5.0;    // `alim`, src/dwbc.cpp:4398
+    cfg.oNorm = -1;
+    cfg.tlim_idx = -1;
+    cfg.tlim_special = 0.0;
+    if (!reduced) {
+        cfg.n_tasks = b->su.n_levels;
+        for (int i = 0; i < b->su.n_levels; i++) { cfg.t_dof[i] = b->su.t_dof[i]; cfg.fstar_off[i] = b->su.fstar_off[i]; }
+        cfg.oBn = b->d_qdot ? b->dl.B : b->dl.G;  // B_(q, qdot = 0) = G_
+        cfg.jacc_mt = b->n - 6;
+        return 1;
+    }
+    // ---- the reduced system: contact chains (leading dofs) + 6 centroidal coordinates (dwbc.cpp:2818-2823)
+    int vcd = 0;
+    for (int j = 0; j < b->n; j++) vcd += (int)((comask >> j) & 1ull);
+    if (comask != ((1ull << vcd) - 1ull) || (vcd != 12 && vcd != 18)) return fail("LQP_R / JACC_R: the contact chains must occupy the leading joint dofs (TOCABI: L+R or L)");
+    const int RS = vcd + 6;
+    ReducedInfo info;
+    info.vcd = vcd; info.RS = RS; info.comask = comask;
+    ReducedRecCfg rc{};
+    rc.n = b->n; rc.vcd = vcd; rc.cd = cfg.cd; rc.n_src = 0;
+    for (int lv = 0; lv < b->su.n_levels; lv++) {
+        int nco = 0, nnc = 0;
+        for (int li = 0; li < b->su.t_nlinks[lv]; li++) {
+            const int link = b->su.t_link[lv][li];
+            if (link == 0 || ((comask >> (link + 5)) & 1ull)) nco++; else nnc++;
+        }
+        if (nco && nnc) return fail("LQP_R / JACC_R: a task level mixes contact-chain and other links (undefined in the reference, src/task.cpp:134-141)");
+        info.kind[lv] = nco ? 1 : 2;
+        if (nco) {  // `!ts_[i].noncont_task` (dwbc.cpp:4610): packed in level order
+            rc.src[rc.n_src] = lv;
+            rc.t_dof[rc.n_src] = b->su.t_dof[lv];
+            cfg.t_dof[rc.n_src] = b->su.t_dof[lv];
+            cfg.fstar_off[rc.n_src] = b->su.fstar_off[lv];
+            rc.n_src++;
+        }
+    }
+    cfg.n_tasks = rc.n_src;
+    cfg.n = RS;
+    const DumpLayout dr = DumpLayout::make(RS);
+    cfg.oBn = dr.G;
+    cfg.oNorm = dr.com;             // |A_|_F of the full model (dwbc.cpp:4533)
+    cfg.tlim_idx = (RS - 6) - 4;    // `tlim(tlim_size - 4) = 600` (dwbc.cpp:4552)
+    cfg.tlim_special = 600.0;
+    cfg.jacc_mt = RS - 12;          // `_torque_dof - 6` rows carry the +-200 bound (dwbc.cpp:4096-4097)
+    HIP_OK(hipSetDevice(b->device));
+    if (b->rrec_n != RS || !b->d_rrec) {
+        if (b->d_rrec) hipFree(b->d_rrec);
+        b->d_rrec = nullptr;
+        HIP_OK(hipMalloc(&b->d_rrec, (size_t)b->B * dr.total * 8));
+        HIP_OK(hipMemset(b->d_rrec, 0, (size_t)b->B * dr.total * 8));
+        b->rrec_n = RS;
+    }
+    hipLaunchKernelGGL(dwbc_reduced_record_kernel, dim3(b->B), dim3(kNT), 0, b->stream, rc, b->B, (const double *)b->d_dump, b->d_rrec);
+    HIP_OK(hipGetLastError());
+    if (ri) *ri = info;
     return 1;
 }
 
-int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
+static int configure_lqp_common(dwbc_batch *b, dwbc_hqp *h, bool reduced) {
     LqpCfg cfg{};
-    if (!formulation_cfg(b, h, cfg)) return 0;
-    if (h->acc != b->n || h->torque != 0 || h->contact != cfg.cd)
-        return fail("LQP: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(b->n) + ", 0, " + std::to_string(cfg.cd) + ")");
+    if (!formulation_cfg(b, h, cfg, reduced)) return 0;
+    const int n = cfg.n, m = n - 6;
+    if (h->acc != n || h->torque != 0 || h->contact != cfg.cd)
+        return fail("LQP: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(n) + ", 0, " + std::to_string(cfg.cd) + ")");
     if (2 + cfg.n_tasks > kHqpMaxLevels) return fail("LQP: too many task levels");
     // (re)build the hierarchy if its shape changed
-    bool same = h->is_lqp && h->laid_out && h->d.n_levels == 2 + cfg.n_tasks && h->lqp.cd == cfg.cd;
+    bool same = h->is_lqp && h->laid_out && h->d.n_levels == 2 + cfg.n_tasks && h->lqp.cd == cfg.cd && h->lqp.n == n;
     for (int i = 0; same && i < cfg.n_tasks; i++) same = h->d.e[2 + i] == cfg.t_dof[i];
     if (!same) {
         dwbc_hqp_clear(h);
         h->share_cost = true;
-        if (dwbc_hqp_add_hierarchy(h, 2 * b->m, 6) < 0) return 0;
-        if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 2 * b->m, cfg.cd) < 0) return 0;
+        if (dwbc_hqp_add_hierarchy(h, 2 * m, 6) < 0) return 0;
+        if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 2 * m, cfg.cd) < 0) return 0;
         h->d.has_cost[1] = 1;
         for (int i = 0; i < cfg.n_tasks; i++) {
             if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[i]) < 0) return 0;
@@ -348,43 +429,65 @@ int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) {
         h->is_lqp = true;
     }
     h->lqp = cfg;
+    h->lqp_reduced = reduced;
     h->stream = b->stream;
     HIP_OK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(dwbc_lqp_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar);
+    hipLaunchKernelGGL(dwbc_lqp_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, h->d, hqp_io(h), (const double *)(reduced ? b->d_rrec : b->d_dump),
+                       (const double *)b->d_fstar);
     HIP_OK(hipGetLastError());
     return 1;
 }
 
+int dwbc_batch_reduced_dims(dwbc_batch *b, int *vc_dof, int *nc_dof) {
+    if (!b || !vc_dof || !nc_dof) return fail("NULL argument");
+    if (b->h_flags.empty()) return fail("reduced dims: set the contact flags first");
+    unsigned long long comask = 0x3full;
+    for (int c = 0; c < b->su.n_contacts; c++)
+        if (b->h_flags[c]) comask |= b->su.c_dofmask[c];
+    int vcd = 0;
+    for (int j = 0; j < b->n; j++) vcd += (int)((comask >> j) & 1ull);
+    if (comask != ((1ull << vcd) - 1ull) || (vcd != 12 && vcd != 18)) return fail("reduced dims: the contact chains must occupy the leading joint dofs");
+    *vc_dof = vcd;
+    *nc_dof = b->n - vcd;
+    return 1;
+}
+
+int dwbc_batch_configure_lqp(dwbc_batch *b, dwbc_hqp *h) { return configure_lqp_common(b, h, false); }
+int dwbc_batch_configure_lqp_r(dwbc_batch *b, dwbc_hqp *h) { return configure_lqp_common(b, h, true); }
+
 int dwbc_batch_lqp_torque(dwbc_batch *b, dwbc_hqp *h, double *tau) {
     if (!b || !h || !tau) return fail("NULL argument");
     if (!h->is_lqp || !h->laid_out) return fail("LQP: dwbc_batch_configure_lqp first");
+    if (h->lqp_reduced && (!b->d_rrec || b->rrec_n != h->lqp.n)) return fail("LQP_R: the reduced record of this batch is gone");
     HIP_OK(hipSetDevice(b->device));
+    const size_t m = (size_t)h->lqp.n - 6;
     double *d_tau = nullptr;
-    HIP_OK(hipMalloc(&d_tau, (size_t)b->B * b->m * 8));
-    hipLaunchKernelGGL(dwbc_lqp_torque_kernel, dim3(b->B), dim3(kNT), 0, b->stream, h->lqp, h->d, hqp_io(h), (const double *)b->d_dump, d_tau);
+    HIP_OK(hipMalloc(&d_tau, (size_t)b->B * m * 8));
+    hipLaunchKernelGGL(dwbc_lqp_torque_kernel, dim3(b->B), dim3(kNT), 0, b->stream, h->lqp, h->d, hqp_io(h), (const double *)(h->lqp_reduced ? b->d_rrec : b->d_dump), d_tau);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    if (e == hipSuccess) e = hipMemcpy(tau, d_tau, (size_t)b->B * b->m * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tau, d_tau, (size_t)b->B * m * 8, hipMemcpyDeviceToHost);
     hipFree(d_tau);
     if (e != hipSuccess) return fail(std::string("lqp torque: ") + hipGetErrorString(e));
     return 1;
 }
 
-int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level) {
+static int solve_jacc_common(dwbc_batch *b, dwbc_hqp *h, int level, bool reduced) {
     LqpCfg cfg{};
-    if (!formulation_cfg(b, h, cfg)) return 0;
+    if (!formulation_cfg(b, h, cfg, reduced)) return 0;
+    const int n = cfg.n, m = n - 6;
     if (level < 0 || level >= cfg.n_tasks) return fail("JACC: bad task level");
-    if (h->acc != b->n || h->torque != 0 || h->contact != cfg.cd)
-        return fail("JACC: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(b->n) + ", 0, " + std::to_string(cfg.cd) + ")");
+    if (h->acc != n || h->torque != 0 || h->contact != cfg.cd)
+        return fail("JACC: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(n) + ", 0, " + std::to_string(cfg.cd) + ")");
     int e0 = 6 + cfg.cd;
     for (int i = 0; i < level; i++) {
-        if (!b->d_jacc[i]) return fail("JACC: solve the levels in order (level " + std::to_string(i) + " has no result yet)");
+        if (!b->d_jacc[i] || b->jacc_n[i] != n) return fail("JACC: solve the levels in order (level " + std::to_string(i) + " has no result yet)");
         e0 += cfg.t_dof[i];
     }
     if (e0 > kHqpMaxEq) return fail("JACC: too many equality rows");
     // two levels: the exact constraint level and the task level
     dwbc_hqp_clear(h);
-    if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 4 * b->m, e0) < 0) return 0;
+    if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 2 * m + 2 * cfg.jacc_mt, e0) < 0) return 0;
     if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[level]) < 0) return 0;
     h->d.exact[0] = 1;
     h->d.exact[1] = 0;
@@ -393,26 +496,133 @@ int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level) {
     h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
     h->stream = b->stream;
     HIP_OK(hipSetDevice(b->device));
-    const size_t rs = (size_t)jacc_rec_size(b->n);
+    const size_t rs = (size_t)jacc_rec_size(n);
+    if (b->d_jacc[level] && b->jacc_n[level] != n) { hipFree(b->d_jacc[level]); b->d_jacc[level] = nullptr; }
     if (!b->d_jacc[level]) HIP_OK(hipMalloc(&b->d_jacc[level], (size_t)b->B * rs * 8));
+    b->jacc_n[level] = n;
     if (!b->d_jacc_status) {
         HIP_OK(hipMalloc(&b->d_jacc_status, (size_t)kMaxLevels * b->B * sizeof(int)));
         HIP_OK(hipMemset(b->d_jacc_status, 0, (size_t)kMaxLevels * b->B * sizeof(int)));
     }
     JaccPrev prev{};
     for (int i = 0; i < level; i++) prev.rec[i] = b->d_jacc[i];
-    hipLaunchKernelGGL(dwbc_jacc_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, prev, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar);
+    const double *sys = reduced ? b->d_rrec : b->d_dump;
+    hipLaunchKernelGGL(dwbc_jacc_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, prev, h->d, hqp_io(h), sys, (const double *)b->d_fstar);
     HIP_OK(hipGetLastError());
     if (!launch_solve(h, 0)) return 0;
-    hipLaunchKernelGGL(dwbc_jacc_extract_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar,
+    hipLaunchKernelGGL(dwbc_jacc_extract_kernel, dim3(b->B), dim3(kNT), 0, b->stream, cfg, level, h->d, hqp_io(h), sys, (const double *)b->d_fstar,
                        b->d_jacc[level], b->d_jacc_status + (size_t)level * b->B);
     HIP_OK(hipGetLastError());
     return 1;
 }
 
+int dwbc_batch_solve_jacc(dwbc_batch *b, dwbc_hqp *h, int level) { return solve_jacc_common(b, h, level, false); }
+int dwbc_batch_solve_jacc_r(dwbc_batch *b, dwbc_hqp *h, int level) { return solve_jacc_common(b, h, level, true); }
+
+// the non-contact halves: one 6-D level on a non-contact link; `prev` = the reduced answer it continues
+static int nc_cfg(dwbc_batch *b, dwbc_hqp *h, int level, NcCfg &c, ReducedInfo &ri) {
+    LqpCfg tmp{};
+    if (!formulation_cfg(b, h, tmp, true, &ri)) return 0;
+    if (level < 0 || level >= b->su.n_levels) return fail("R_NC: bad task level");
+    if (ri.kind[level] != 2 || b->su.t_nlinks[level] != 1 || b->su.t_dof[level] != 6)
+        return fail("R_NC: the level must be ONE 6-D task on a non-contact link (the reference's ConfigureLQP_R_NC / JACC_QP_R_NC read ts_[1] as such, src/dwbc.cpp:4144,4728)");
+    const int ncd = b->n - ri.vcd;
+    if (h->acc != ncd || h->torque != 0 || h->contact != 0)
+        return fail("R_NC: create the HQP object with (acceleration, torque, contact) = (" + std::to_string(ncd) + ", 0, 0)");
+    c = NcCfg{};
+    c.n = b->n; c.vcd = ri.vcd; c.level = level; c.link = b->su.t_link[level][0]; c.t = 6;
+    c.fstar_off = b->su.fstar_off[level]; c.fstar_total = b->su.fstar_total;
+    return 1;
+}
+
+int dwbc_batch_configure_lqp_r_nc(dwbc_batch *b, dwbc_hqp *h, const dwbc_hqp *hr, int level) {
+    if (!hr || !hr->is_lqp || !hr->lqp_reduced || !hr->laid_out) return fail("LQP_R_NC: needs the solved reduced LQP (dwbc_batch_configure_lqp_r + solve)");
+    if (hr == h) return fail("LQP_R_NC: use a second HQP object");
+    NcCfg c{};
+    ReducedInfo ri;
+    if (!nc_cfg(b, h, level, c, ri)) return 0;
+    if (hr->lqp.n != ri.RS || hr->B != b->B) return fail("LQP_R_NC: the reduced LQP belongs to another contact state or batch");
+    c.prev_stride = hr->d.rec;
+    c.prev_off = hr->d.oy[hr->d.n_levels - 1];
+    const int ncd = b->n - ri.vcd;
+    dwbc_hqp_clear(h);
+    h->share_cost = true;
+    if (dwbc_hqp_add_hierarchy(h, 2 * ncd, 6) < 0) return 0;
+    if (dwbc_hqp_add_hierarchy(h, 2 * ncd, 6) < 0) return 0;
+    h->d.has_cost[0] = h->d.has_cost[1] = 1;
+    if (!layout_and_alloc(h)) return 0;
+    h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+    h->stream = b->stream;
+    HIP_OK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(dwbc_lqp_nc_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, c, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar,
+                       (const double *)hr->d_rec);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_batch_solve_jacc_r_nc(dwbc_batch *b, dwbc_hqp *h, int level, int src_level) {
+    NcCfg c{};
+    ReducedInfo ri;
+    if (!nc_cfg(b, h, level, c, ri)) return 0;
+    if (src_level < 0 || src_level >= kMaxLevels || !b->d_jacc[src_level] || b->jacc_n[src_level] != ri.RS)
+        return fail("JACC_R_NC: no reduced JACC result for the source level (dwbc_batch_solve_jacc_r first)");
+    c.prev_stride = jacc_rec_size(ri.RS);
+    c.prev_off = 0;
+    dwbc_hqp_clear(h);
+    if (dwbc_hqp_add_hierarchy(h, 0, 6 + c.t) < 0) return 0;
+    if (!layout_and_alloc(h)) return 0;
+    h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+    h->stream = b->stream;
+    HIP_OK(hipSetDevice(b->device));
+    if (!b->d_jacc_nc) {
+        HIP_OK(hipMalloc(&b->d_jacc_nc, (size_t)b->B * jacc_nc_rec_size(b->n - 12) * 8));
+        HIP_OK(hipMalloc(&b->d_jacc_nc_status, (size_t)b->B * sizeof(int)));
+        HIP_OK(hipMemset(b->d_jacc_nc_status, 0, (size_t)b->B * sizeof(int)));
+    }
+    const double *prev = b->d_jacc[src_level];
+    hipLaunchKernelGGL(dwbc_jacc_nc_configure_kernel, dim3(b->B), dim3(kNT), 0, b->stream, c, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar, prev);
+    HIP_OK(hipGetLastError());
+    if (!launch_solve(h, 1)) return 0;
+    hipLaunchKernelGGL(dwbc_jacc_nc_extract_kernel, dim3(b->B), dim3(kNT), 0, b->stream, c, h->d, hqp_io(h), (const double *)b->d_dump, (const double *)b->d_fstar, prev,
+                       b->d_jacc_nc, b->d_jacc_nc_status);
+    HIP_OK(hipGetLastError());
+    return 1;
+}
+
+int dwbc_batch_get_jacc_nc(dwbc_batch *b, int field, void *out, size_t bytes) {
+    if (!b || !b->d_jacc_nc) return fail("JACC_R_NC: no result");
+    // nc_dof of the contact state the result was computed in
+    unsigned long long comask = 0x3full;
+    for (int c = 0; c < b->su.n_contacts; c++)
+        if (b->h_flags[c]) comask |= b->su.c_dofmask[c];
+    int vcd = 0;
+    for (int j = 0; j < b->n; j++) vcd += (int)((comask >> j) & 1ull);
+    const int ncd = b->n - vcd;
+    const size_t rs = (size_t)jacc_nc_rec_size(ncd);
+    int off = 0, len = 0;
+    switch (field) {
+        case DWBC_JACC_ACC: off = 0; len = ncd; break;
+        case DWBC_JACC_TORQUE: off = ncd; len = ncd; break;
+        case DWBC_JACC_CONTACT: off = 2 * ncd; len = 6; break;  // gacc_qp_
+        case DWBC_JACC_FSTAR_QP: off = 2 * ncd + 6; len = kMaxTaskDof; break;
+        case DWBC_JACC_STATUS:
+            if (bytes != (size_t)b->B * sizeof(int)) return fail("JACC_R_NC: size mismatch");
+            HIP_OK(hipSetDevice(b->device));
+            HIP_OK(hipStreamSynchronize(b->stream));
+            HIP_OK(hipMemcpy(out, b->d_jacc_nc_status, bytes, hipMemcpyDeviceToHost));
+            return 1;
+        default: return fail("JACC_R_NC: unknown field");
+    }
+    if (bytes != (size_t)b->B * len * 8) return fail("JACC_R_NC: size mismatch");
+    HIP_OK(hipSetDevice(b->device));
+    HIP_OK(hipStreamSynchronize(b->stream));
+    HIP_OK(hipMemcpy2D(out, (size_t)len * 8, b->d_jacc_nc + off, rs * 8, (size_t)len * 8, b->B, hipMemcpyDeviceToHost));
+    return 1;
+}
+
 int dwbc_batch_get_jacc(dwbc_batch *b, int level, int field, void *out, size_t bytes) {
     if (level < 0 || level >= kMaxLevels || !b->d_jacc[level]) return fail("JACC: no result for this level");
-    const int n = b->n, m = b->m;
+    const int n = b->jacc_n[level], m = n - 6;  // n of the system the level was solved on (RS after dwbc_batch_solve_jacc_r)
     const size_t rs = (size_t)jacc_rec_size(n);
     int off = 0, len = 0;
     switch (field) {

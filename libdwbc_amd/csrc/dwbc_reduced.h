@@ -352,6 +352,13 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     // A_R_inv = J_R A^-1 J_R^T (dwbc.cpp:2937-2956), A_R = its inverse (dwbc.cpp:2958)
     real_t *AR = L + S::AR;
     reduce_to_R<N, NT, RSX>(th, s, JIt, vcd, AR, L + S::tmpE);
+    if (dump) {  // A_R_inv, J_I_nc for the reduced LQP / JACC configurators (dwbc.cpp:4504-4760) and the facade
+        for (int idx = th.tid; idx < RSX * RSX; idx += NT) dump[dl.A_R_inv + idx] = (idx / RSX < RS && idx % RSX < RS) ? AR[idx] : real_t(0.0);
+        for (int idx = th.tid; idx < 6 * NCX; idx += NT) {
+            const int r6 = idx / NCX, i = idx - r6 * NCX;
+            dump[dl.J_I_nc + idx] = i < ncd ? JIt[i * 6 + r6] : real_t(0.0);
+        }
+    }
     {
         PLA(real_t, r, RSX);
         PL(real_t, dr);
@@ -362,6 +369,14 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             LV(dr) = (lane < RS) ? AR[col * RSX + col] : real_t(1.0);
         }
         if (!sweep_inverse_rl<RSX>(r, dr, RS)) st_contact = 0;
+        if (dump) {
+            LANES {
+                if (lane < RSX) {
+#pragma unroll
+                    for (int a = 0; a < RSX; a++) dump[dl.A_R + a * RSX + lane] = (lane < RS && a < RS) ? LV(r)[a] : real_t(0.0);
+                }
+            }
+        }
         real_t *ARrow = L + S::ARrow;
         LANES {
             if (lane >= vcd && lane < vcd + 6) {
@@ -398,6 +413,8 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
     }
     DWBC_STAMP(3);  // reduced dynamics: J_I_nc, A_R_inv, A_R, J_I_nc_inv_T
     const real_t *JIiT = L + S::JIiT;
+    if (dump)
+        for (int idx = th.tid; idx < 6 * NCX; idx += NT) dump[dl.J_I_nc_inv_T + idx] = (idx % NCX) < ncd ? JIiT[idx] : real_t(0.0);
 
 #include "dwbc_cycle2_stage1.inc"
 
@@ -425,6 +442,7 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             for (int i = 0; i < ncd; i++) acc += JIiT[(a - vcd) * NCX + i] * L[S::G + vcd + i];  // dwbc.cpp:2984
         }
         GR[a] = acc;
+        if (dump) dump[dl.G_R + a] = acc;
     }
     DWBC_SYNC();
     for (int p = th.tid; p < C; p += NT) {
@@ -624,6 +642,8 @@ DWBC_DEV void cycle_instance_reduced(Thr th, const Setup &su, const BatchIO &io,
             row += rsel == 0 ? 6 : 3;
         }
         DWBC_SYNC();
+        if (dump)
+            for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jtt[(idx % N) * T + idx / N];
         if (kind[lv] != 2) {
             // J_task_R_ = [J_task[:, :vc], 0] (task.cpp:119) or, for a COM task, [J_task[:, :vc], J_task[:, nc] J_I_nc_inv_T^T]
             // (task.cpp:109-110); CalculateJKT_R, Null_task_R_ chain (dwbc.cpp:3236-3246)

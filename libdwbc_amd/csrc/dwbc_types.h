@@ -25,6 +25,7 @@ constexpr int kMaxActiveContacts = 2; // simultaneously active 6D contacts the f
 constexpr int kMaxLevels = 4;
 constexpr int kMaxTaskLinks = 2;
 constexpr int kMaxTaskDof = 6;        // per level (one 6D link or two 3-dof links)
+constexpr int kMaxReducedDof = 24;    // reduced system: 6 + 12 contact-chain joints of two legs + 6 centroidal coordinates
 constexpr int kBodyStride = 25;       // doubles per body in the device model table
 
 // per-body record (doubles): R_T[9] p_T[3] axis[3] mass com[3] Icom[6]{xx,xy,xz,yy,yz,zz}
@@ -80,14 +81,19 @@ enum DiagField {
     DG_QP_NACT = 9,  // [kMaxLevels+1]
     DG_QP_ACT = 14,  // [kMaxLevels+1][12]
     DG_TIME = 14 + 5 * 12,  // [16] stage stamps (shader cycles since kernel start), only in the DWBC_STAGE_TIMERS build
+#ifdef DWBC_STAGE_TIMERS
+    DG_FTIME = 14 + 5 * 12 + 16,  // [64] fine-grained stamps of the diagnostic build (lean and full kernels alike)
+    DG_COUNT = 14 + 5 * 12 + 16 + 64
+#else
     DG_COUNT = 14 + 5 * 12 + 16
+#endif
 };
 
 // dump layout (doubles per instance) for the debug / facade getters; N = ndof, M = N-6, C = 12
 struct DumpLayout {
     int N, M;
     int A, A_inv, J_C, Lambda_c, J_C_INV_T, A_inv_N_C, W_inv, NwJw, Vb, G, P_C, link_R, link_p;
-    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, B, link_v, link_w, contact_pos, contact_rot, zmp, stamps, total;
+    int J_task, Lambda_task, J_kt, X, Y, fstar_qp, contact_qp, cf_redis, qp_viol, CMM, com, com_inertia, J_com, B, link_v, link_w, contact_pos, contact_rot, zmp, A_R_inv, A_R, G_R, J_I_nc, J_I_nc_inv_T, total;
     __host__ __device__ static DumpLayout make(int n) {
         DumpLayout d;
         d.N = n;
@@ -126,7 +132,12 @@ struct DumpLayout {
         d.contact_pos = o; o += kMaxActiveContacts * 3;  // cc_[i].xc_pos of the active contacts (contact_constraint.cpp:53)
         d.contact_rot = o; o += kMaxActiveContacts * 9;  // cc_[i].rotm
         d.zmp = o; o += 3 + kMaxActiveContacts * 3;      // getZMP(getContactForce(tau_total)), then cc_[i].zmp_pos (dwbc.cpp:898-939)
-        d.stamps = o; o += 64;  // fine-grained stage stamps (diagnostic build only)
+        // reduced (centroidal) model, written by the reduced cycle only (dwbc.cpp:2932-2988); RS <= kMaxReducedDof, row stride kMaxReducedDof
+        d.A_R_inv = o; o += kMaxReducedDof * kMaxReducedDof;
+        d.A_R = o; o += kMaxReducedDof * kMaxReducedDof;
+        d.G_R = o; o += kMaxReducedDof;
+        d.J_I_nc = o; o += 6 * (n - 12);          // 6 x nc_dof, row stride n - 12
+        d.J_I_nc_inv_T = o; o += 6 * (n - 12);    // 6 x nc_dof, row stride n - 12
         d.total = o;
         return d;
     }

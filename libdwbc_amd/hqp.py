@@ -90,9 +90,59 @@ class HQP:
         self._sizes[1] = (nb // (8 * self.B), self.contact_size_)
 
     def lqp_torque(self, wbc):
-        tau = np.zeros((self.B, wbc.m))
+        """B x m after configure_lqp; B x (RS - 6) after configure_lqp_r (chain torques, then the wrench on the centroidal coordinates)"""
+        tau = np.zeros((self.B, self.acceleration_size_ - 6))
         _check(self._L.dwbc_batch_lqp_torque(wbc._h, self._h, tau.ctypes.data))
         return tau
+
+    # ---- the reduced variants (src/dwbc.cpp:4455-4760, 3946-4302), after wbc.solve(reduced=True) with the dump on
+    @classmethod
+    def for_lqp_r(cls, wbc, reduced_system_dof, contact_dof, device=0):
+        """ConfigureLQP_R's object: y = [qddot_R (reduced_system_dof = vc_dof + 6); f_c]"""
+        return cls(wbc.B, reduced_system_dof, 0, contact_dof, device=device)
+
+    @classmethod
+    def for_nc(cls, wbc, nc_dof, device=0):
+        """ConfigureLQP_R_NC's / JACC_QP_R_NC's object: y = accelerations of the nc_dof non-contact joints"""
+        return cls(wbc.B, nc_dof, 0, 0, device=device)
+
+    def configure_lqp_r(self, wbc):
+        """RobotData::ConfigureLQP_R(hqp); then solveSequential() = CalcControlTorqueLQP_R"""
+        _check(self._L.dwbc_batch_configure_lqp_r(wbc._h, self._h))
+        n = self._L.dwbc_hqp_num_levels(self._h)
+        m = self.acceleration_size_ - 6
+        self._sizes = [(2 * m, 6), (self._L.dwbc_hqp_field_bytes(self._h, 1, V_ANS) // (8 * self.B), self.contact_size_)]
+        self._sizes += [(0, self._L.dwbc_hqp_field_bytes(self._h, i, W_ANS) // (8 * self.B)) for i in range(2, n)]
+
+    def configure_lqp_r_nc(self, wbc, hqp_r, level):
+        """RobotData::ConfigureLQP_R_NC(hqp_nc, q_acc) with q_acc = the answer of the solved reduced LQP `hqp_r`; `level`: the 6-D
+        task level on a non-contact link.  Then solvefirst() + solveSequential() = CalcControlTorqueLQP_R_NC"""
+        _check(self._L.dwbc_batch_configure_lqp_r_nc(wbc._h, self._h, hqp_r._h, int(level)))
+        nc = self.acceleration_size_
+        self._sizes = [(2 * nc, 6), (2 * nc, 6)]
+
+    def solve_jacc_r(self, wbc, level):
+        """CalcSingleTaskTorqueWithJACC_QP_R(ts_[level]); `level` counts the contact-chain levels; results: jacc_result(wbc, level)"""
+        _check(self._L.dwbc_batch_solve_jacc_r(wbc._h, self._h, int(level)))
+        self._sizes = []
+
+    def solve_jacc_r_nc(self, wbc, level, src_level):
+        """CalcSingleTaskTorqueWithJACC_QP_R_NC(ts_[level], acc_qp_ of the reduced JACC level src_level)"""
+        _check(self._L.dwbc_batch_solve_jacc_r_nc(wbc._h, self._h, int(level), int(src_level)))
+        self._sizes = []
+
+    def jacc_nc_result(self, wbc):
+        """dict(acc_qp, torque_qp, gacc_qp, f_star_qp, status) after solve_jacc_r_nc"""
+        nc = self.acceleration_size_
+        out = {}
+        for name, fid, width in (("acc_qp", 0, nc), ("torque_qp", 1, nc), ("gacc_qp", 2, 6), ("f_star_qp", 3, 6)):
+            a = np.zeros((self.B, width))
+            _check(self._L.dwbc_batch_get_jacc_nc(wbc._h, fid, a.ctypes.data, a.nbytes))
+            out[name] = a
+        st = np.zeros(self.B, np.int32)
+        _check(self._L.dwbc_batch_get_jacc_nc(wbc._h, 4, st.ctypes.data, st.nbytes))
+        out["status"] = st
+        return out
 
     # ---- RobotData::CalcSingleTaskTorqueWithJACC_QP(ts_[level], init) (src/dwbc.cpp:3772-3945); levels in order 0, 1, ...
     def solve_jacc(self, wbc, level):
@@ -100,12 +150,13 @@ class HQP:
         self._sizes = []
 
     @staticmethod
-    def jacc_result(wbc, level):
-        """dict(acc_qp, torque_qp, contact_qp, f_star_qp, status) of ts_[level] after solve_jacc"""
+    def jacc_result(wbc, level, system_dof=None):
+        """dict(acc_qp, torque_qp, contact_qp, f_star_qp, status) of ts_[level] after solve_jacc (system_dof = RS after solve_jacc_r)"""
         L = _lib.load()
         B = wbc.B
         out = {}
-        for name, fid, width in (("acc_qp", 0, wbc.n), ("torque_qp", 1, wbc.m), ("contact_qp", 2, 12), ("f_star_qp", 3, 6)):
+        n = wbc.n if system_dof is None else int(system_dof)
+        for name, fid, width in (("acc_qp", 0, n), ("torque_qp", 1, n - 6), ("contact_qp", 2, 12), ("f_star_qp", 3, 6)):
             a = np.zeros((B, width))
             _check(L.dwbc_batch_get_jacc(wbc._h, int(level), fid, a.ctypes.data, a.nbytes))
             out[name] = a

@@ -312,14 +312,16 @@ LQP_TAU_LIM = 200.0  # `tlim`, hard-coded in the reference (dwbc.cpp:4360)
 LQP_ACC_LIM = 5.0    # `alim` (dwbc.cpp:4398)
 
 
-def configure_lqp(c, B_nle, J_tasks, f_stars):
-    """c: dwbc_np.Cycle (A, A_inv, J_C, cone_matrix()); B_nle = RobotData::B_ (n); J_tasks / f_stars per task level"""
+def configure_lqp(c, B_nle, J_tasks, f_stars, cost_norm=None, tau_lim=None):
+    """c: dwbc_np.Cycle (A, A_inv, J_C, cone_matrix()); B_nle = RobotData::B_ (n); J_tasks / f_stars per task level.
+    cost_norm / tau_lim: what ConfigureLQP_R changes (the norm of the FULL A_ scales the cost, one torque limit is 600)"""
     n, m, cd = c.n, c.m, c.cdof
     nv = n + cd
     hqp = HQP()
     hqp.initialize(n, 0, cd)
     cost_h = np.zeros((nv, nv))
-    cost_h[:n, :n] = c.A / np.linalg.norm(c.A) * 5.0
+    cost_h[:n, :n] = c.A / (np.linalg.norm(c.A) if cost_norm is None else cost_norm) * 5.0
+    tl = np.full(m, LQP_TAU_LIM) if tau_lim is None else np.asarray(tau_lim, float)
     cost_g = np.zeros(nv)
     JCt = c.J_C.T
     # priority 1: torque limit (inequality), floating-base dynamics (equality); "solved" analytically
@@ -334,8 +336,8 @@ def configure_lqp(c, B_nle, J_tasks, f_stars):
     A[:m, n:] = JCt[6:]
     A[m:, :n] = -c.A[6:]
     A[m:, n:] = -JCt[6:]
-    a[:m] = -LQP_TAU_LIM + B_nle[6:]
-    a[m:] = -LQP_TAU_LIM - B_nle[6:]
+    a[:m] = -tl + B_nle[6:]
+    a[m:] = -tl - B_nle[6:]
     h0 = hqp.hqp_hs_[0]
     h0.updateConstraintMatrix(A, a, Bm, b)
     h0.normalizeConstraintMatrix()
@@ -385,27 +387,29 @@ def lqp_torque(c, B_nle, y):
 JACC_ACC_LIM, JACC_TAU_LIM = 10.0, 200.0
 
 
-def jacc_qp(c, level, J_tasks, f_stars, fqp_prev):
-    """c: dwbc_np.Cycle after update_kinematics / set_contact.  Returns (ok, acc_qp, torque_qp, contact_qp, f_star_qp, hqp)"""
+def jacc_qp(c, level, J_tasks, f_stars, fqp_prev, tau_rows=None):
+    """c: dwbc_np.Cycle after update_kinematics / set_contact.  Returns (ok, acc_qp, torque_qp, contact_qp, f_star_qp, hqp).
+    tau_rows: how many of the m torques carry the +-200 bound (JACC_QP_R: all but the six virtual ones, dwbc.cpp:4096-4097)"""
     n, m, cd = c.n, c.m, c.cdof
+    mt = m if tau_rows is None else tau_rows
     nv = n + cd
     JCt = c.J_C.T
     ncc = 10 * len(c.act_contacts)
     hq = HQP()
     hq.initialize(n, 0, cd)
     e0 = 6 + cd + sum(J_tasks[i].shape[0] for i in range(level))
-    hq.addHierarchy(ncc + 4 * m, e0)
-    A = np.zeros((ncc + 4 * m, nv))
-    a = np.zeros(ncc + 4 * m)
+    hq.addHierarchy(ncc + 2 * m + 2 * mt, e0)
+    A = np.zeros((ncc + 2 * m + 2 * mt, nv))
+    a = np.zeros(ncc + 2 * m + 2 * mt)
     A[:ncc, n:] = -c.cone_matrix()
     A[ncc : ncc + m, 6 : 6 + m] = np.eye(m)
     A[ncc + m : ncc + 2 * m, 6 : 6 + m] = -np.eye(m)
     a[ncc : ncc + 2 * m] = -JACC_ACC_LIM
-    D = np.hstack([c.A[6:], JCt[6:]])
-    A[ncc + 2 * m : ncc + 3 * m] = D
-    A[ncc + 3 * m :] = -D
-    a[ncc + 2 * m : ncc + 3 * m] = -JACC_TAU_LIM + c.G[6:]
-    a[ncc + 3 * m :] = -JACC_TAU_LIM - c.G[6:]
+    D = np.hstack([c.A[6 : 6 + mt], JCt[6 : 6 + mt]])
+    A[ncc + 2 * m : ncc + 2 * m + mt] = D
+    A[ncc + 2 * m + mt :] = -D
+    a[ncc + 2 * m : ncc + 2 * m + mt] = -JACC_TAU_LIM + c.G[6 : 6 + mt]
+    a[ncc + 2 * m + mt :] = -JACC_TAU_LIM - c.G[6 : 6 + mt]
     B = np.zeros((e0, nv))
     b = np.zeros(e0)
     B[:6, :n] = c.A[:6]
@@ -437,3 +441,124 @@ def jacc_qp(c, level, J_tasks, f_stars, fqp_prev):
     y = h1.y_ans_
     tau = c.A[6:] @ y[:n] + JCt[6:] @ y[n:] + c.G[6:]
     return ok, y[:n].copy(), tau, y[n:].copy(), J @ y[:n] - np.asarray(f_stars[level], float), hq
+
+
+# ----------------------------------------------------------------------------------------------
+# The same formulations on the REDUCED system (contact chains + 6 centroidal coordinates of the other bodies):
+#   RobotData::ConfigureLQP_R / CalcControlTorqueLQP_R              src/dwbc.cpp:4504-4632, 4455-4477
+#   RobotData::ConfigureLQP_R_NC / CalcControlTorqueLQP_R_NC        src/dwbc.cpp:4634-4760, 4479-4502
+#   RobotData::CalcSingleTaskTorqueWithJACC_QP_R                    src/dwbc.cpp:3946-4122
+#   RobotData::CalcSingleTaskTorqueWithJACC_QP_R_NC                 src/dwbc.cpp:4124-4302
+# The _R functions are the full-model ones with (A_, J_C, G_ / B_, J_task) replaced by (A_R, J_CR, G_R, J_task J_R_INV_T^T);
+# the differences are the arguments of configure_lqp / jacc_qp above.  PARITY UNPINNED like everything in this file; the
+# reference's only callers are the timing harnesses tests/sp_test/{jacc_compare, dof_comparison, dof_comparison_jacc}.cpp.
+# ----------------------------------------------------------------------------------------------
+LQP_R_TAU_LIM_SPECIAL = 600.0  # `tlim(tlim_size - 4) = 600`, src/dwbc.cpp:4552: the vertical centroidal force of the body group
+LQP_NC_TAU_LIM, LQP_NC_ACC_LIM = 200.0, 5.0  # src/dwbc.cpp:4666, 4744-4748
+JACC_NC_W_TASK = 5.0  # src/dwbc.cpp:4163
+
+
+class ReducedView:
+    """the reduced system of an oracle ReducedCycle (after reduced_dynamics / reduced_contact_constraint) under the names
+    configure_lqp / jacc_qp read from a Cycle"""
+
+    def __init__(self, r):
+        self.A, self.A_inv, self.J_C, self.G = r.A_R, r.A_R_inv, r.J_CR, r.G_R
+        self.n = r.r_sys_dof
+        self.m = r.r_model_dof
+        self.cdof = r.cdof
+        self.act_contacts = r.act_contacts
+        self.cone_matrix = r.cone_matrix
+
+
+def reduced_task_jacobians(r, J_tasks, noncont):
+    """J_task J_R_INV_T^T of the contact-chain levels (src/dwbc.cpp:4619), in level order"""
+    return [J @ r.J_R_INV_T.T for J, nc in zip(J_tasks, noncont) if not nc]
+
+
+def configure_lqp_r(r, J_tasks, f_stars, noncont):
+    """ConfigureLQP_R.  The reference writes hierarchy 2 + i for task i and so skips a slot when a non-contact level
+    precedes a contact-chain one (src/dwbc.cpp:4608-4626); here the contact-chain levels are packed in order."""
+    v = ReducedView(r)
+    tl = np.full(v.m, LQP_TAU_LIM)
+    tl[v.m - 4] = LQP_R_TAU_LIM_SPECIAL
+    Jr = reduced_task_jacobians(r, J_tasks, noncont)
+    fr = [f for f, nc in zip(f_stars, noncont) if not nc]
+    return configure_lqp(v, r.G_R, Jr, fr, cost_norm=np.linalg.norm(r.A), tau_lim=tl)
+
+
+def lqp_r_torque(r, y):
+    """A_R[6:] qdd_R + J_CR^T[6:] f_c + G_R[6:]: the rows ConfigureLQP_R bounds (12 chain torques + the 6-D wrench on the
+    centroidal coordinates)"""
+    v = ReducedView(r)
+    return lqp_torque(v, r.G_R, y)
+
+
+def _nc_task_local(r, J_task, f_star, link_pos, base_acc):
+    """fstar_local = Ja (f* - base acceleration), Ja = [[I, skew(x_link - x_pelvis)], [0, I]] (src/dwbc.cpp:4144-4147, 4728-4731)"""
+    d = np.asarray(link_pos, float) - r.p[0]
+    Ja = np.eye(6)
+    Ja[0:3, 3:6] = np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+    return Ja @ (np.asarray(f_star, float) - base_acc)
+
+
+def configure_lqp_r_nc(r, q_acc, J_task, f_star, link_pos):
+    """ConfigureLQP_R_NC for ONE 6-D non-contact level (the reference hard-codes ts_[1]).  q_acc: the reduced answer
+    [base 6 | chain joints | centroidal 6]."""
+    ncd, vcd = r.nc_dof, r.vc_dof
+    Ann = r.A[vcd:, vcd:]
+    Gn = r.G[vcd:]
+    hq = HQP()
+    hq.initialize(ncd, 0, 0)
+    cost = Ann / np.linalg.norm(Ann) * 5.0
+    hq.addHierarchy(2 * ncd, 6)
+    A = np.vstack([Ann, -Ann])
+    a = np.concatenate([-LQP_NC_TAU_LIM + Gn, -LQP_NC_TAU_LIM - Gn])
+    h0 = hq.hqp_hs_[0]
+    h0.updateConstraintMatrix(A, a, r.J_I_nc.copy(), -np.asarray(q_acc[-6:], float))
+    h0.updateCostMatrix(cost, np.zeros(ncd))
+    hq.addHierarchy(2 * ncd, 6)
+    A = np.vstack([np.eye(ncd), -np.eye(ncd)])
+    a = np.full(2 * ncd, -LQP_NC_ACC_LIM)
+    h1 = hq.hqp_hs_[1]
+    h1.updateConstraintMatrix(A, a, J_task[:, vcd:].copy(), -_nc_task_local(r, J_task, f_star, link_pos, np.asarray(q_acc[:6], float)))
+    h1.updateCostMatrix(cost, np.zeros(ncd))
+    hq.prepare()
+    return hq
+
+
+def solve_lqp_r_nc(hq):
+    """CalcControlTorqueLQP_R_NC: solvefirst, then the remaining levels"""
+    ok = hq.solvefirst()
+    for i in range(1, len(hq.hqp_hs_)):
+        ok = hq.solveSequentialSingle(i) and ok
+    return ok
+
+
+def jacc_qp_r(r, level, J_tasks, f_stars, fqp_prev):
+    """CalcSingleTaskTorqueWithJACC_QP_R; J_tasks: full-model Jacobians of the contact-chain levels"""
+    v = ReducedView(r)
+    Jr = [J @ r.J_R_INV_T.T for J in J_tasks]
+    return jacc_qp(v, level, Jr, f_stars, fqp_prev, tau_rows=v.m - 6)
+
+
+def jacc_qp_r_nc(r, prev_acc, J_task, f_star, link_pos):
+    """CalcSingleTaskTorqueWithJACC_QP_R_NC.  The bounds the reference prepares are removed again before the solve
+    (`DeleteSubjectToX`, src/dwbc.cpp:4277) and tau only appears in its own defining equality, so the problem is
+        min 1/2 |J_I_nc a - gacc_prev|^2 + 5/2 |J_task[:, nc] a - fstar_local|^2   over a (nc_dof),
+    under-determined (12 residuals, 21 unknowns): canon = least norm (Tikhonov HQP_EPS).
+    Returns (acc_qp, torque_qp, gacc_qp, f_star_qp)."""
+    ncd, vcd = r.nc_dof, r.vc_dof
+    fl = _nc_task_local(r, J_task, f_star, link_pos, np.asarray(prev_acc[:6], float))
+    t = J_task.shape[0]
+    w = np.sqrt(JACC_NC_W_TASK)
+    hq = HQP()
+    hq.initialize(ncd, 0, 0)
+    hq.addHierarchy(0, 6 + t)
+    B = np.vstack([r.J_I_nc, w * J_task[:, vcd:]])
+    b = -np.concatenate([np.asarray(prev_acc[-6:], float), w * fl])
+    hq.hqp_hs_[0].updateConstraintMatrix(None, None, B, b)
+    hq.prepare()
+    hq.solvefirst()
+    a = hq.hqp_hs_[0].y_ans_[:ncd].copy()
+    return a, r.A[vcd:, vcd:] @ a + r.G[vcd:], r.J_I_nc @ a - np.asarray(prev_acc[-6:], float), J_task[:, vcd:] @ a - fl, hq

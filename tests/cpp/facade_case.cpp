@@ -37,8 +37,13 @@ int main(int argc, char **argv) {
     rd_.AddContactConstraint(23, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.04, 0.04);
     rd_.AddContactConstraint(31, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.04, 0.04);
     rd_.AddTaskSpace(0, TASK_LINK_6D, 0, Vec3());
-    rd_.AddTaskSpace(1, TASK_LINK_ROTATION, "upperbody_link", Vec3());
-    const bool with_reduced = argc > 3 && std::string(argv[3]) == "reduced";
+    const bool lqp_r = argc > 3 && std::string(argv[3]) == "lqp_r";
+    if (lqp_r) {  // the reduced LQP / JACC harness shape: a 6-D task on a non-contact link (tests/sp_test/jacc_compare.cpp:456-487)
+        rd_.AddTaskSpace(1, TASK_LINK_6D, "upperbody_link", Vec3());
+        fstar_2 = Vec{0.05, -0.1, 0.02, fstar_2[0], fstar_2[1], fstar_2[2]};
+    } else
+        rd_.AddTaskSpace(1, TASK_LINK_ROTATION, "upperbody_link", Vec3());
+    const bool with_reduced = lqp_r || (argc > 3 && std::string(argv[3]) == "reduced");
     if (!with_reduced) rd_.SetTorqueLimit(Vec(rd_.model_dof_, 300.0));  // the reduced sequence runs without it (redu_dyn_test.cpp:63)
     rd_.UpdateKinematics(q, qdot, qddot);
     rd_.SetContact(true, true);
@@ -76,6 +81,27 @@ int main(int argc, char **argv) {
         print_vec("reduced_torque_grav_", rd_.torque_grav_);
         print_vec("reduced_torque_task_", rd_.torque_task_);
         print_vec("reduced_torque_contact_", rd_.torque_contact_);
+    }
+    if (lqp_r) {
+        // reference tests/sp_test/jacc_compare.cpp:456-487 and dof_comparison_jacc.cpp:358-362 through the facade
+        DWBC::HQP hqp_, hqp_nc_;
+        rd_.ReducedDynamicsCalculate();
+        int ok_cfg = rd_.ConfigureLQP_R(hqp_);
+        int ok_lqp = rd_.CalcControlTorqueLQP_R(hqp_, true);
+        int ok_ncc = rd_.ConfigureLQP_R_NC(hqp_nc_, hqp_, 1);
+        int ok_nc = rd_.CalcControlTorqueLQP_R_NC(hqp_nc_, true);
+        printf("\"lqp_r_ok\": [%d, %d, %d, %d, %d, %d],\n", ok_cfg, ok_lqp, ok_ncc, ok_nc, (int)hqp_.hqp_hs_.size(), (int)hqp_nc_.hqp_hs_.size());
+        printf("\"reduced_dims\": [%u, %u, %u, %u, %u],\n", rd_.vc_dof, rd_.nc_dof, rd_.co_dof, rd_.reduced_model_dof_, rd_.reduced_system_dof_);
+        print_vec("lqp_r_y", hqp_.hqp_hs_.back().y_ans_);
+        print_vec("lqp_r_torque", rd_.LQPTorque(hqp_));
+        print_vec("lqp_nc_y", hqp_nc_.hqp_hs_.back().y_ans_);
+        int ok_j = rd_.CalcSingleTaskTorqueWithJACC_QP_R(0);
+        int ok_jn = rd_.CalcSingleTaskTorqueWithJACC_QP_R_NC(1, 0);
+        printf("\"jacc_r_ok\": [%d, %d],\n", ok_j, ok_jn);
+        print_vec("jacc_r_acc", rd_.ts_[0].acc_qp_);
+        print_vec("jacc_r_torque", rd_.ts_[0].torque_qp_);
+        print_vec("jacc_nc_acc", rd_.ts_[1].acc_qp_);
+        print_vec("G_R", rd_.G_R);
     }
     if (argc > 3 && std::string(argv[3]) == "lqp") {
         // reference tests/sp_test/jacc_compare.cpp:386-418: ConfigureLQP, CalcControlTorqueLQP, torque of the answer

@@ -176,6 +176,82 @@ class EmuHQP:
         L.emu_jacc_solve(self.h, emu.h, len(act), act.ctypes.data, level, dump.ctypes.data, fstar.ctypes.data, ptrs, out.ctypes.data, st.ctypes.data)
         return out, st
 
+    # ---- reduced variants (ConfigureLQP_R, JACC_QP_R and the _NC halves): same device functions on the reduced record
+    @staticmethod
+    def reduced_record(emu, B, vcd, cd, src, dump):
+        L = lib(False)
+        L.emu_rrec_total.restype = C.c_int
+        L.emu_rrec_total.argtypes = [C.c_int]
+        L.emu_reduced_record.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        src = np.asarray(src, np.int32)
+        dump = np.ascontiguousarray(dump, np.float64)
+        rrec = np.zeros((B, L.emu_rrec_total(vcd + 6)))
+        L.emu_reduced_record(emu.h, B, vcd, cd, len(src), src.ctypes.data, dump.ctypes.data, rrec.ctypes.data)
+        return rrec
+
+    @staticmethod
+    def rrec_field(rrec, RS, name, shape):
+        L = lib(False)
+        L.emu_rrec_offset.restype = C.c_int
+        L.emu_rrec_offset.argtypes = [C.c_int, C.c_char_p]
+        off = L.emu_rrec_offset(RS, name.encode())
+        n = int(np.prod(shape))
+        return rrec[:, off : off + n].reshape((rrec.shape[0],) + tuple(shape))
+
+    def configure_lqp_r(self, emu, act, RS, src, rrec, fstar):
+        act = np.asarray(act, np.int32)
+        src = np.asarray(src, np.int32)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        self.L.emu_lqp_configure_r.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.emu_lqp_configure_r(self.h, emu.h, len(act), act.ctypes.data, RS, len(src), src.ctypes.data, rrec.ctypes.data, fstar.ctypes.data)
+
+    def lqp_torque_r(self, emu, act, RS, rrec):
+        act = np.asarray(act, np.int32)
+        tau = np.zeros((self.B, RS - 6))
+        self.L.emu_lqp_torque_r.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.L.emu_lqp_torque_r(self.h, emu.h, len(act), act.ctypes.data, RS, rrec.ctypes.data, tau.ctypes.data)
+        return tau
+
+    def jacc_solve_r(self, emu, act, RS, src, level, rrec, fstar, prev):
+        L = self.L
+        L.emu_jacc_rec_r.restype = C.c_int
+        L.emu_jacc_rec_r.argtypes = [C.c_int]
+        L.emu_jacc_solve_r.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        act = np.asarray(act, np.int32)
+        src = np.asarray(src, np.int32)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        prev = [np.ascontiguousarray(p, np.float64) for p in prev]
+        ptrs = (C.c_void_p * max(1, len(prev)))(*[p.ctypes.data for p in prev])
+        out = np.zeros((self.B, L.emu_jacc_rec_r(RS)))
+        st = np.zeros(self.B, np.int32)
+        L.emu_jacc_solve_r(self.h, emu.h, len(act), act.ctypes.data, RS, len(src), src.ctypes.data, level, rrec.ctypes.data, fstar.ctypes.data, ptrs, out.ctypes.data, st.ctypes.data)
+        return out, st
+
+    def configure_lqp_nc(self, emu, vcd, level, dump, fstar, prev, prev_off=0):
+        """prev: (B, stride) array whose columns prev_off.. hold the reduced answer [base 6 | chain | centroidal 6]"""
+        dump = np.ascontiguousarray(dump, np.float64)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        prev = np.ascontiguousarray(prev, np.float64)
+        self.L.emu_lqp_nc_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self.L.emu_lqp_nc_configure(self.h, emu.h, vcd, level, dump.ctypes.data, fstar.ctypes.data, prev.ctypes.data, prev.shape[1], prev_off)
+
+    def solve_levels(self, n_levels, solve_first):
+        self.L.emu_hqp_solve_levels.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.emu_hqp_solve_levels(self.h, n_levels, 1 if solve_first else 0)
+
+    def jacc_solve_nc(self, emu, vcd, level, dump, fstar, prev):
+        L = self.L
+        L.emu_jacc_nc_rec.restype = C.c_int
+        L.emu_jacc_nc_rec.argtypes = [C.c_int]
+        L.emu_jacc_nc_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        dump = np.ascontiguousarray(dump, np.float64)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        prev = np.ascontiguousarray(prev, np.float64)
+        out = np.zeros((self.B, L.emu_jacc_nc_rec(emu.n - vcd)))
+        st = np.zeros(self.B, np.int32)
+        L.emu_jacc_nc_solve(self.h, emu.h, vcd, level, dump.ctypes.data, fstar.ctypes.data, prev.ctypes.data, prev.shape[1], out.ctypes.data, st.ctypes.data)
+        return out, st
+
     def status(self, level):
         return self.stat[:, level]
 

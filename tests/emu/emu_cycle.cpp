@@ -77,7 +77,7 @@ int emu_dump_offset(EmuCtx *c, const char *name) {
     std::string n(name);
 #define F(x) if (n == #x) return d.x;
     F(A) F(A_inv) F(J_C) F(Lambda_c) F(J_C_INV_T) F(A_inv_N_C) F(W_inv) F(NwJw) F(Vb) F(G) F(P_C) F(link_R) F(link_p)
-    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com) F(B) F(link_v) F(link_w) F(contact_pos) F(contact_rot) F(zmp)
+    F(J_task) F(Lambda_task) F(J_kt) F(X) F(Y) F(fstar_qp) F(contact_qp) F(cf_redis) F(qp_viol) F(CMM) F(com) F(com_inertia) F(J_com) F(B) F(link_v) F(link_w) F(contact_pos) F(contact_rot) F(zmp) F(A_R_inv) F(A_R) F(G_R) F(J_I_nc) F(J_I_nc_inv_T)
 #undef F
     return -1;
 }
@@ -216,7 +216,31 @@ static LqpCfg emu_cfg(EmuCtx *c, int nc, const int *act) {
     for (int a = 0; a < nc; a++) { cfg.act[a] = act[a]; cfg.lx[a] = c->su.c_lx[act[a]]; cfg.ly[a] = c->su.c_ly[act[a]]; cfg.mu[a] = c->su.c_mu[act[a]]; cfg.muz[a] = c->su.c_muz[act[a]]; }
     cfg.oBn = dl.G;
     cfg.tlim = 200.0; cfg.alim = 5.0;
+    cfg.oNorm = -1; cfg.tlim_idx = -1; cfg.jacc_mt = cfg.n - 6;
     return cfg;
+}
+// the reduced system (record written by reduced_record_instance): contact-chain levels src[0..n_src) packed in order
+static LqpCfg emu_cfg_r(EmuCtx *c, int nc, const int *act, int RS, int n_src, const int *src) {
+    LqpCfg cfg = emu_cfg(c, nc, act);
+    const DumpLayout dr = DumpLayout::make(RS);
+    cfg.n = RS; cfg.n_tasks = n_src;
+    for (int i = 0; i < n_src; i++) { cfg.t_dof[i] = c->su.t_dof[src[i]]; cfg.fstar_off[i] = c->su.fstar_off[src[i]]; }
+    cfg.oBn = dr.G; cfg.oNorm = dr.com; cfg.tlim_idx = RS - 6 - 4; cfg.tlim_special = 600.0; cfg.jacc_mt = RS - 12;
+    return cfg;
+}
+int emu_rrec_total(int RS) { return DumpLayout::make(RS).total; }
+int emu_rrec_offset(int RS, const char *name) {
+    const DumpLayout d = DumpLayout::make(RS);
+    const std::string s(name);
+    if (s == "A") return d.A; if (s == "A_inv") return d.A_inv; if (s == "J_C") return d.J_C; if (s == "G") return d.G;
+    if (s == "J_task") return d.J_task; if (s == "com") return d.com;
+    return -1;
+}
+void emu_reduced_record(EmuCtx *c, int B, int vcd, int cd, int n_src, const int *src, const double *dump, double *rrec) {
+    ReducedRecCfg rc{};
+    rc.n = c->model.ndof; rc.vcd = vcd; rc.cd = cd; rc.n_src = n_src;
+    for (int i = 0; i < n_src; i++) { rc.src[i] = src[i]; rc.t_dof[i] = c->su.t_dof[src[i]]; }
+    for (int b = 0; b < B; b++) reduced_record_instance<1>(Thr{0}, rc, dump, rrec, b);
 }
 int emu_jacc_rec(EmuCtx *c) { return jacc_rec_size(c->model.ndof); }
 // CalcSingleTaskTorqueWithJACC_QP for one level: h must have been created with the two levels (152 | e0, 0 | t) and exact level 0;
@@ -235,14 +259,9 @@ void emu_jacc_solve(EmuHqp *h, EmuCtx *c, int nc, const int *act, int level, con
 }
 // RobotData::ConfigureLQP from a dump record (B x DumpLayout::total doubles) + f*, then the cascade and the LQP torque
 void emu_lqp_configure(EmuHqp *h, EmuCtx *c, int nc, const int *act, int use_B, const double *dump, const double *fstar) {
-    LqpCfg cfg{};
-    cfg.n = c->model.ndof; cfg.nc = nc; cfg.cd = 6 * nc; cfg.n_tasks = c->su.n_levels;
+    LqpCfg cfg = emu_cfg(c, nc, act);
     const DumpLayout dl = DumpLayout::make(cfg.n);
-    for (int i = 0; i < c->su.n_levels; i++) { cfg.t_dof[i] = c->su.t_dof[i]; cfg.fstar_off[i] = c->su.fstar_off[i]; }
-    cfg.fstar_total = c->su.fstar_total;
-    for (int a = 0; a < nc; a++) { cfg.act[a] = act[a]; cfg.lx[a] = c->su.c_lx[act[a]]; cfg.ly[a] = c->su.c_ly[act[a]]; cfg.mu[a] = c->su.c_mu[act[a]]; cfg.muz[a] = c->su.c_muz[act[a]]; }
     cfg.oBn = use_B ? dl.B : dl.G;
-    cfg.tlim = 200.0; cfg.alim = 5.0;
     HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
     for (int b = 0; b < h->B; b++) lqp_configure_instance<1>(Thr{0}, cfg, h->d, io, dump, fstar, b);
 }
@@ -253,5 +272,61 @@ void emu_lqp_torque(EmuHqp *h, EmuCtx *c, int nc, int use_B, const double *dump,
     cfg.oBn = use_B ? dl.B : dl.G;
     HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
     for (int b = 0; b < h->B; b++) lqp_torque_instance<1>(Thr{0}, cfg, h->d, io, dump, tau, b);
+}
+// ---- the reduced variants: the same device functions on the record of emu_reduced_record
+void emu_lqp_configure_r(EmuHqp *h, EmuCtx *c, int nc, const int *act, int RS, int n_src, const int *src, const double *rrec, const double *fstar) {
+    const LqpCfg cfg = emu_cfg_r(c, nc, act, RS, n_src, src);
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    for (int b = 0; b < h->B; b++) lqp_configure_instance<1>(Thr{0}, cfg, h->d, io, rrec, fstar, b);
+}
+void emu_lqp_torque_r(EmuHqp *h, EmuCtx *c, int nc, const int *act, int RS, const double *rrec, double *tau) {
+    const LqpCfg cfg = emu_cfg_r(c, nc, act, RS, 0, nullptr);
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    for (int b = 0; b < h->B; b++) lqp_torque_instance<1>(Thr{0}, cfg, h->d, io, rrec, tau, b);
+}
+int emu_jacc_rec_r(int RS) { return jacc_rec_size(RS); }
+void emu_jacc_solve_r(EmuHqp *h, EmuCtx *c, int nc, const int *act, int RS, int n_src, const int *src, int level, const double *rrec, const double *fstar,
+                      const double *const *prev, double *out, int *status) {
+    const LqpCfg cfg = emu_cfg_r(c, nc, act, RS, n_src, src);
+    JaccPrev pv{};
+    for (int i = 0; i < level; i++) pv.rec[i] = prev[i];
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    std::vector<double> lds(h->d.lds + 16);
+    for (int b = 0; b < h->B; b++) {
+        jacc_configure_instance<1>(Thr{0}, cfg, level, pv, h->d, io, rrec, fstar, b);
+        hqp_instance<1>(Thr{0}, h->d, io, b, lds.data());
+        jacc_extract_instance<1>(Thr{0}, cfg, level, h->d, io, rrec, fstar, out, status, b);
+    }
+}
+static NcCfg emu_nc(EmuCtx *c, int vcd, int level, int prev_stride, int prev_off) {
+    NcCfg n{};
+    n.n = c->model.ndof; n.vcd = vcd; n.level = level; n.link = c->su.t_link[level][0]; n.t = c->su.t_dof[level];
+    n.fstar_off = c->su.fstar_off[level]; n.fstar_total = c->su.fstar_total; n.prev_stride = prev_stride; n.prev_off = prev_off;
+    return n;
+}
+void emu_lqp_nc_configure(EmuHqp *h, EmuCtx *c, int vcd, int level, const double *dump, const double *fstar, const double *prev, int prev_stride, int prev_off) {
+    const NcCfg n = emu_nc(c, vcd, level, prev_stride, prev_off);
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    for (int b = 0; b < h->B; b++) lqp_nc_configure_instance<1>(Thr{0}, n, h->d, io, dump, fstar, prev, b);
+}
+void emu_hqp_solve_levels(EmuHqp *h, int n_levels, int solve_first) {  // HQP::solvefirst = (1, 1); solveSequential = (all, 0)
+    HqpDesc d = h->d;
+    d.n_levels = n_levels; d.solve_first = solve_first;
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    std::vector<double> lds(h->d.lds + 16);
+    for (int b = 0; b < h->B; b++) hqp_instance<1>(Thr{0}, d, io, b, lds.data());
+}
+int emu_jacc_nc_rec(int ncd) { return jacc_nc_rec_size(ncd); }
+void emu_jacc_nc_solve(EmuHqp *h, EmuCtx *c, int vcd, int level, const double *dump, const double *fstar, const double *prev, int prev_stride, double *out, int *status) {
+    const NcCfg n = emu_nc(c, vcd, level, prev_stride, 0);
+    HqpDesc d = h->d;
+    d.solve_first = 1;
+    HqpIO io{h->B, h->rec.data(), h->scratch.data(), h->stat.data()};
+    std::vector<double> lds(h->d.lds + 16);
+    for (int b = 0; b < h->B; b++) {
+        jacc_nc_configure_instance<1>(Thr{0}, n, d, io, dump, fstar, prev, b);
+        hqp_instance<1>(Thr{0}, d, io, b, lds.data());
+        jacc_nc_extract_instance<1>(Thr{0}, n, d, io, dump, fstar, prev, out, status, b);
+    }
 }
 }

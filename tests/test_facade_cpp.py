@@ -80,3 +80,26 @@ def test_facade_lqp_sequence():
     y = np.asarray(r["lqp_y"])
     assert (np.abs(y - hq.hqp_hs_[-1].y_ans_) / (1 + np.abs(y))).max() < 1e-6
     assert np.abs(np.asarray(r["lqp_torque"]) - tau).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_facade_reduced_lqp_and_jacc_sequence():
+    """ConfigureLQP_R / CalcControlTorqueLQP_R, ConfigureLQP_R_NC / CalcControlTorqueLQP_R_NC, CalcSingleTaskTorqueWithJACC_QP_R
+    and _R_NC (reference tests/sp_test/jacc_compare.cpp:456-487, dof_comparison_jacc.cpp:358-362) through the facade, against the
+    numpy restatement on the CASE 1 state."""
+    from tests.test_hqp_reduced import _oracle, _rel
+
+    _build()
+    out = subprocess.check_output([EXE, cases.URDF, "1", "lqp_r"], text=True)
+    r = json.loads(out[out.index("{"):])
+    assert r["lqp_r_ok"] == [1, 1, 1, 1, 3, 2] and r["jacc_r_ok"] == [1, 1] and r["reduced_dims"] == [18, 21, 12, 18, 24]
+    q = np.array(cases.Q_CASE[1])
+    f1 = list(cases.FSTAR_CASE[1][1])
+    fs = np.array(list(cases.FSTAR_CASE[1][0]) + [0.05, -0.1, 0.02] + f1)
+    o = _oracle(q, fs)
+    assert _rel(np.asarray(r["lqp_r_y"]), o["lqp"].hqp_hs_[-1].y_ans_) < 2e-6
+    assert _rel(np.asarray(r["lqp_r_torque"]), o["lqp_tau"]) < 1e-4
+    assert _rel(np.asarray(r["lqp_nc_y"]), o["nc"].hqp_hs_[-1].y_ans_) < 1e-4
+    assert _rel(np.asarray(r["jacc_r_acc"]), o["jacc"]["acc"]) < 1e-5 and _rel(np.asarray(r["jacc_r_torque"]), o["jacc"]["tau"]) < 1e-3
+    assert _rel(np.asarray(r["jacc_nc_acc"]), o["jacc_nc"]["acc"]) < 1e-4
+    assert np.abs(np.asarray(r["G_R"]) - o["r"].G_R).max() < 1e-8
