@@ -6,10 +6,10 @@ thin Python host layer over that ABI.  It fails loudly when the library or a GPU
 from .batch import (  # noqa: F401
     CONTACT_6D, TASK_LINK_6D, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME, TASK_LINK_POSITION,
     TASK_LINK_POSITION_COM_FRAME, TASK_LINK_POSITION_CUSTOM_FRAME, TASK_LINK_ROTATION, TASK_LINK_ROTATION_CUSTOM_FRAME,
-    Batch, DwbcError, Model,
+    Batch, DwbcError, Model, build_pack,
 )
 
 from .rl_bridge import RlWBCBridge  # noqa: F401,E402
 from .hqp import HQP  # noqa: F401,E402
 
-__all__ = ["Batch", "Model", "DwbcError", "RlWBCBridge", "HQP"]
+__all__ = ["Batch", "Model", "DwbcError", "RlWBCBridge", "HQP", "build_pack"]

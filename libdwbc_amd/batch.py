@@ -44,6 +44,21 @@ def _check(ok):
         raise DwbcError(_lib.last_error())
 
 
+def build_pack(model_or_ndof, nb=None, quiet=True):
+    """Compile the cycle kernels for a model size other than TOCABI's (libdwbc_amd/csrc/dwbc_pack.hip -> libdwbc_pack_<N>_<NB>.so next
+    to libdwbc_hip.so; about two minutes with hipcc, nothing to do when it is up to date).  dwbc_batch_create loads it by itself."""
+    import os
+    import subprocess
+
+    if nb is None:
+        n, nb = int(model_or_ndof.ndof), int(model_or_ndof.nb)
+    else:
+        n, nb = int(model_or_ndof), int(nb)
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    subprocess.check_call(["make", "-C", csrc, "pack", f"N={n}", f"NB={nb}"], stdout=subprocess.DEVNULL if quiet else None)
+    return os.path.join(os.path.dirname(csrc), f"libdwbc_pack_{n}_{nb}.so")
+
+
 class Model:
     def __init__(self, handle):
         self._L = _lib.load()

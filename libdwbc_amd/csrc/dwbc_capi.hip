@@ -1,11 +1,13 @@
 // dwbc_capi.hip -- C-ABI (include/dwbc_batch.h) + kernel launch for the MI355X-native batched libdwbc hot path.
 // gfx950 only.  No CPU fallback: every compute entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "dwbc_kernels.h"
@@ -106,19 +108,76 @@ int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, do
     return 1;
 }
 
+// ---- kernel packs: the cycle kernels of model sizes other than TOCABI's (dwbc_pack.hip), loaded on demand
+namespace {
+struct KernelPack { void *dl; const KernelEntry *tab; int count; };
+std::vector<KernelPack> g_packs;
+std::mutex g_pack_mutex;
+bool builtin_has(int n, int nb) {
+    for (const auto &k : kKernels)
+        if (k.n == n && k.nb == nb) return true;
+    return false;
+}
+const KernelEntry *pack_lookup(int n, int nb, int nlv) {
+    std::lock_guard<std::mutex> lk(g_pack_mutex);
+    for (const auto &p : g_packs)
+        for (int i = 0; i < p.count; i++)
+            if (p.tab[i].n == n && p.tab[i].nb == nb && (nlv < 0 || p.tab[i].nlv == nlv)) return &p.tab[i];
+    return nullptr;
+}
+static std::string lib_dir_impl() {
+    Dl_info di;
+    if (dladdr((const void *)&builtin_has, &di) && di.dli_fname) {
+        std::string f(di.dli_fname);
+        const size_t s = f.rfind('/');
+        return s == std::string::npos ? std::string(".") : f.substr(0, s);
+    }
+    return ".";
+}
+// true when kernels for (n, nb) exist: built in, already loaded, or in a pack next to this library / under $DWBC_PACK_DIR
+bool ensure_kernels(int n, int nb, std::string &err) {
+    if (builtin_has(n, nb) || pack_lookup(n, nb, -1)) return true;
+    const std::string name = "libdwbc_pack_" + std::to_string(n) + "_" + std::to_string(nb) + ".so";
+    std::vector<std::string> dirs;
+    if (const char *e = getenv("DWBC_PACK_DIR")) dirs.push_back(e);
+    dirs.push_back(lib_dir_impl());
+    std::string tried;
+    for (const auto &d : dirs) {
+        const std::string path = d + "/" + name;
+        void *dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!dl) { tried += " " + path; continue; }
+        typedef const KernelEntry *(*table_fn)(int *, unsigned *);
+        table_fn tf = (table_fn)dlsym(dl, "dwbc_pack_table");
+        int count = 0;
+        unsigned tag = 0;
+        const KernelEntry *tab = tf ? tf(&count, &tag) : nullptr;
+        if (!tab || tag != kernel_abi_tag()) {
+            dlclose(dl);
+            err = path + " was built from another version of the kernels: rebuild it (make -C libdwbc_amd/csrc pack N=" + std::to_string(n) + " NB=" + std::to_string(nb) + ")";
+            return false;
+        }
+        std::lock_guard<std::mutex> lk(g_pack_mutex);
+        g_packs.push_back(KernelPack{dl, tab, count});
+        return true;
+    }
+    err = "no kernel for a model with " + std::to_string(n) + " dof / " + std::to_string(nb) + " bodies: the cycle kernels are compiled per model size; build the pack once with"
+          " `make -C libdwbc_amd/csrc pack N=" + std::to_string(n) + " NB=" + std::to_string(nb) + "` (Python: libdwbc_amd.build_pack(model)); looked for" + tried;
+    return false;
+}
+}  // namespace
+
 dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype) {
     if (!m || B < 1) { g_err = "bad arguments"; return nullptr; }
     if (dtype != DWBC_F64 && dtype != DWBC_F32) { g_err = "dtype must be DWBC_F64 or DWBC_F32"; return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device: libdwbc_hip has no CPU path"; return nullptr; }
     if (device < 0 || device >= ndev) { g_err = "bad device index"; return nullptr; }
-    const KernelEntry *ke = nullptr;
-    for (const auto &k : kKernels)
-        if (k.n == m->m.ndof && k.nb == m->m.nb) ke = &k;
-    if (!ke) {
-        g_err = "no kernel instantiated for a model with " + std::to_string(m->m.ndof) + " dof / " + std::to_string(m->m.nb) + " bodies";
+    if (m->m.ndof != m->m.nb + 5 || m->m.ndof > 50 || m->m.nb > kMaxBodies) {
+        g_err = "model outside the kernels' range (floating base + one revolute joint per body, at most 50 dof)";
         return nullptr;
     }
+    if (!ensure_kernels(m->m.ndof, m->m.nb, g_err)) return nullptr;
+    if (dtype == DWBC_F32 && !builtin_has(m->m.ndof, m->m.nb)) { g_err = "kernel packs are fp64 only"; return nullptr; }
     auto *b = new dwbc_batch();
     b->model = m;
     b->B = B;
@@ -126,7 +185,7 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
     b->dtype = dtype;
     b->n = m->m.ndof;
     b->m = b->n - 6;
-    b->kern = ke;
+    b->kern = nullptr;  // picked at the first solve (pick_kernel: the level count is not known yet)
     b->dl = DumpLayout::make(b->n);
     setup_init(b->su, m->m.nb, b->n, m->m.maxdepth);
     auto bad = [&](const char *what, hipError_t e) {
@@ -426,7 +485,8 @@ static bool lean_ok(const dwbc_batch *b) {
 
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
-    return lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind);
+    if (const KernelEntry *ke = lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind)) return ke;
+    return reduced ? nullptr : pack_lookup(b->n, b->su.nb, b->su.n_levels);  // packs hold the full-model cycle only
 }
 
 // fp32 launch: the fp32 kernels read and write the double buffers of the boundary themselves (io_t); only the model table is

@@ -58,8 +58,10 @@ struct KernelEntry {
     void (*fn_wide_lean)(const Setup, const BatchIO);
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
-// flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).
-#ifdef DWBC_EXPERIMENT
+// flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).  Other model sizes come
+// from kernel packs (dwbc_pack.hip: this header instantiated for one (N, NB), loaded by the C-ABI at model-load time).
+#ifdef DWBC_PACK_N
+#elif defined(DWBC_EXPERIMENT)
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
     {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
@@ -94,6 +96,7 @@ const KernelEntry kKernelsReduced[] = {
     {39, 34, 4, 0, dwbc_cycle_kernel_reduced<39, 34, 4, kNT, TopoGeneric>, LdsR<39, 34, 4>::total_bytes, nullptr, nullptr, nullptr},
 };
 #endif
+#ifndef DWBC_PACK_N
 // which: 0 = full-model kernel, 2 = reduced dynamics
 // topo: Setup::topo_kind of the loaded model -- an instantiation for that constant tree is preferred, else the generic one
 inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which, int topo) {
@@ -109,5 +112,9 @@ inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which, int t
     }
     return nullptr;
 }
+#endif
+
+// what a pack and the library that loads it must agree on (both are built from this header)
+inline unsigned kernel_abi_tag() { return (unsigned)(sizeof(Setup) * 2654435761u) ^ (unsigned)(sizeof(BatchIO) * 40503u) ^ (unsigned)(DG_COUNT * 97u) ^ (unsigned)sizeof(KernelEntry); }
 
 }  // namespace dwbc

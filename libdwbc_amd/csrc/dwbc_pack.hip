@@ -1,0 +1,30 @@
+// dwbc_pack.hip -- the fused cycle kernels for ONE model size other than TOCABI's, as a loadable pack:
+//   hipcc ... -DDWBC_PACK_N=<system dof> -DDWBC_PACK_NB=<bodies> -shared -o ../libdwbc_pack_<N>_<NB>.so dwbc_pack.hip
+// (`make pack N=.. NB=..`; libdwbc_amd.build_pack(model) from Python).  The reference is model-generic (any URDF RBDL reads:
+// src/dwbc.cpp:140-277, tests/dof_test/*.urdf); here the kernels keep their matrices in registers, so the sizes are template
+// arguments and each (N, NB) is compiled once.  TopoGeneric build (dense A^-1 sweep), fp64, full-model cycle; the reduced
+// (centroidal) path is laid out for TOCABI's tree and is not part of a pack.  dwbc_batch_create() dlopens the pack of the
+// loaded model's size from the directory of libdwbc_hip.so (or $DWBC_PACK_DIR).
+#ifndef DWBC_PACK_N
+#error "compile with -DDWBC_PACK_N=<system dof> -DDWBC_PACK_NB=<bodies>"
+#endif
+#include "dwbc_kernels.h"
+
+using namespace dwbc;
+
+static_assert(DWBC_PACK_N == DWBC_PACK_NB + 5, "floating base (6 dof) + one revolute joint per further body");
+static_assert(DWBC_PACK_N <= 50, "one lane per column, and the wave QP keeps (N - 6) + 20 rows on 64 lanes");
+static_assert(DWBC_PACK_NB <= kMaxBodies, "body table");
+
+#define DWBC_PACK_ENTRY(NLV)                                                                                                        \
+    {DWBC_PACK_N, DWBC_PACK_NB, NLV, 0, dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, TopoGeneric>,                \
+     Lds2<DWBC_PACK_N, DWBC_PACK_NB, NLV>::total_bytes, dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, TopoGeneric>, \
+     dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>,                                                  \
+     dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>}
+static const KernelEntry kPack[] = {DWBC_PACK_ENTRY(1), DWBC_PACK_ENTRY(2), DWBC_PACK_ENTRY(3), DWBC_PACK_ENTRY(4)};
+
+extern "C" const KernelEntry *dwbc_pack_table(int *count, unsigned *abi_tag) {
+    *count = (int)(sizeof(kPack) / sizeof(kPack[0]));
+    *abi_tag = kernel_abi_tag();
+    return kPack;
+}

@@ -27,6 +27,7 @@ def lib(f32=False):
         L.emu_dump_offset.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.emu_run_reduced.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.emu_run_other.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         _libs[f32] = L
     return _libs[f32]
 
@@ -93,7 +94,8 @@ class Emu:
         tr = None if traj is None else np.ascontiguousarray(traj, np.float64)
         ct = None if ctime is None else np.ascontiguousarray(ctime, np.float64)
         self.L.emu_set_traj_data(C.c_void_p(tr.ctypes.data if tr is not None else None), C.c_void_p(ct.ctypes.data if ct is not None else None))
-        ok = (self.L.emu_run_reduced if reduced else self.L.emu_run)(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
+        other = (self.n, self.nb) != (39, 34)  # the kernel-pack sizes: emu_run_other
+        ok = (self.L.emu_run_other if other else self.L.emu_run_reduced if reduced else self.L.emu_run)(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data,
                             st.ctypes.data, diag.ctypes.data, dmp.ctypes.data if dump else None)
         assert ok == 1, self.L.emu_error(self.h)
         return dict(tau=tau, wrench=wr, status=st, diag=diag, dump=dmp)

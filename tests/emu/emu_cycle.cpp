@@ -171,6 +171,33 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     return 1;
 }
 
+// ---- other model sizes (the kernel packs of dwbc_pack.hip): the same source instantiated for (37, 32) and (23, 18), two task
+//      levels, TopoGeneric -- the sizes tests/test_model_packs.py builds from the TOCABI fixture
+}  // extern "C"
+template <int N, int NB>
+static void emu_run_size(EmuCtx *c, BatchIO &io, int B) {
+    std::vector<real_t> lds(Lds2<N, NB, 2>::total + 64);
+    std::vector<int> ilds(64);
+    for (int b = 0; b < B; b++) cycle_instance_v2<N, NB, 2, 1, true, TopoGeneric>(Thr{0}, c->su, io, b, lds.data(), ilds.data());
+}
+extern "C" {
+int emu_run_other(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
+                  int *status, int *diag, double *dump) {
+    const int n = c->model.ndof, nb = c->model.nb;
+    if (c->su.n_levels != 2) { c->err = "emu_run_other: two task levels"; return 0; }
+    const size_t D = DumpLayout::make(n).total;
+    auto rb = to_real(c->body.data(), c->body.size());
+    std::vector<real_t> rdump(dump ? (size_t)B * D : 0);
+    BatchIO io{};
+    io.B = B; io.q = q; io.flags = flags; io.fstar = fstar; io.tau = tau; io.wrench = wrench; io.status = status;
+    io.diag = diag; io.dump = dump ? rdump.data() : nullptr; io.body = rb.data(); io.topo = c->topo.data(); io.hqp = 1;
+    if (n == 37 && nb == 32) emu_run_size<37, 32>(c, io, B);
+    else if (n == 23 && nb == 18) emu_run_size<23, 18>(c, io, B);
+    else { c->err = "emu_run_other: instantiated for (37, 32) and (23, 18)"; return 0; }
+    from_real(rdump, dump);
+    return 1;
+}
+
 // ---- generic HQP class (dwbc_hqp.h): levels described by (m, e, has_cost); per-instance records laid out by hqp_layout()
 struct EmuHqp {
     HqpDesc d;
