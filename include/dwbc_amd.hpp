@@ -59,6 +59,7 @@ using dwbc_amd::Mat;
 using dwbc_amd::Vec;
 using dwbc_amd::Vec3;
 
+enum { JOINT_FLOATING_BASE, JOINT_6DOF, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FIXED };  // dwbc_link.h:12-19 (AddLink's joint_type)
 enum CONTACT_TYPE { CONTACT_6D = 0, CONTACT_POINT = 1, CONTACT_LINK = 2, CONTACT_LINE = 3 };  // dwbc_contact_constraint.h:19-25
 enum TASK_LINK_MODE {                                                                          // dwbc_task.h:23-33
     TASK_LINK_6D = 0, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME, TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME,
@@ -195,9 +196,26 @@ class RobotData {
     // ---- RobotData::LoadModelData (dwbc.h:237)
     void LoadModelData(std::string urdf_path, bool floating, int verbose = 0, int device = 0) {
         release();
-        model_ = dwbc_model_create_from_urdf(urdf_path.c_str(), floating ? 1 : 0);
+        device_ = device;
+        adopt_model(dwbc_model_create_from_urdf(urdf_path.c_str(), floating ? 1 : 0), floating, verbose);
+    }
+    // ---- init-time model surgery (dwbc.h:206-226; src/dwbc.cpp:1764-2382, 2707-2730), BEFORE contacts and task spaces are added
+    //      (link ids move).  The edited model needs the kernel pack of its size (`make -C libdwbc_amd/csrc pack N=.. NB=..`).
+    void DeleteLink(std::string link_name, bool verbose = false) { DeleteLink(getLinkID(link_name), verbose); }
+    void DeleteLink(int link_idx, bool verbose = false) { if (model_) replace_model(dwbc_model_delete_link(model_, link_idx), verbose); }
+    void AddLink(int parent_link_id, const char *link_name, int joint_type, const Vec3 &joint_axis, const Mat &joint_rotm, const Vec3 &joint_trans, double body_mass,
+                 const Vec3 &com_position, const Mat &inertia, bool verbose = false) {
+        if (model_) replace_model(dwbc_model_add_link(model_, parent_link_id, link_name, joint_type == JOINT_FIXED ? 0 : (joint_type == JOINT_REVOLUTE ? 1 : -1), joint_axis.v,
+                                                      joint_rotm.d.data(), joint_trans.v, body_mass, com_position.v, inertia.d.data()), verbose);
+    }
+    void ChangeLinkToFixedJoint(std::string link_name, bool verbose = false) { if (model_) replace_model(dwbc_model_change_link_to_fixed_joint(model_, getLinkID(link_name)), verbose); }
+    void ChangeLinkInertia(std::string link_name, const Mat &com_inertia, const Vec3 &com_position, double com_mass, bool verbose = false) {
+        if (model_) replace_model(dwbc_model_change_link_inertia(model_, getLinkID(link_name), com_inertia.d.data(), com_position.v, com_mass), verbose);
+    }
+    void adopt_model(dwbc_model *m, bool floating, int verbose) {
+        model_ = m;
         if (!model_) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
-        batch_ = dwbc_batch_create(model_, 1, device, DWBC_F64);
+        batch_ = dwbc_batch_create(model_, 1, device_, DWBC_F64);
         if (!batch_) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
         dwbc_batch_enable_dump(batch_, 1);
         is_floating_ = floating;
@@ -455,10 +473,20 @@ class RobotData {
     int diag_[96] = {0};
     Vec tau_contact_final_;
 
+    int device_ = 0;
     void release() {
         if (batch_) dwbc_batch_destroy(batch_);
         if (model_) dwbc_model_destroy(model_);
         batch_ = nullptr; model_ = nullptr;
+    }
+    void replace_model(dwbc_model *edited, bool verbose) {
+        if (!edited) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        if (!cc_.empty() || !ts_.empty()) std::cout << "libdwbc_amd : model surgery after AddContactConstraint / AddTaskSpace: they are cleared (link ids moved)" << std::endl;
+        cc_.clear(); ts_.clear();
+        const bool fl = is_floating_;
+        release();
+        dirty_ = true; contact_ok_ = true;
+        adopt_model(edited, fl, verbose ? 1 : 0);
     }
     Mat fetch(int field, int r, int c, int src_cols = -1) {
         size_t nb = dwbc_batch_field_bytes(batch_, field);

@@ -118,6 +118,24 @@ int dwbc_model_link_id(const dwbc_model *m, const char *name); /* case-insensiti
 const char *dwbc_model_link_name(const dwbc_model *m, int link);
 int dwbc_model_get_arrays(const dwbc_model *m, int32_t *parent, double *R_T, double *p_T, double *axis, double *mass,
                           double *com, double *inertia);
+/* ---- init-time model surgery (reference include/dwbc.h:206-226, src/dwbc.cpp:1764-2382, 2707-2730).  Each call returns a NEW
+ * model (NULL + dwbc_last_error on refusal) and leaves its argument alone: destroy both when done.  A model of another size
+ * runs on its own kernel pack (`make -C libdwbc_amd/csrc pack N=.. NB=..`).
+ *   DeleteLink(link)                  the link and all its descendants; the links after them move down
+ *   AddLink(parent, name, joint_type, axis, joint_rotm, joint_trans, mass, com, inertia)
+ *                                     joint_type 0 = JOINT_FIXED: the body is joined to the parent link (RBDL Body::Join), no new link;
+ *                                     1 = JOINT_REVOLUTE: a new LAST link whose joint is the last coordinate -- accepted when the parent
+ *                                     is the last link or one of its ancestors (the kernels need the depth-first numbering kept)
+ *   ChangeLinkToFixedJoint(link)      = DeleteLink(link) + AddLink(fixed) of the link's own body, as the reference does it
+ *                                     (src/dwbc.cpp:2360-2382: the link's descendants are deleted with it)
+ *   ChangeLinkInertia(link, com_inertia, com_position, com_mass)
+ * joint_rotm: 3x3 row-major rotation child -> parent of the joint frame, joint_trans its origin in the parent frame */
+dwbc_model *dwbc_model_delete_link(const dwbc_model *m, int link);
+dwbc_model *dwbc_model_add_link(const dwbc_model *m, int parent_link, const char *link_name, int joint_type, const double *joint_axis,
+                                const double *joint_rotm, const double *joint_trans, double body_mass, const double *com_position,
+                                const double *inertia);
+dwbc_model *dwbc_model_change_link_to_fixed_joint(const dwbc_model *m, int link);
+dwbc_model *dwbc_model_change_link_inertia(const dwbc_model *m, int link, const double *com_inertia, const double *com_position, double com_mass);
 
 /* ---- batch of B RobotData instances sharing one model and one contact/task setup ---- */
 dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype);

@@ -24,6 +24,10 @@ SYMBOLS = [
     ("dwbc_model_link_id", _i, [_vp, _cp]),
     ("dwbc_model_link_name", _cp, [_vp, _i]),
     ("dwbc_model_get_arrays", _i, [_vp] + [_vp] * 7),
+    ("dwbc_model_delete_link", _vp, [_vp, _i]),
+    ("dwbc_model_add_link", _vp, [_vp, _i, C.c_char_p, _i, _vp, _vp, _vp, C.c_double, _vp, _vp]),
+    ("dwbc_model_change_link_to_fixed_joint", _vp, [_vp, _i]),
+    ("dwbc_model_change_link_inertia", _vp, [_vp, _i, _vp, _vp, C.c_double]),
     ("dwbc_batch_create", _vp, [_vp, _i, _i, _i]),
     ("dwbc_batch_destroy", None, [_vp]),
     ("dwbc_batch_size", _i, [_vp]),

@@ -89,6 +89,36 @@ class Model:
     def link_id(self, name):
         return self._L.dwbc_model_link_id(self._h, name.encode())
 
+    # ---- init-time model surgery (RobotData::DeleteLink / AddLink / ChangeLinkToFixedJoint / ChangeLinkInertia, src/dwbc.cpp:1764-2382,
+    #      2707-2730): each returns a NEW Model; a model of another size runs on its own kernel pack (build_pack)
+    def _link(self, link):
+        i = self.link_id(link) if isinstance(link, str) else int(link)
+        if i < 0:
+            raise DwbcError(f"no link named {link}")
+        return i
+
+    def _new(self, h):
+        if not h:
+            raise DwbcError(_lib.last_error())
+        return Model(h)
+
+    def delete_link(self, link):
+        return self._new(self._L.dwbc_model_delete_link(self._h, self._link(link)))
+
+    def add_link(self, parent, name, joint_type, joint_axis, joint_rotm, joint_trans, mass, com, inertia):
+        """joint_type: 0 fixed (joined to the parent link), 1 revolute (a new last link; the parent must be the last link or one of
+        its ancestors).  joint_rotm: rotation child -> parent of the joint frame"""
+        a = [np.ascontiguousarray(x, np.float64) for x in (joint_axis, joint_rotm, joint_trans, com, inertia)]
+        return self._new(self._L.dwbc_model_add_link(self._h, self._link(parent), str(name).encode(), int(joint_type), a[0].ctypes.data, a[1].ctypes.data,
+                                                     a[2].ctypes.data, float(mass), a[3].ctypes.data, a[4].ctypes.data))
+
+    def change_link_to_fixed_joint(self, link):
+        return self._new(self._L.dwbc_model_change_link_to_fixed_joint(self._h, self._link(link)))
+
+    def change_link_inertia(self, link, com_inertia, com_position, com_mass):
+        a = [np.ascontiguousarray(x, np.float64) for x in (com_inertia, com_position)]
+        return self._new(self._L.dwbc_model_change_link_inertia(self._h, self._link(link), a[0].ctypes.data, a[1].ctypes.data, float(com_mass)))
+
     def link_name(self, i):
         return self._L.dwbc_model_link_name(self._h, i).decode()
 

@@ -167,6 +167,33 @@ void add_parallel_axis(M3 &I, double m, const double *d) {
         for (int j = 0; j < 3; j++) I.m[i * 3 + j] += m * ((i == j ? dd : 0.0) - d[i] * d[j]);
 }
 
+// RBDL Body::Join: body `b` of m absorbs a rigid body (mass2, com2, I2 about its com) attached through the frame (R child -> parent, p)
+void join_body(Model &m, int b, const M3 &R, const V3 &p, double mass2, const V3 &com2, const M3 &I2_in) {
+    if (mass2 == 0.0) return;
+    V3 c2 = mulv(R, com2);
+    for (int a = 0; a < 3; a++) c2.v[a] += p.v[a];
+    M3 I2 = mul(mul(R, I2_in), transpose(R));
+    const double m1 = m.mass[b], mt = m1 + mass2;
+    double c1[3], c[3], d1[3], d2[3];
+    for (int a = 0; a < 3; a++) {
+        c1[a] = m.com[b * 3 + a];
+        c[a] = (m1 * c1[a] + mass2 * c2.v[a]) / mt;
+        d1[a] = c1[a] - c[a];
+        d2[a] = c2.v[a] - c[a];
+    }
+    M3 I1;
+    for (int a = 0; a < 9; a++) I1.m[a] = m.inertia[b * 9 + a];
+    add_parallel_axis(I1, m1, d1);
+    add_parallel_axis(I2, mass2, d2);
+    for (int a = 0; a < 9; a++) m.inertia[b * 9 + a] = I1.m[a] + I2.m[a];
+    for (int a = 0; a < 3; a++) m.com[b * 3 + a] = c[a];
+    m.mass[b] = mt;
+}
+template <class T>
+void erase_rows(std::vector<T> &v, int first, int count, int width) {
+    v.erase(v.begin() + (size_t)first * width, v.begin() + (size_t)(first + count) * width);
+}
+
 struct UrdfLink { double mass = 0; V3 com{{0, 0, 0}}; M3 inertia{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; };
 struct UrdfJoint { std::string name, type, parent, child; V3 xyz{{0, 0, 0}}; M3 R = identity(); V3 axis{{1, 0, 0}}; };
 
@@ -200,26 +227,7 @@ struct Builder {
             const UrdfLink &l = lit->second;
             if (j.type == "fixed") {
                 Model &m = *out;
-                if (l.mass != 0.0) {  // Body::Join
-                    V3 c2 = mulv(Rj, l.com);
-                    for (int a = 0; a < 3; a++) c2.v[a] += pj.v[a];
-                    M3 I2 = mul(mul(Rj, l.inertia), transpose(Rj));
-                    const double m1 = m.mass[body], m2 = l.mass, mt = m1 + m2;
-                    double c1[3], c[3], d1[3], d2[3];
-                    for (int a = 0; a < 3; a++) {
-                        c1[a] = m.com[body * 3 + a];
-                        c[a] = (m1 * c1[a] + m2 * c2.v[a]) / mt;
-                        d1[a] = c1[a] - c[a];
-                        d2[a] = c2.v[a] - c[a];
-                    }
-                    M3 I1;
-                    for (int a = 0; a < 9; a++) I1.m[a] = m.inertia[body * 9 + a];
-                    add_parallel_axis(I1, m1, d1);
-                    add_parallel_axis(I2, m2, d2);
-                    for (int a = 0; a < 9; a++) m.inertia[body * 9 + a] = I1.m[a] + I2.m[a];
-                    for (int a = 0; a < 3; a++) m.com[body * 3 + a] = c[a];
-                    m.mass[body] = mt;
-                }
+                join_body(m, body, Rj, pj, l.mass, l.com, l.inertia);  // Body::Join
                 if (!visit(j.child, body, Rj, pj)) return false;
             } else if (j.type == "revolute" || j.type == "continuous") {
                 double nrm = sqrt(j.axis.v[0] * j.axis.v[0] + j.axis.v[1] * j.axis.v[1] + j.axis.v[2] * j.axis.v[2]);
@@ -251,6 +259,95 @@ void Model::finalize() {
         total_mass += mass[i];
     }
     for (int i = nb - 1; i > 0; i--) subtree[parent[i]] += subtree[i];
+}
+
+bool Model::is_preorder() const {
+    // pre-order <=> the parent of body i is body i-1 or one of its ancestors
+    for (int i = 1; i < (int)parent.size(); i++) {
+        if (parent[i] < 0 || parent[i] >= i) return false;
+        int a = i - 1;
+        while (a != parent[i] && a > 0) a = parent[a];
+        if (a != parent[i]) return false;
+    }
+    return true;
+}
+
+
+bool Model::delete_link(int link, std::string &err) {
+    if (link <= 0 || link >= nb) { err = "DeleteLink: bad link (the base link cannot be deleted)"; return false; }
+    if (!is_preorder()) { err = "DeleteLink: model is not numbered depth first"; return false; }
+    const int len = subtree[link];
+    erase_rows(names, link, len, 1);
+    erase_rows(parent, link, len, 1);
+    erase_rows(R_T, link, len, 9);
+    erase_rows(p_T, link, len, 3);
+    erase_rows(axis, link, len, 3);
+    erase_rows(mass, link, len, 1);
+    erase_rows(com, link, len, 3);
+    erase_rows(inertia, link, len, 9);
+    for (size_t i = 0; i < parent.size(); i++)
+        if (parent[i] >= link + len) parent[i] -= len;  // (no surviving body has its parent inside the deleted range)
+    finalize();
+    return true;
+}
+
+bool Model::add_link(int parent_link, const char *name, int joint_type, const double *axis3, const double *R9, const double *p3, double body_mass,
+                     const double *com3, const double *inertia9, std::string &err) {
+    if (parent_link < 0 || parent_link >= nb) { err = "AddLink: bad parent link"; return false; }
+    M3 R, I;
+    V3 p, c;
+    for (int a = 0; a < 9; a++) { R.m[a] = R9[a]; I.m[a] = inertia9[a]; }
+    for (int a = 0; a < 3; a++) { p.v[a] = p3[a]; c.v[a] = com3[a]; }
+    if (joint_type == 0) {
+        join_body(*this, parent_link, R, p, body_mass, c, I);
+        finalize();
+        return true;
+    }
+    if (joint_type != 1) { err = "AddLink: joint type must be fixed (0) or revolute (1)"; return false; }
+    // the new body becomes the LAST one (RBDL appends; its joint is the last generalized coordinate).  The kernels need the
+    // depth-first numbering to survive that: the parent must be the last body or one of its ancestors
+    int a = nb - 1;
+    while (a != parent_link && a > 0) a = parent[a];
+    if (a != parent_link) {
+        err = "AddLink: a revolute link can only be attached to the last link or one of its ancestors (the bodies stay numbered depth first; "
+              "the new joint is the last coordinate, as in the reference)";
+        return false;
+    }
+    const double nrm = sqrt(axis3[0] * axis3[0] + axis3[1] * axis3[1] + axis3[2] * axis3[2]);
+    if (nrm == 0.0) { err = "AddLink: zero joint axis"; return false; }
+    names.push_back(name ? name : "");
+    parent.push_back(parent_link);
+    R_T.insert(R_T.end(), R.m, R.m + 9);
+    p_T.insert(p_T.end(), p.v, p.v + 3);
+    for (int k = 0; k < 3; k++) axis.push_back(axis3[k] / nrm);
+    mass.push_back(body_mass);
+    com.insert(com.end(), c.v, c.v + 3);
+    inertia.insert(inertia.end(), I.m, I.m + 9);
+    finalize();
+    return true;
+}
+
+bool Model::change_link_to_fixed_joint(int link, std::string &err) {
+    if (link <= 0 || link >= nb) { err = "ChangeLinkToFixedJoint: bad link"; return false; }
+    const int par = parent[link];
+    M3 R, I;
+    V3 p, c;
+    for (int a = 0; a < 9; a++) { R.m[a] = R_T[link * 9 + a]; I.m[a] = inertia[link * 9 + a]; }
+    for (int a = 0; a < 3; a++) { p.v[a] = p_T[link * 3 + a]; c.v[a] = com[link * 3 + a]; }
+    const double ms = mass[link];
+    const std::string nm = names[link];
+    if (!delete_link(link, err)) return false;  // descendants go with it, as in the reference
+    const double ax[3] = {0, 0, 1};
+    return add_link(par, nm.c_str(), 0, ax, R.m, p.v, ms, c.v, I.m, err);
+}
+
+bool Model::change_link_inertia(int link, const double *inertia9, const double *com3, double body_mass, std::string &err) {
+    if (link < 0 || link >= nb) { err = "ChangeLinkInertia: bad link"; return false; }
+    for (int a = 0; a < 9; a++) inertia[link * 9 + a] = inertia9[a];
+    for (int a = 0; a < 3; a++) com[link * 3 + a] = com3[a];
+    mass[link] = body_mass;
+    finalize();
+    return true;
 }
 
 int Model::link_id(const char *name) const {
