@@ -110,7 +110,7 @@ struct Lds2 {
 template <int NN>
 DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int npiv = NN) {
     DWBC_LANE_DECL;
-    static_assert(NN <= 40, "five candidate registers per kr");
+    static_assert(NN <= 56, "seven candidate registers per kr");
     int ok = 1;
     LANES {
         DWBC_LANE_OPAQUE(lp);
@@ -139,6 +139,8 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
                     if (16 + kr < NN) cj = (kb == 2) ? LV(s)[(16 + kr) < NN ? 16 + kr : 0] : cj;
                     if (24 + kr < NN) cj = (kb == 3) ? LV(s)[(24 + kr) < NN ? 24 + kr : 0] : cj;
                     if (32 + kr < NN) cj = (kb == 4) ? LV(s)[(32 + kr) < NN ? 32 + kr : 0] : cj;
+                    if (40 + kr < NN) cj = (kb == 5) ? LV(s)[(40 + kr) < NN ? 40 + kr : 0] : cj;  // (models beyond TOCABI's 39 dof: kernel packs)
+                    if (48 + kr < NN) cj = (kb == 6) ? LV(s)[(48 + kr) < NN ? 48 + kr : 0] : cj;
                     const bool piv = lk == k;
                     const real_t h = piv ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll

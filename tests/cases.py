@@ -103,3 +103,14 @@ def synth_batch(B, seed=20251226, yaw=False, contact_mode="LR", levels=2):
         flags[(u >= 0.5) & (u < 0.75), 1] = 0
         flags[u >= 0.75, 0] = 0
     return q, flags, fstar
+
+
+def ensure_pack(model):
+    """the kernel pack of a model size other than TOCABI's: __graft_entry__.build() makes the ones the tests use; only a missing
+    one is compiled here (two minutes of hipcc)"""
+    import libdwbc_amd as D
+
+    path = os.path.join(os.path.dirname(os.path.abspath(D.__file__)), f"libdwbc_pack_{model.ndof}_{model.nb}.so")
+    if not os.path.exists(path):
+        D.build_pack(model)
+    return path

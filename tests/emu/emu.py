@@ -36,7 +36,13 @@ class Emu:
     def __init__(self, urdf, contacts, tasks, tau_lim=None, f32=False):
         L = lib(f32)
         self.L = L
-        self.h = L.emu_create(urdf.encode())
+        if isinstance(urdf, dict):  # a model given as arrays (the result of model surgery)
+            L.emu_create_from_arrays.restype = C.c_void_p
+            L.emu_create_from_arrays.argtypes = [C.c_int] + [C.c_void_p] * 7
+            arrs = [np.ascontiguousarray(urdf["parent"], np.int32)] + [np.ascontiguousarray(urdf[k], np.float64) for k in ("R_T", "p_T", "axis", "mass", "com", "inertia")]
+            self.h = L.emu_create_from_arrays(int(urdf["nb"]), *[a.ctypes.data for a in arrs])
+        else:
+            self.h = L.emu_create(urdf.encode())
         err = L.emu_error(self.h).decode()
         if err:
             raise RuntimeError(err)

@@ -47,6 +47,25 @@ EmuCtx *emu_create(const char *urdf) {
     setup_set_parents(c->su, c->topo.data());
     return c;
 }
+// a model given as arrays (e.g. the result of model surgery): same tables as emu_create builds from a URDF
+EmuCtx *emu_create_from_arrays(int nb, const int *parent, const double *R_T, const double *p_T, const double *axis, const double *mass, const double *com, const double *inertia) {
+    auto *c = new EmuCtx();
+    Model &m = c->model;
+    m.parent.assign(parent, parent + nb);
+    m.R_T.assign(R_T, R_T + 9 * nb);
+    m.p_T.assign(p_T, p_T + 3 * nb);
+    m.axis.assign(axis, axis + 3 * nb);
+    m.mass.assign(mass, mass + nb);
+    m.com.assign(com, com + 3 * nb);
+    m.inertia.assign(inertia, inertia + 9 * nb);
+    for (int i = 0; i < nb; i++) m.names.push_back("link" + std::to_string(i));
+    m.finalize();
+    setup_init(c->su, m.nb, m.ndof, m.maxdepth);
+    m.body_table(c->body);
+    m.topo_table(c->topo);
+    setup_set_parents(c->su, c->topo.data());
+    return c;
+}
 const char *emu_error(EmuCtx *c) { return c->err.c_str(); }
 void emu_destroy(EmuCtx *c) { delete c; }
 int emu_nb(EmuCtx *c) { return c->model.nb; }
@@ -172,7 +191,7 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
 }
 
 // ---- other model sizes (the kernel packs of dwbc_pack.hip): the same source instantiated for (37, 32) and (23, 18), two task
-//      levels, TopoGeneric -- the sizes tests/test_model_packs.py builds from the TOCABI fixture
+//      levels, TopoGeneric -- the sizes tests/test_model_packs.py builds from the TOCABI fixture (43 / 38: four links added to a hand)
 }  // extern "C"
 template <int N, int NB>
 static void emu_run_size(EmuCtx *c, BatchIO &io, int B) {
@@ -193,7 +212,8 @@ int emu_run_other(EmuCtx *c, int B, const double *q, const unsigned char *flags,
     io.diag = diag; io.dump = dump ? rdump.data() : nullptr; io.body = rb.data(); io.topo = c->topo.data(); io.hqp = 1;
     if (n == 37 && nb == 32) emu_run_size<37, 32>(c, io, B);
     else if (n == 23 && nb == 18) emu_run_size<23, 18>(c, io, B);
-    else { c->err = "emu_run_other: instantiated for (37, 32) and (23, 18)"; return 0; }
+    else if (n == 43 && nb == 38) emu_run_size<43, 38>(c, io, B);
+    else { c->err = "emu_run_other: instantiated for (37, 32), (23, 18) and (43, 38)"; return 0; }
     from_real(rdump, dump);
     return 1;
 }

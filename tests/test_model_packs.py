@@ -113,7 +113,7 @@ def test_gpu_other_model_sizes_match_oracle(tmp_path, name):
     path = variant_urdf(tmp_path / f"{name}.urdf", fixed)
     mo = urdf_model.load_urdf(path)
     md = D.Model.from_urdf(path)
-    D.build_pack(md)  # in-tree next to libdwbc_hip.so; __graft_entry__.build() has normally done it already
+    cases.ensure_pack(md)
     B = 48
     q, fs = variant_states(mo, B, seed=7)
     links = [md.link_id("L_AnkleRoll_Link"), md.link_id("R_AnkleRoll_Link"), md.link_id("Upperbody_Link")]
@@ -160,3 +160,84 @@ def test_gpu_missing_pack_is_reported_with_the_command_that_builds_it(tmp_path, 
     assert (md.ndof, md.nb) == (36, 31)
     with pytest.raises(D.DwbcError, match="make -C libdwbc_amd/csrc pack N=36 NB=31"):
         D.Batch(md, 4, device=0)
+
+
+# ---- a model LARGER than TOCABI (43 dof / 38 bodies, the size of the reference's tests/dof_test/dyros_tocabi_dof43.urdf): four links
+#      added to the right hand by model surgery (AddLink with revolute joints; tests/test_model_surgery.py checks the surgery itself)
+def model_43():
+    import libdwbc_amd as D
+
+    md = D.Model.from_urdf(cases.URDF)
+    par = "R_Wrist2_Link"
+    for k in range(4):
+        ax = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0]][k]
+        ang = 0.3 * (k + 1)
+        R = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+        md = md.add_link(par, f"finger{k}", 1, ax, R, [0.02 * (k + 1), -0.01 * k, -0.04], 0.2 + 0.05 * k, [0.005, 0.0, -0.01 * (k + 1)],
+                         np.diag([2e-4, 3e-4, 1e-4]) * (k + 1))
+        par = f"finger{k}"
+    a = md.arrays()
+    a["names"] = [md.link_name(i) for i in range(md.nb)]
+    return md, a
+
+
+def states_43(B, seed):
+    rng = np.random.default_rng(seed)
+    q = np.zeros((B, 44))
+    q0 = np.array(cases.Q_CASE[1])
+    q[:, :39] = q0[:39]
+    q[:, 39:43] = rng.uniform(-0.5, 0.5, size=(B, 4))
+    q[:, 43] = 1.0
+    q[:, 6:39] += 0.02 * rng.uniform(-1, 1, size=(B, 33))
+    fs = np.concatenate([np.array(cases.FSTAR_CASE[1][0]) + 0.1 * rng.uniform(-1, 1, size=(B, 6)),
+                         np.array(cases.FSTAR_CASE[1][1]) + 0.1 * rng.uniform(-1, 1, size=(B, 3))], axis=1)
+    return q, fs
+
+
+def test_emulated_43_dof_model_matches_oracle():
+    from tests.emu.emu import Emu
+
+    md, mo = model_43()
+    assert (md.ndof, md.nb) == (43, 38)
+    links = [6, 12, 15]
+    lim = np.full(37, 300.0)
+    e = Emu(mo, [dict(cc, link=l) for cc, l in zip(cases.CONTACTS_2, links[:2])], [[(0, 0, (0, 0, 0))], [(6, 15, (0, 0, 0))]], lim)
+    B = 4
+    q, fs = states_43(B, 5)
+    r = e.run(q, np.ones((B, 2), np.uint8), fs, dump=True)
+    c = Dn.Cycle(mo)
+    c.update_kinematics(q[0])
+    assert np.abs(e.dump_field(r["dump"], "A", (43, 43))[0] - c.A).max() < 1e-10 * np.abs(c.A).max()
+    assert np.abs(e.dump_field(r["dump"], "A_inv", (43, 43))[0] - c.A_inv).max() < 1e-9 * np.abs(c.A_inv).max()
+    for b in range(B):
+        o = oracle_cycle(mo, links, q[b], fs[b], lim)
+        assert r["status"][b] == o["status"] == 1
+        assert np.abs(r["tau"][b] - np.stack([o["tau_grav"], o["tau_task"], o["tau_contact"]])).max() < TOL_TAU
+
+
+@pytest.mark.gpu
+def test_gpu_43_dof_model_matches_oracle():
+    import libdwbc_amd as D
+
+    md, mo = model_43()
+    cases.ensure_pack(md)
+    B = 32
+    q, fs = states_43(B, 9)
+    links = [6, 12, 15]
+    lim = np.full(37, 300.0)
+    wbc = D.Batch(md, B, device=0)
+    for cc, l in zip(cases.CONTACTS_2, links[:2]):
+        wbc.add_contact(l, cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, 15)
+    wbc.set_torque_limit(lim)
+    for dump in (False, True):
+        wbc.enable_dump(dump)
+        wbc.set_state(q); wbc.set_contact(np.ones((B, 2), np.uint8)); wbc.set_fstar_all(fs)
+        wbc.solve()
+        tau, st = wbc.get("tau"), wbc.get("status")
+        assert "<43, 38," in wbc.kernel_name()
+        for b in range(B):
+            o = oracle_cycle(mo, links, q[b], fs[b], lim)
+            assert st[b] == o["status"] == 1
+            assert np.abs(tau[b] - np.stack([o["tau_grav"], o["tau_task"], o["tau_contact"]])).max() < TOL_TAU, (b, dump)

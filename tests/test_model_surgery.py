@@ -119,7 +119,7 @@ def test_gpu_solve_on_a_surgically_edited_model(tmp_path):
 
     md = _tocabi().change_link_to_fixed_joint("Head_Link").change_link_to_fixed_joint("Neck_Link")
     mu = D.Model.from_urdf(variant_urdf(tmp_path / "fh.urdf", HEAD))
-    D.build_pack(md)
+    cases.ensure_pack(md)
     mo = urdf_model.load_urdf(str(tmp_path / "fh.urdf"))
     B = 32
     q, fs = variant_states(mo, B, seed=3)
