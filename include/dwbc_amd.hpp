@@ -60,6 +60,7 @@ using dwbc_amd::Vec;
 using dwbc_amd::Vec3;
 
 enum { JOINT_FLOATING_BASE, JOINT_6DOF, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FIXED };  // dwbc_link.h:12-19 (AddLink's joint_type)
+enum TASK_TYPE { TASK_UNDEFINED, TASK_LINK, TASK_CUSTOM, TASK_NONCONTACT_CHAIN, TASK_CONTACT_CHAIN, TASK_CENTROIDAL };  // dwbc_task.h:12-20
 enum CONTACT_TYPE { CONTACT_6D = 0, CONTACT_POINT = 1, CONTACT_LINK = 2, CONTACT_LINE = 3 };  // dwbc_contact_constraint.h:19-25
 enum TASK_LINK_MODE {                                                                          // dwbc_task.h:23-33
     TASK_LINK_6D = 0, TASK_LINK_6D_COM_FRAME, TASK_LINK_6D_CUSTOM_FRAME, TASK_LINK_POSITION, TASK_LINK_POSITION_COM_FRAME,
@@ -102,7 +103,8 @@ struct ContactView {  // include/dwbc_contact_constraint.h:27-80
     Vec3 xc_pos, zmp_pos;  // include/dwbc_contact_constraint.h: contact point (world) and the contact's ZMP
     Mat rotm;
     bool contact = false;
-    int contact_dof_ = 6;
+    int contact_dof_ = 6, constraint_number_ = 10;
+    double contact_plane_x_ = 0.0, contact_plane_y_ = 0.0, friction_ratio_ = 0.2, friction_ratio_z_ = 0.2;  // dwbc_contact_constraint.h:44-52
 };
 
 // DWBC::HQP / HQP_Hierarch (include/dwbc_hqp.h:8-141): the fields callers read after a solve, one instance
@@ -255,7 +257,7 @@ class RobotData {
     void AddContactConstraint(int link_number, int contact_type, Vec3 contact_point, Vec3 /*contact_vector*/, double contact_x = 0, double contact_y = 0, bool verbose = false) {
         for (auto &c : cc_) if (c.link_number_ == link_number) { std::cout << "Contact Constraint Already Exist for Link : " << link_number << std::endl; return; }
         if (dwbc_batch_add_contact(batch_, link_number, contact_type, contact_point.data(), contact_x, contact_y, 0.2, 0.2) < 0) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
-        ContactView c; c.link_number_ = link_number; cc_.push_back(c);
+        ContactView c; c.link_number_ = link_number; c.contact_plane_x_ = contact_x; c.contact_plane_y_ = contact_y; cc_.push_back(c);
         flags_.push_back(0);
         if (verbose) std::cout << "#" << (cc_.size() - 1) << " Contact Constraint Added : " << dwbc_model_link_name(model_, link_number) << std::endl;
     }
@@ -263,6 +265,47 @@ class RobotData {
         int id = getLinkID(link_name);
         if (id < 0) { std::cout << "Link Name is Wrong : " << link_name << std::endl; return; }
         AddContactConstraint(id, contact_type, p, n, cx, cy, verbose);
+    }
+    void ClearContactConstraint() {  // dwbc.h:277
+        if (batch_) dwbc_batch_clear_contacts(batch_);
+        cc_.clear(); flags_.clear(); contact_dof_ = 0; contact_link_num_ = 0; dirty_ = true;
+    }
+    void UpdateContactConstraint() { refresh(); }  // dwbc.cpp:433-454: part of the fused launch
+    // getContactConstraintMatrix() (dwbc.cpp:480-513): C = -A_const_a A_rot over the active contacts, rows [4 CoP | 6 friction] per contact
+    // (GetZMPConstMatrix4x6 / GetForceConstMatrix6x6, src/wbd.cpp:59-97), acting on the world-frame contact wrench
+    Mat getContactConstraintMatrix() {
+        refresh();
+        Mat C(contact_link_num_ * 10, contact_dof_);
+        int a = 0;
+        for (auto &c : cc_) {
+            if (!c.contact) continue;
+            const double lx = c.contact_plane_x_, ly = c.contact_plane_y_, mu = c.friction_ratio_, muz = c.friction_ratio_z_;
+            const double Ac[10][6] = {{0, 0, -lx, 0, -1, 0}, {0, 0, -lx, 0, 1, 0}, {0, 0, -ly, -1, 0, 0}, {0, 0, -ly, 1, 0, 0}, {1, 0, -mu, 0, 0, 0},
+                                      {-1, 0, -mu, 0, 0, 0}, {0, 1, -mu, 0, 0, 0}, {0, -1, -mu, 0, 0, 0}, {0, 0, -muz, 0, 0, 1}, {0, 0, -muz, 0, 0, -1}};
+            for (int r = 0; r < 10; r++)
+                for (int h = 0; h < 2; h++)
+                    for (int j = 0; j < 3; j++) {
+                        double v = 0.0;  // (A_const_a * blkdiag(R^T, R^T))[r][3h + j] = sum_x Ac[r][3h + x] R[j][x]
+                        for (int x = 0; x < 3; x++) v += Ac[r][3 * h + x] * c.rotm(j, x);
+                        C(10 * a + r, 6 * a + 3 * h + j) = -v;
+                    }
+            a++;
+        }
+        return C;
+    }
+    void getContactConstraintMatrix(Mat &C_) { C_ = getContactConstraintMatrix(); }
+    // CalcAngularMomentumMatrix (dwbc.cpp:1633-1680): angular momentum about the COM per unit generalized velocity = the angular rows of
+    // CMM_; the overload with an argument returns [angular; linear] (6 x system_dof_)
+    Mat CalcAngularMomentumMatrix() {
+        refresh();
+        Mat H(3, system_dof_);
+        for (int r = 0; r < 3; r++) for (unsigned c = 0; c < system_dof_; c++) H(r, c) = CMM_(3 + r, c);
+        return H;
+    }
+    void CalcAngularMomentumMatrix(Mat &cmm) {
+        refresh();
+        cmm = Mat(6, system_dof_);
+        for (int r = 0; r < 3; r++) for (unsigned c = 0; c < system_dof_; c++) { cmm(r, c) = CMM_(3 + r, c); cmm(3 + r, c) = CMM_(r, c); }
     }
     template <typename... Types>
     void SetContact(Types... args) {  // dwbc.h:432-474
@@ -292,6 +335,51 @@ class RobotData {
         if (id < 0) { std::cout << "Link Name is not Correct" << std::endl; return; }
         AddTaskSpace(heirarchy, task_mode, id, task_point, verbose);
     }
+    // a further link of the same hierarchy level (dwbc.h:326-327)
+    void AddTaskLink(int heirarchy, int task_mode, int link_number, Vec3 task_point, bool verbose = false) { AddTaskSpace(heirarchy, task_mode, link_number, task_point, verbose); }
+    void AddTaskLink(int heirarchy, int task_mode, const char *link_name, Vec3 task_point, bool verbose = false) { AddTaskSpace(heirarchy, task_mode, link_name, task_point, verbose); }
+    // TASK_CUSTOM level: the caller hands J_task over with SetTaskSpace(h, f*, J) (dwbc.h:318,333; dwbc.cpp:664-681)
+    void AddTaskSpace(int heirarchy, int /*task_mode = TASK_CUSTOM*/, int task_dof, bool verbose = false) {
+        if (!dwbc_batch_add_custom_task(batch_, heirarchy, task_dof)) { std::cout << dwbc_last_error() << std::endl; return; }
+        if ((int)ts_.size() <= heirarchy) ts_.resize(heirarchy + 1);
+        ts_[heirarchy].task_dof_ = task_dof;
+        ts_[heirarchy].f_star_.assign(task_dof, 0.0);
+        if (verbose) std::cout << "#" << heirarchy << " Task Space Added : custom, dof " << task_dof << std::endl;
+    }
+    void SetTaskSpace(int heirarchy, const Vec &f_star, const Mat &J_task) {
+        if (heirarchy >= (int)ts_.size()) { std::cout << "ERROR : task space size overflow" << std::endl; return; }
+        const int t = ts_[heirarchy].task_dof_;
+        if (J_task.rows != t || J_task.cols != (int)system_dof_ || (int)f_star.size() != t) { std::cout << "ERROR : custom task sizes (J_task task_dof x system_dof, f_star task_dof)" << std::endl; return; }
+        std::vector<double> J((size_t)t * system_dof_, 0.0);  // task_dof x system_dof_, row-major
+        for (int r = 0; r < t; r++) for (unsigned c = 0; c < system_dof_; c++) J[r * system_dof_ + c] = J_task(r, c);
+        if (!dwbc_batch_set_custom_task(batch_, heirarchy, f_star.data(), J.data())) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        ts_[heirarchy].f_star_ = f_star;
+        dirty_ = true;
+    }
+    void ClearTaskSpace() { if (batch_) dwbc_batch_clear_tasks(batch_); ts_.clear(); dirty_ = true; }  // dwbc.cpp:515-520
+    void ClearQP() {}  // the QP solvers live inside the kernel: nothing to allocate or clear (dwbc.h:329-330)
+    void AddQP() {}
+    void UpdateTaskSpace() { refresh(); }           // dwbc.cpp:685-793: part of the fused launch
+    void CalcTaskSpace(bool = true) { refresh(); }  // dwbc.cpp:795-816
+    void InitModelData(int = 0) {}                  // done by LoadModelData
+    void InitializeMatrix() {}
+    // CopyKinematicsData(target) (dwbc.cpp:1711-1762): state, torque limit, contact constraints (with their flags) and task spaces
+    // (with their f*) go to the target, which then runs its own Calc* sequence; the derived quantities are recomputed there
+    void CopyKinematicsData(RobotData &target_rd) {
+        if (!batch_ || !target_rd.batch_) return;
+        if (!dwbc_batch_copy_kinematics(target_rd.batch_, batch_)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return; }
+        target_rd.q_system_ = q_system_; target_rd.q_dot_system_ = q_dot_system_; target_rd.q_ddot_system_ = q_ddot_system_;
+        target_rd.control_time_ = control_time_; target_rd.sent_time_ = control_time_;
+        target_rd.torque_limit_set_ = torque_limit_set_; target_rd.torque_limit_ = torque_limit_;
+        target_rd.cc_ = cc_; target_rd.flags_ = flags_; target_rd.ts_ = ts_;
+        target_rd.contact_dof_ = contact_dof_; target_rd.contact_link_num_ = contact_link_num_; target_rd.contact_ok_ = contact_ok_;
+        target_rd.dirty_ = true;
+    }
+    void printLinkInfo() {  // dwbc.cpp:2399-2423
+        for (unsigned i = 0; i < link_num_; i++) std::cout << i << " : " << dwbc_model_link_name(model_, (int)i) << std::endl;
+    }
+    Vec GetControlTorque(bool = false, bool = true) { return Vec(); }  // the reference returns an empty vector (dwbc.cpp:1622-1631)
+    int CalcContactRedistributeR(bool hqp = true, bool init = true) { return ReducedCalcContactRedistribute(hqp, init); }  // dwbc.cpp:4762-4774
     void SetTaskSpace(int heirarchy, const Vec &f_star) {  // dwbc.h:333
         if (heirarchy >= (int)ts_.size()) { std::cout << "ERROR : task space size overflow" << std::endl; return; }
         if ((int)f_star.size() != ts_[heirarchy].task_dof_) { std::cout << "ERROR : task dof not matching! heir : " << heirarchy << " fstar size : " << f_star.size() << " task_dof : " << ts_[heirarchy].task_dof_ << std::endl; return; }

@@ -21,6 +21,7 @@ int main(int argc, char **argv) {
     RobotData rd_;
     rd_.LoadModelData(argv[1], true, false);
     if (rd_.system_dof_ != 39) { fprintf(stderr, "model load failed\n"); return 3; }
+    if (argc > 3 && std::string(argv[3]) == "api") rd_.printLinkInfo();  // (before the JSON block)
     Vec q(rd_.system_dof_ + 1, 0.0), qdot(rd_.system_dof_, 0.0), qddot(rd_.system_dof_, 0.0);
     const double q1[40] = {0, 0, 0.92983, 0, 0, 0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0, 0, 0,
                            0.3, 0.3, 1.5, -1.27, -1, 0, -1, 0, 0, 0, -0.3, -0.3, -1.5, 1.27, 1, 0, 1, 0, 1};
@@ -120,6 +121,37 @@ int main(int argc, char **argv) {
         rd_.SetTaskSpace(1, f2);
         std::vector<float> back = dwbc_amd::to_vector<std::vector<float>>(rd_.torque_grav_);
         printf("\"generic\": [%zu],\n", back.size());
+    }
+    if (argc > 3 && std::string(argv[3]) == "api") {
+        // the rest of RobotData's public interface (include/dwbc.h:259-410)
+        print_vec("C_contact", rd_.getContactConstraintMatrix().d);
+        print_vec("cam3", rd_.CalcAngularMomentumMatrix().d);
+        Mat cmm6;
+        rd_.CalcAngularMomentumMatrix(cmm6);
+        print_vec("cmm6", cmm6.d);
+        // CopyKinematicsData into a second object: it takes over state, contacts and task spaces, then is switched to single support
+        RobotData rd2_;
+        rd2_.LoadModelData(argv[1], true, false);
+        rd_.CopyKinematicsData(rd2_);
+        rd2_.SetContact(true, false);
+        int ok2 = rd2_.CalcContactConstraint();
+        print_vec("rd2_torque_grav_", rd2_.CalcGravCompensation());
+        print_vec("rd2_A00", Vec{rd2_.A_(0, 0), rd2_.A_(7, 9), (double)rd2_.contact_dof_, (double)ok2});
+        // a custom level and a second link on a level; clearing both sets up a new problem on the same object
+        rd_.ClearTaskSpace();
+        rd_.ClearContactConstraint();
+        rd_.AddContactConstraint(left_foot_id, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.15, 0.075);
+        rd_.AddContactConstraint(right_foot_id, CONTACT_6D, Vec3(0.03, 0, -0.1585), Vec3(0, 0, 1), 0.15, 0.075);
+        rd_.AddTaskSpace(0, TASK_LINK_6D, 0, Vec3());
+        rd_.AddTaskSpace(1, TASK_LINK_ROTATION, "upperbody_link", Vec3());
+        rd_.AddTaskLink(1, TASK_LINK_POSITION, "R_Wrist2_Link", Vec3());
+        rd_.SetContact(true, true);
+        rd_.SetTaskSpace(0, fstar_1);
+        rd_.SetTaskSpace(1, Vec{fstar_2[0], fstar_2[1], fstar_2[2], 0.2, -0.1, 0.3});
+        int ok3 = rd_.CalcTaskControlTorque(true);
+        printf("\"api_ok\": [%d, %d, %d],\n", ok3, (int)rd_.ts_.size(), rd_.ts_[1].task_dof_);
+        print_vec("api_torque_task_", rd_.torque_task_);
+        (void)rd_.GetControlTorque();
     }
     print_vec("contact_qp_last", rd_.ts_.back().contact_qp_, true);
     printf("}\n");

@@ -103,3 +103,46 @@ def test_facade_reduced_lqp_and_jacc_sequence():
     assert _rel(np.asarray(r["jacc_r_acc"]), o["jacc"]["acc"]) < 1e-5 and _rel(np.asarray(r["jacc_r_torque"]), o["jacc"]["tau"]) < 1e-3
     assert _rel(np.asarray(r["jacc_nc_acc"]), o["jacc_nc"]["acc"]) < 1e-4
     assert np.abs(np.asarray(r["G_R"]) - o["r"].G_R).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_facade_rest_of_the_public_interface():
+    """getContactConstraintMatrix, CalcAngularMomentumMatrix (both overloads), CopyKinematicsData into an object with another contact
+    setup, ClearTaskSpace / ClearContactConstraint + a level of two links (AddTaskLink): against the numpy restatement (CASE 1 state)"""
+    from oracle import dwbc_np as Dn
+
+    _build()
+    out = subprocess.check_output([EXE, cases.URDF, "1", "api"], text=True)
+    r = json.loads(out[out.index("{"):out.rindex("}") + 1]) if "{" in out else {}
+    q = np.array(cases.Q_CASE[1])
+    m = cases.tocabi_model()
+    c = Dn.Cycle(m)
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    c.update_kinematics(q)
+    c.set_contact([1, 1])
+    assert np.abs(np.asarray(r["C_contact"]).reshape(20, 12) + c.cone_matrix()).max() < 1e-12  # C = -A_const_a A_rot (dwbc.cpp:512)
+    assert np.abs(np.asarray(r["cam3"]).reshape(3, 39) - c.CMM[3:]).max() < 1e-9
+    cmm6 = np.asarray(r["cmm6"]).reshape(6, 39)
+    assert np.abs(cmm6[:3] - c.CMM[3:]).max() < 1e-9 and np.abs(cmm6[3:] - c.CMM[:3]).max() < 1e-9
+    # the copy target took over state + contact constraints + task spaces and was then switched to left single support
+    c1 = Dn.Cycle(m)
+    for cc in cases.CONTACTS_2:
+        c1.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    c1.update_kinematics(q)
+    c1.set_contact([1, 0])
+    c1.calc_contact_constraint()
+    assert np.abs(np.asarray(r["rd2_torque_grav_"]) - c1.calc_grav()).max() < 1e-7
+    assert abs(r["rd2_A00"][0] - c1.A[0, 0]) < 1e-9 and abs(r["rd2_A00"][1] - c1.A[7, 9]) < 1e-9 and r["rd2_A00"][2:] == [6.0, 1.0]
+    # two links on level 1 (rotation of the upper body + position of the right hand)
+    c2 = Dn.Cycle(m)
+    for cc in cases.CONTACTS_2:
+        c2.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    c2.add_task(0, 0, 0, (0, 0, 0))
+    c2.add_task(1, 6, 15, (0, 0, 0))
+    c2.add_task(1, 3, m["names"].index("R_Wrist2_Link"), (0, 0, 0))
+    c2.set_torque_limit(np.full(33, 300.0))
+    f1 = list(cases.FSTAR_CASE[1][1])
+    c2.run(q, [1, 1], [np.array(cases.FSTAR_CASE[1][0]), np.array(f1 + [0.2, -0.1, 0.3])])
+    assert r["api_ok"] == [1, 2, 6] and c2.status == 1
+    assert np.abs(np.asarray(r["api_torque_task_"]) - c2.tau_task).max() < 1e-6
