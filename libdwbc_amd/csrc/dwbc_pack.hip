@@ -21,7 +21,11 @@ static_assert(DWBC_PACK_NB <= kMaxBodies, "body table");
      Lds2<DWBC_PACK_N, DWBC_PACK_NB, NLV>::total_bytes, dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, TopoGeneric>, \
      dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>,                                                  \
      dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>}
+#ifdef DWBC_PACK_ONLY_NLV  // development: one level count only (a quarter of the compile time)
+static const KernelEntry kPack[] = {DWBC_PACK_ENTRY(DWBC_PACK_ONLY_NLV)};
+#else
 static const KernelEntry kPack[] = {DWBC_PACK_ENTRY(1), DWBC_PACK_ENTRY(2), DWBC_PACK_ENTRY(3), DWBC_PACK_ENTRY(4)};
+#endif
 
 extern "C" const KernelEntry *dwbc_pack_table(int *count, unsigned *abi_tag) {
     *count = (int)(sizeof(kPack) / sizeof(kPack[0]));
