@@ -13,7 +13,7 @@ using namespace dwbc;
 
 namespace {
 int fail(const std::string &s) { return capi_fail(s); }
-constexpr int kNT = 64;
+constexpr int kNT = 256;  // four wavefronts per instance: the matrices of this path live in HBM, more lanes keep more loads in flight
 }  // namespace
 
 __global__ __launch_bounds__(kNT) void dwbc_hqp_kernel(const HqpDesc d, const HqpIO io) {
