@@ -1,6 +1,6 @@
 // dwbc_hqp.h -- the reference's generic hierarchical-QP class (HQP / HQP_Hierarch, include/dwbc_hqp.h, src/dwbc_hqp.cpp) for a
 // batch of instances, and the LQP configurator that fills it from a solved control cycle (RobotData::ConfigureLQP,
-// src/dwbc.cpp:4304-4430).  SURVEY 8 rows a16 / f3.  One workgroup (one wavefront) per instance.
+// src/dwbc.cpp:4304-4430).  SURVEY 8 rows a16 / f3.  One workgroup per instance (256 threads on the device, dwbc_hqp_capi.hip).
 //
 //   level i:   min_{u, v}  1/2 |B_i Z u + (B_i y_prev + b_i)|^2  [+ 1/2 u^T Z^T H Z u + (Z^T H y_prev)^T u]  + 1/2 |v|^2
 //              s.t.        A_i Z u - v <= -(A_i y_prev) - a_i                      own inequalities, slack v   (dwbc_hqp.cpp:320-336)
@@ -15,8 +15,8 @@
 // in oracle/hqp_np.py: Tikhonov term eps |u|^2 / 2.  PARITY UNPINNED in the reference (no fixture, no assertion).
 //
 // Storage: the level matrices, answers and the scratch (Z, H Z, C Z) live in HBM -- this is not the headline path; LDS holds
-// the solver state (H^-1, T, M, the vectors).  Code is NT-generic (strided loops + DWBC_SYNC) so that tests/emu runs it with
-// one host thread.
+// the solver state (H^-1, T, M, the vectors).  Code is NT-generic (strided loops, every hand-over between threads behind a
+// workgroup barrier) so that tests/emu runs it with one host thread and the device with several wavefronts.
 #pragma once
 #include "dwbc_cycle.h"
 
