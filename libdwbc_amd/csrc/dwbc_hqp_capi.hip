@@ -485,15 +485,20 @@ static int solve_jacc_common(dwbc_batch *b, dwbc_hqp *h, int level, bool reduced
         e0 += cfg.t_dof[i];
     }
     if (e0 > kHqpMaxEq) return fail("JACC: too many equality rows");
-    // two levels: the exact constraint level and the task level
-    dwbc_hqp_clear(h);
-    if (dwbc_hqp_add_hierarchy(h, 10 * cfg.nc + 2 * m + 2 * cfg.jacc_mt, e0) < 0) return 0;
-    if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[level]) < 0) return 0;
-    h->d.exact[0] = 1;
-    h->d.exact[1] = 0;
-    h->d.has_cost[1] = 1;
-    if (!layout_and_alloc(h)) return 0;
-    h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+    // two levels: the exact constraint level and the task level (the buffers are kept while the shape stays the same)
+    const int m0 = 10 * cfg.nc + 2 * m + 2 * cfg.jacc_mt;
+    const bool same = h->laid_out && !h->is_lqp && h->d.n_levels == 2 && h->d.nv == n + cfg.cd && h->d.m[0] == m0 && h->d.e[0] == e0 && h->d.m[1] == 0 &&
+                      h->d.e[1] == cfg.t_dof[level] && h->d.exact[0] == 1 && h->d.exact[1] == 0 && h->d.has_cost[0] == 0 && h->d.has_cost[1] == 1;
+    if (!same) {
+        dwbc_hqp_clear(h);
+        if (dwbc_hqp_add_hierarchy(h, m0, e0) < 0) return 0;
+        if (dwbc_hqp_add_hierarchy(h, 0, cfg.t_dof[level]) < 0) return 0;
+        h->d.exact[0] = 1;
+        h->d.exact[1] = 0;
+        h->d.has_cost[1] = 1;
+        if (!layout_and_alloc(h)) return 0;
+        h->stage.assign(h->d.n_levels, dwbc_hqp::Stage{});
+    }
     h->stream = b->stream;
     HIP_OK(hipSetDevice(b->device));
     const size_t rs = (size_t)jacc_rec_size(n);
