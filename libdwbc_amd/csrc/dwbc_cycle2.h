@@ -55,8 +55,11 @@ struct Lds2 {
     static constexpr int k_F = k_S + N * 6;
     static constexpr int k_col = k_F + N * 6;                  // pivot column of the sweep
     static constexpr bool a_overlay = (Rw - JbT) >= N * N;
-    static constexpr int k_A = a_overlay ? JbT : k_col + N;
-    static constexpr int k_end = a_overlay ? k_col + N : k_col + N + N * N;
+    // larger models (N >= 42, kernel packs): the square no longer fits the hole, the lower triangle (row-packed) does -- without it
+    // the map of a 43-dof model is 48 KB and only three workgroups share a CU
+    static constexpr bool a_packed = !a_overlay && (Rw - JbT) >= N * (N + 1) / 2;
+    static constexpr int k_A = (a_overlay || a_packed) ? JbT : k_col + N;
+    static constexpr int k_end = (a_overlay || a_packed) ? k_col + N : k_col + N + N * N;
     // ---- contact / task-space scratch
     static constexpr int c_Vb = tmp;                           // M x K
     static constexpr int c_VG = c_Vb + M * K;                  // M x K
@@ -243,11 +246,20 @@ __device__ __forceinline__ void lds_col_issue(dwbc_d2v (&c)[NP], unsigned addr) 
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[P]) : "v"(addr), "n"(16 * P));
     if constexpr (P + 1 < NP) lds_col_issue<P + 1, NP>(c, addr);
 }
+template <int P, int NP>
+__device__ __forceinline__ void lds_col_pin(dwbc_d2v (&c)[NP]) {  // (no instruction: the value of c[P] is defined after the wait)
+    asm volatile("" : "+v"(c[P]));
+    if constexpr (P + 1 < NP) lds_col_pin<P + 1, NP>(c);
+}
 template <int NP>
 __device__ __forceinline__ void lds_col_wait(dwbc_d2v (&c)[NP]) {
-    static_assert(NP == 17, "33-wide sweep");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]),
-                 "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(c[16]));
+    if constexpr (NP == 17) {  // TOCABI's 33-wide sweep: one statement
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]),
+                     "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]), "+v"(c[16]));
+    } else {  // any width (the kernel packs): the wait, then every register re-defined behind it (volatile asms keep their order)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]));
+        if constexpr (NP > 1) lds_col_pin<1, NP>(c);
+    }
 }
 template <int NN, int K>
 __device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
@@ -277,7 +289,7 @@ DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real
     (void)colbuf;
     return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
 #else
-    if constexpr (sizeof(real_t) != 8 || NN != 33) {
+    if constexpr (sizeof(real_t) != 8 || NN < 16) {  // fp32 build; small matrices: the register sweep
         return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
     } else {
         const int lane = (int)threadIdx.x;
