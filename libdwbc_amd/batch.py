@@ -44,9 +44,20 @@ def _check(ok):
         raise DwbcError(_lib.last_error())
 
 
-def build_pack(model_or_ndof, nb=None, quiet=True):
+def tree_tag(parents):
+    """name tag of a tree-specific kernel pack: FNV-1a over the parent table as little-endian 32-bit words (dwbc_capi.hip: tree_tag)"""
+    h = 2166136261
+    for p in parents:
+        for b in int(max(p, 0)).to_bytes(4, "little"):
+            h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+    return f"{h:08x}"
+
+
+def build_pack(model_or_ndof, nb=None, quiet=True, tree=False):
     """Compile the cycle kernels for a model size other than TOCABI's (libdwbc_amd/csrc/dwbc_pack.hip -> libdwbc_pack_<N>_<NB>.so next
-    to libdwbc_hip.so; about two minutes with hipcc, nothing to do when it is up to date).  dwbc_batch_create loads it by itself."""
+    to libdwbc_hip.so; about two minutes with hipcc, nothing to do when it is up to date).  dwbc_batch_create loads it by itself.
+    tree=True (needs a Model): a pack for exactly this model's kinematic tree (libdwbc_pack_<N>_<NB>_t<tag>.so) -- the tree-sparse
+    A^-1 sweep and compile-time round counts the built-in TOCABI kernels have; it is preferred over the generic pack of the size."""
     import os
     import subprocess
 
@@ -55,8 +66,15 @@ def build_pack(model_or_ndof, nb=None, quiet=True):
     else:
         n, nb = int(model_or_ndof), int(nb)
     csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    subprocess.check_call(["make", "-C", csrc, "pack", f"N={n}", f"NB={nb}"], stdout=subprocess.DEVNULL if quiet else None)
-    return os.path.join(os.path.dirname(csrc), f"libdwbc_pack_{n}_{nb}.so")
+    cmd = ["make", "-C", csrc, "pack", f"N={n}", f"NB={nb}"]
+    name = f"libdwbc_pack_{n}_{nb}.so"
+    if tree:
+        parents = [max(int(p), 0) for p in model_or_ndof.arrays()["parent"]]
+        tag = tree_tag(parents)
+        cmd += ["PARENTS=" + ",".join(str(p) for p in parents), f"TAG={tag}"]
+        name = f"libdwbc_pack_{n}_{nb}_t{tag}.so"
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return os.path.join(os.path.dirname(csrc), name)
 
 
 class Model:

@@ -108,9 +108,11 @@ int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, do
     return 1;
 }
 
-// ---- kernel packs: the cycle kernels of model sizes other than TOCABI's (dwbc_pack.hip), loaded on demand
+// ---- kernel packs: the cycle kernels of model sizes other than TOCABI's (dwbc_pack.hip), loaded on demand.  A pack is either
+//      generic (any tree of its size) or built for one parent table (TopoPack: the tree-sparse sweep); the latter is preferred
+//      when its table equals the model's
 namespace {
-struct KernelPack { void *dl; const KernelEntry *tab; int count; };
+struct KernelPack { void *dl; const KernelEntry *tab; int count; std::vector<int> parents; };  // parents empty: generic
 std::vector<KernelPack> g_packs;
 std::mutex g_pack_mutex;
 bool builtin_has(int n, int nb) {
@@ -118,14 +120,32 @@ bool builtin_has(int n, int nb) {
         if (k.n == n && k.nb == nb) return true;
     return false;
 }
-const KernelEntry *pack_lookup(int n, int nb, int nlv) {
+std::vector<int> clean_parents(const Model &m) {
+    std::vector<int> p(m.parent.size());
+    for (size_t i = 0; i < p.size(); i++) p[i] = m.parent[i] < 0 ? 0 : m.parent[i];
+    return p;
+}
+unsigned tree_tag(const std::vector<int> &parents) {  // FNV-1a over the parents as little-endian 32-bit words (libdwbc_amd.build_pack names the file with it)
+    unsigned h = 2166136261u;
+    for (int p : parents)
+        for (int b = 0; b < 4; b++) { h ^= (unsigned)((p >> (8 * b)) & 0xff); h *= 16777619u; }
+    return h;
+}
+// nlv < 0: any level count.  tree: only a pack built for exactly these parents (or, generic = true, only a generic one)
+const KernelEntry *pack_lookup(int n, int nb, int nlv, const std::vector<int> &parents, bool generic) {
     std::lock_guard<std::mutex> lk(g_pack_mutex);
-    for (const auto &p : g_packs)
+    for (const auto &p : g_packs) {
+        if (generic ? !p.parents.empty() : p.parents != parents) continue;
         for (int i = 0; i < p.count; i++)
             if (p.tab[i].n == n && p.tab[i].nb == nb && (nlv < 0 || p.tab[i].nlv == nlv)) return &p.tab[i];
+    }
     return nullptr;
 }
-static std::string lib_dir_impl() {
+const KernelEntry *pack_pick(int n, int nb, int nlv, const std::vector<int> &parents) {
+    if (const KernelEntry *ke = pack_lookup(n, nb, nlv, parents, false)) return ke;
+    return pack_lookup(n, nb, nlv, parents, true);
+}
+std::string lib_dir_impl() {
     Dl_info di;
     if (dladdr((const void *)&builtin_has, &di) && di.dli_fname) {
         std::string f(di.dli_fname);
@@ -134,31 +154,61 @@ static std::string lib_dir_impl() {
     }
     return ".";
 }
-// true when kernels for (n, nb) exist: built in, already loaded, or in a pack next to this library / under $DWBC_PACK_DIR
-bool ensure_kernels(int n, int nb, std::string &err) {
-    if (builtin_has(n, nb) || pack_lookup(n, nb, -1)) return true;
-    const std::string name = "libdwbc_pack_" + std::to_string(n) + "_" + std::to_string(nb) + ".so";
+// 1 loaded, 0 no such file, -1 unusable (err set)
+int try_load_pack(const std::string &path, const std::vector<int> &parents, bool want_tree, std::string &err) {
+    void *dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return 0;
+    typedef const KernelEntry *(*table_fn)(int *, unsigned *);
+    typedef const int *(*parents_fn)(int *);
+    table_fn tf = (table_fn)dlsym(dl, "dwbc_pack_table");
+    parents_fn pf = (parents_fn)dlsym(dl, "dwbc_pack_parents");
+    int count = 0;
+    unsigned tag = 0;
+    const KernelEntry *tab = tf ? tf(&count, &tag) : nullptr;
+    if (!tab || tag != kernel_abi_tag()) {
+        dlclose(dl);
+        err = path + " was built from another version of the kernels: rebuild it (make -C libdwbc_amd/csrc pack ...)";
+        return -1;
+    }
+    KernelPack kp{dl, tab, count, {}};
+    if (pf) {
+        int pnb = 0;
+        const int *pp = pf(&pnb);
+        kp.parents.assign(pp, pp + pnb);
+    }
+    if (want_tree && kp.parents != parents) {  // a file with this tag but another tree (hash collision or a stale file): not ours
+        dlclose(dl);
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_pack_mutex);
+    g_packs.push_back(kp);
+    return 1;
+}
+// true when kernels for the model exist: built in, already loaded, or in a pack next to this library / under $DWBC_PACK_DIR
+bool ensure_kernels(const Model &m, std::string &err) {
+    const int n = m.ndof, nb = m.nb;
+    if (builtin_has(n, nb)) return true;
+    const std::vector<int> parents = clean_parents(m);
+    if (pack_lookup(n, nb, -1, parents, false)) return true;
+    char tagbuf[16];
+    snprintf(tagbuf, sizeof tagbuf, "%08x", tree_tag(parents));
+    const std::string base = "libdwbc_pack_" + std::to_string(n) + "_" + std::to_string(nb);
     std::vector<std::string> dirs;
     if (const char *e = getenv("DWBC_PACK_DIR")) dirs.push_back(e);
     dirs.push_back(lib_dir_impl());
     std::string tried;
+    for (const auto &d : dirs) {  // the pack of this very tree first
+        const int r = try_load_pack(d + "/" + base + "_t" + tagbuf + ".so", parents, true, err);
+        if (r < 0) return false;
+        if (r > 0) return true;
+    }
+    if (pack_lookup(n, nb, -1, parents, true)) return true;
     for (const auto &d : dirs) {
-        const std::string path = d + "/" + name;
-        void *dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!dl) { tried += " " + path; continue; }
-        typedef const KernelEntry *(*table_fn)(int *, unsigned *);
-        table_fn tf = (table_fn)dlsym(dl, "dwbc_pack_table");
-        int count = 0;
-        unsigned tag = 0;
-        const KernelEntry *tab = tf ? tf(&count, &tag) : nullptr;
-        if (!tab || tag != kernel_abi_tag()) {
-            dlclose(dl);
-            err = path + " was built from another version of the kernels: rebuild it (make -C libdwbc_amd/csrc pack N=" + std::to_string(n) + " NB=" + std::to_string(nb) + ")";
-            return false;
-        }
-        std::lock_guard<std::mutex> lk(g_pack_mutex);
-        g_packs.push_back(KernelPack{dl, tab, count});
-        return true;
+        const std::string path = d + "/" + base + ".so";
+        const int r = try_load_pack(path, parents, false, err);
+        if (r < 0) return false;
+        if (r > 0) return true;
+        tried += " " + path;
     }
     err = "no kernel for a model with " + std::to_string(n) + " dof / " + std::to_string(nb) + " bodies: the cycle kernels are compiled per model size; build the pack once with"
           " `make -C libdwbc_amd/csrc pack N=" + std::to_string(n) + " NB=" + std::to_string(nb) + "` (Python: libdwbc_amd.build_pack(model)); looked for" + tried;
@@ -176,7 +226,7 @@ dwbc_batch *dwbc_batch_create(const dwbc_model *m, int B, int device, int dtype)
         g_err = "model outside the kernels' range (floating base + one revolute joint per body, at most 50 dof)";
         return nullptr;
     }
-    if (!ensure_kernels(m->m.ndof, m->m.nb, g_err)) return nullptr;
+    if (!ensure_kernels(m->m, g_err)) return nullptr;
     if (dtype == DWBC_F32 && !builtin_has(m->m.ndof, m->m.nb)) { g_err = "kernel packs are fp64 only"; return nullptr; }
     auto *b = new dwbc_batch();
     b->model = m;
@@ -486,7 +536,7 @@ static bool lean_ok(const dwbc_batch *b) {
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
     if (const KernelEntry *ke = lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind)) return ke;
-    return reduced ? nullptr : pack_lookup(b->n, b->su.nb, b->su.n_levels);  // packs hold the full-model cycle only
+    return reduced ? nullptr : pack_pick(b->n, b->su.nb, b->su.n_levels, clean_parents(b->model->m));  // packs hold the full-model cycle only
 }
 
 // fp32 launch: the fp32 kernels read and write the double buffers of the boundary themselves (io_t); only the model table is
@@ -811,7 +861,7 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "dwbc::";  // as rocprofv3 prints the instantiations
     if (!ke) return "";
-    const std::string topo = ", " + pre + (ke->topo == 1 ? "TopoTocabi" : "TopoGeneric");
+    const std::string topo = ", " + pre + (ke->topo == 1 ? "TopoTocabi" : (ke->topo == 2 ? "TopoPack" : "TopoGeneric"));
     const std::string sz = std::to_string(ke->n) + ", " + std::to_string(ke->nb);
     if (b->last_reduced) {
         name = pre + "dwbc_cycle_kernel_reduced<" + sz + ", " + std::to_string(ke->nlv) + ", 64" + topo + ">";

@@ -16,17 +16,33 @@ static_assert(DWBC_PACK_N == DWBC_PACK_NB + 5, "floating base (6 dof) + one revo
 static_assert(DWBC_PACK_N <= 50, "one lane per column, and the wave QP keeps (N - 6) + 20 rows on 64 lanes");
 static_assert(DWBC_PACK_NB <= kMaxBodies, "body table");
 
+// with -DDWBC_PACK_PARENTS=... the pack is built for that one kinematic tree (TopoPack, dwbc_topo.h: tree-sparse A^-1 sweep, compile-time
+// round counts) and is only used for a model with exactly that parent table; without it, for any tree of the size (TopoGeneric)
+#ifdef DWBC_PACK_PARENTS
+#define DWBC_PACK_TOPO TopoPack
+#define DWBC_PACK_KIND 2
+#else
+#define DWBC_PACK_TOPO TopoGeneric
+#define DWBC_PACK_KIND 0
+#endif
 #define DWBC_PACK_ENTRY(NLV)                                                                                                        \
-    {DWBC_PACK_N, DWBC_PACK_NB, NLV, 0, dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, TopoGeneric>,                \
-     Lds2<DWBC_PACK_N, DWBC_PACK_NB, NLV>::total_bytes, dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, TopoGeneric>, \
-     dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>,                                                  \
-     dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, TopoGeneric>}
+    {DWBC_PACK_N, DWBC_PACK_NB, NLV, DWBC_PACK_KIND, dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, DWBC_PACK_TOPO>,  \
+     Lds2<DWBC_PACK_N, DWBC_PACK_NB, NLV>::total_bytes, dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, true, DWBC_PACK_TOPO>, \
+     dwbc_cycle_kernel_v2<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, DWBC_PACK_TOPO>,                                               \
+     dwbc_cycle_kernel_v2w<DWBC_PACK_N, DWBC_PACK_NB, NLV, kNT, false, DWBC_PACK_TOPO>}
 #ifdef DWBC_PACK_ONLY_NLV  // development: one level count only (a quarter of the compile time)
 static const KernelEntry kPack[] = {DWBC_PACK_ENTRY(DWBC_PACK_ONLY_NLV)};
 #else
 static const KernelEntry kPack[] = {DWBC_PACK_ENTRY(1), DWBC_PACK_ENTRY(2), DWBC_PACK_ENTRY(3), DWBC_PACK_ENTRY(4)};
 #endif
 
+#ifdef DWBC_PACK_PARENTS
+// the tree this pack was compiled for: the loader compares it with the model's
+extern "C" const int *dwbc_pack_parents(int *nb) {
+    *nb = TopoPack::nb;
+    return TopoPack::parent;
+}
+#endif
 extern "C" const KernelEntry *dwbc_pack_table(int *count, unsigned *abi_tag) {
     *count = (int)(sizeof(kPack) / sizeof(kPack[0]));
     *abi_tag = kernel_abi_tag();

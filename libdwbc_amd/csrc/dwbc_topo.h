@@ -58,4 +58,41 @@ struct TopoTocabi {
 
 static_assert(TopoTocabi::computed_maxdepth() == TopoTocabi::maxdepth, "TopoTocabi::maxdepth");
 
+// A kernel pack built for ONE model's tree (dwbc_pack.hip with -DDWBC_PACK_PARENTS=p0,p1,...: the parent of every body, body 0's
+// entry 0): the same compile-time sparsity and round counts TopoTocabi gives the built-in kernels.  The loader uses such a pack
+// only for a model whose parent table equals this one (dwbc_pack_parents).
+#ifdef DWBC_PACK_PARENTS
+namespace pack_tree {
+constexpr int kParent[DWBC_PACK_NB] = {DWBC_PACK_PARENTS};
+constexpr int max_depth() {
+    int m = 0;
+    for (int b = 0; b < DWBC_PACK_NB; b++) {
+        int d = 0;
+        for (int c = b; c > 0; c = kParent[c]) d++;
+        m = d > m ? d : m;
+    }
+    return m;
+}
+}  // namespace pack_tree
+struct TopoPack {
+    static constexpr int nb = DWBC_PACK_NB;
+    static constexpr int ndof = nb + 5;
+    static constexpr int parent[nb] = {DWBC_PACK_PARENTS};
+    static constexpr bool anc_or_self(int a, int b) {
+        while (b > a) b = parent[b];
+        return a == b;
+    }
+    static constexpr unsigned long long relatives(int k) {
+        unsigned long long m = 0;
+        const int bk = k < 6 ? 0 : k - 5;
+        for (int i = 0; i < ndof; i++) {
+            const int bi = i < 6 ? 0 : i - 5;
+            if (anc_or_self(bi, bk) || anc_or_self(bk, bi)) m |= 1ull << i;
+        }
+        return m;
+    }
+    static constexpr int maxdepth = pack_tree::max_depth();
+};
+#endif
+
 }  // namespace dwbc

@@ -105,12 +105,16 @@ def synth_batch(B, seed=20251226, yaw=False, contact_mode="LR", levels=2):
     return q, flags, fstar
 
 
-def ensure_pack(model):
+def ensure_pack(model, tree=False):
     """the kernel pack of a model size other than TOCABI's: __graft_entry__.build() makes the ones the tests use; only a missing
-    one is compiled here (two minutes of hipcc)"""
+    one is compiled here (two minutes of hipcc).  tree=True: the pack built for this model's own kinematic tree"""
     import libdwbc_amd as D
+    from libdwbc_amd.batch import tree_tag
 
-    path = os.path.join(os.path.dirname(os.path.abspath(D.__file__)), f"libdwbc_pack_{model.ndof}_{model.nb}.so")
+    name = f"libdwbc_pack_{model.ndof}_{model.nb}"
+    if tree:
+        name += "_t" + tree_tag([max(int(p), 0) for p in model.arrays()["parent"]])
+    path = os.path.join(os.path.dirname(os.path.abspath(D.__file__)), name + ".so")
     if not os.path.exists(path):
-        D.build_pack(model)
+        D.build_pack(model, tree=tree)
     return path

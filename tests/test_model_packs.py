@@ -131,7 +131,7 @@ def test_gpu_other_model_sizes_match_oracle(tmp_path, name):
         wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
         wbc.solve()
         tau, st = wbc.get("tau"), wbc.get("status")
-        assert "TopoGeneric" in wbc.kernel_name() and f"<{n}, {nb}," in wbc.kernel_name()
+        assert f"<{n}, {nb}," in wbc.kernel_name()  # (generic pack, or the tree-specific one when it has been built for this variant)
         nok = 0
         for b in range(B):
             r = oracle_cycle(mo, links, q[b], fs[b], lim)
@@ -241,3 +241,49 @@ def test_gpu_43_dof_model_matches_oracle():
             o = oracle_cycle(mo, links, q[b], fs[b], lim)
             assert st[b] == o["status"] == 1
             assert np.abs(tau[b] - np.stack([o["tau_grav"], o["tau_task"], o["tau_contact"]])).max() < TOL_TAU, (b, dump)
+
+
+@pytest.mark.gpu
+def test_gpu_tree_specific_pack_is_preferred_and_only_for_its_own_tree(tmp_path):
+    """A pack built for ONE parent table (TopoPack: tree-sparse sweep like the built-in TOCABI kernels) serves exactly that tree;
+    another 37-dof / 32-body tree keeps the generic pack of the size."""
+    import libdwbc_amd as D
+
+    path = variant_urdf(tmp_path / "fh.urdf", HEAD)
+    mo = urdf_model.load_urdf(path)
+    md = D.Model.from_urdf(path)
+    cases.ensure_pack(md)
+    cases.ensure_pack(md, tree=True)
+    other = D.Model.from_urdf(variant_urdf(tmp_path / "fw.urdf", ["L_Wrist2_Joint", "R_Wrist2_Joint"]))  # same size, other tree
+    assert (other.ndof, other.nb) == (md.ndof, md.nb) and list(other.arrays()["parent"]) != list(md.arrays()["parent"])
+    B = 32
+    q, fs = variant_states(mo, B, seed=13)
+    links = [md.link_id("L_AnkleRoll_Link"), md.link_id("R_AnkleRoll_Link"), md.link_id("Upperbody_Link")]
+    lim = np.full(31, 300.0)
+
+    def run(model, qq):
+        wbc = D.Batch(model, B, device=0)
+        for cc, l in zip(cases.CONTACTS_2, ("L_AnkleRoll_Link", "R_AnkleRoll_Link")):
+            wbc.add_contact(model.link_id(l), cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+        wbc.add_task(0, D.TASK_LINK_6D, 0)
+        wbc.add_task(1, D.TASK_LINK_ROTATION, model.link_id("Upperbody_Link"))
+        wbc.set_torque_limit(lim)
+        wbc.set_state(qq); wbc.set_contact(np.ones((B, 2), np.uint8)); wbc.set_fstar_all(fs)
+        wbc.solve()
+        return wbc.kernel_name(), wbc.get("tau"), wbc.get("status")
+
+    name, tau, st = run(md, q)
+    assert "TopoPack" in name and "<37, 32," in name
+    for b in range(B):
+        o = oracle_cycle(mo, links, q[b], fs[b], lim)
+        assert st[b] == o["status"] == 1
+        assert np.abs(tau[b] - np.stack([o["tau_grav"], o["tau_task"], o["tau_contact"]])).max() < TOL_TAU
+    mo2 = urdf_model.load_urdf(str(tmp_path / "fw.urdf"))
+    q2, _ = variant_states(mo2, B, seed=13)
+    name2, tau2, st2 = run(other, q2)
+    assert "TopoGeneric" in name2
+    links2 = [other.link_id("L_AnkleRoll_Link"), other.link_id("R_AnkleRoll_Link"), other.link_id("Upperbody_Link")]
+    for b in range(B):
+        o = oracle_cycle(mo2, links2, q2[b], fs[b], lim)
+        assert st2[b] == o["status"] == 1
+        assert np.abs(tau2[b] - np.stack([o["tau_grav"], o["tau_task"], o["tau_contact"]])).max() < TOL_TAU
