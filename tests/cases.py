@@ -118,3 +118,19 @@ def ensure_pack(model, tree=False):
     if not os.path.exists(path):
         D.build_pack(model, tree=tree)
     return path
+
+
+# ---- variants of the TOCABI fixture with joints fixed (models of other sizes for the kernel packs; RBDL merges fixed joints)
+HEAD_JOINTS = ["Neck_Joint", "Head_Joint"]
+
+
+def variant_urdf(path_out, fixed):
+    import re
+
+    txt = open(URDF).read()
+    for j in fixed:
+        txt, n = re.subn(r'(name="%s"\s+type=)"revolute"' % j, r'\1"fixed"', txt)
+        assert n == 1, j
+    with open(path_out, "w") as f:
+        f.write(txt)
+    return str(path_out)

@@ -13,20 +13,11 @@ from oracle import dwbc_np as Dn
 from oracle import urdf_model
 from tests import cases
 
-HEAD = ["Neck_Joint", "Head_Joint"]
+HEAD = cases.HEAD_JOINTS
 ARMS = [f"{s}_{j}_Joint" for s in "LR" for j in ("Shoulder1", "Shoulder2", "Shoulder3", "Armlink", "Elbow", "Forearm", "Wrist1", "Wrist2")]
 VARIANTS = {"fixed_head": (HEAD, 37, 32), "fixed_arms": (ARMS, 23, 18)}
 TOL_TAU = 1e-6  # BASELINE north star
-
-
-def variant_urdf(path_out, fixed):
-    txt = open(cases.URDF).read()
-    for j in fixed:
-        txt, n = re.subn(r'(name="%s"\s+type=)"revolute"' % j, r'\1"fixed"', txt)
-        assert n == 1, j
-    with open(path_out, "w") as f:
-        f.write(txt)
-    return str(path_out)
+variant_urdf = cases.variant_urdf
 
 
 def variant_states(model, B, seed):
