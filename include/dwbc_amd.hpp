@@ -455,7 +455,7 @@ class RobotData {
     // ---- LQP formulation on the generic HQP class (dwbc.h:365-371; src/dwbc.cpp:4304-4452): y = [qddot; f_c]
     int ConfigureLQP(HQP &hqp, bool = true) {
         if (!refresh()) return 0;
-        if (!hqp.handle() || hqp.acceleration_size_ != (int)system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(system_dof_, 0, contact_dof_);
+        if (!hqp.handle() || hqp.acceleration_size_ != (int)system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(system_dof_, 0, contact_dof_, device_);
         if (!dwbc_batch_configure_lqp(batch_, hqp.handle())) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         hqp.fetch();
         return 1;
@@ -474,7 +474,7 @@ class RobotData {
     // CalcSingleTaskTorqueWithJACC_QP(ts_[level], init) (src/dwbc.cpp:3772-3945); levels in order
     int CalcSingleTaskTorqueWithJACC_QP(int level, bool = true) {
         if (!refresh()) return 0;
-        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(system_dof_, 0, contact_dof_);
+        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(system_dof_, 0, contact_dof_, device_);
         if (!dwbc_batch_solve_jacc(batch_, jacc_h_.handle(), level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         return fetch_jacc(level, system_dof_);
     }
@@ -483,7 +483,7 @@ class RobotData {
     int ConfigureLQP_R(HQP &hqp, bool = true) {
         reduced_on();
         if (!refresh()) return 0;
-        if (!hqp.handle() || hqp.acceleration_size_ != (int)reduced_system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(reduced_system_dof_, 0, contact_dof_);
+        if (!hqp.handle() || hqp.acceleration_size_ != (int)reduced_system_dof_ || hqp.contact_size_ != (int)contact_dof_) hqp.initialize(reduced_system_dof_, 0, contact_dof_, device_);
         if (!dwbc_batch_configure_lqp_r(batch_, hqp.handle())) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         hqp.fetch();
         return 1;
@@ -492,7 +492,7 @@ class RobotData {
     // q_acc of the reference (= hqp_r.hqp_hs_.back().y_ans_.head(acceleration_size_)) is read on the device from hqp_r itself;
     // nc_level: the 6-D task level on a non-contact link (the reference reads ts_[1])
     int ConfigureLQP_R_NC(HQP &hqp_nc, HQP &hqp_r, int nc_level = 1, bool = true) {
-        if (!hqp_nc.handle() || hqp_nc.acceleration_size_ != (int)nc_dof) hqp_nc.initialize(nc_dof, 0, 0);
+        if (!hqp_nc.handle() || hqp_nc.acceleration_size_ != (int)nc_dof) hqp_nc.initialize(nc_dof, 0, 0, device_);
         if (!dwbc_batch_configure_lqp_r_nc(batch_, hqp_nc.handle(), hqp_r.handle(), nc_level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         hqp_nc.fetch();
         return 1;
@@ -508,12 +508,12 @@ class RobotData {
     int CalcSingleTaskTorqueWithJACC_QP_R(int level, bool = true) {
         reduced_on();
         if (!refresh()) return 0;
-        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)reduced_system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(reduced_system_dof_, 0, contact_dof_);
+        if (!jacc_h_.handle() || jacc_h_.acceleration_size_ != (int)reduced_system_dof_ || jacc_h_.contact_size_ != (int)contact_dof_) jacc_h_.initialize(reduced_system_dof_, 0, contact_dof_, device_);
         if (!dwbc_batch_solve_jacc_r(batch_, jacc_h_.handle(), level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         return fetch_jacc(level, reduced_system_dof_);
     }
     int CalcSingleTaskTorqueWithJACC_QP_R_NC(int level, int src_level, bool = true) {
-        if (!jacc_nc_h_.handle() || jacc_nc_h_.acceleration_size_ != (int)nc_dof) jacc_nc_h_.initialize(nc_dof, 0, 0);
+        if (!jacc_nc_h_.handle() || jacc_nc_h_.acceleration_size_ != (int)nc_dof) jacc_nc_h_.initialize(nc_dof, 0, 0, device_);
         if (!dwbc_batch_solve_jacc_r_nc(batch_, jacc_nc_h_.handle(), level, src_level)) { std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return 0; }
         TaskSpaceView &t = ts_[level];
         t.acc_qp_.assign(nc_dof, 0.0); t.torque_qp_.assign(nc_dof, 0.0); t.gacc_qp_.assign(6, 0.0); t.f_star_qp_.assign(6, 0.0);

@@ -184,7 +184,10 @@ int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src);
 /* page-locked host mirror of an input field (DWBC_IN_Q, DWBC_IN_CONTACT, DWBC_IN_FSTAR; NULL for anything else or before the
  * field has a size): a caller that assembles its states directly in this memory and passes the same pointer to
  * dwbc_batch_set_state / set_contact (or calls dwbc_batch_set_fstar with pointers into it -- level l starts at column
- * fstar offset of l) skips the host-side copy; the upload is one asynchronous PCIe transfer on the batch's stream */
+ * fstar offset of l) skips the host-side copy; the upload is one asynchronous PCIe transfer on the batch's stream.
+ * Lifetime of the contents: dwbc_batch_solve starts that transfer and returns; the mirror may be REWRITTEN only after the next call
+ * of dwbc_batch_host_ptr / dwbc_batch_set_state / set_contact / set_fstar (each waits for the pending upload first) or after
+ * dwbc_batch_sync / dwbc_batch_get.  Writing through a pointer kept from before the solve without one of those calls races the DMA. */
 void *dwbc_batch_host_ptr(dwbc_batch *b, int field);
 /* zero-copy: use a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr) for an input or output field */
 int dwbc_batch_bind_device(dwbc_batch *b, int field, void *device_ptr);

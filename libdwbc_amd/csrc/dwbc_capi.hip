@@ -294,6 +294,7 @@ void dwbc_batch_destroy(dwbc_batch *b) {
     hipFree(b->d_dump);
     hipFree(b->d_body);
     hipFree(b->d_topo);
+    if (b->ev_upload) (void)hipEventDestroy(b->ev_upload);
     delete b;
 }
 
@@ -415,10 +416,19 @@ int dwbc_batch_set_torque_limit(dwbc_batch *b, const double *tau_lim) {
 int dwbc_batch_fstar_size(const dwbc_batch *b) { return b->su.fstar_total; }
 int dwbc_batch_task_dof(const dwbc_batch *b, int level) { return (level >= 0 && level < b->su.n_levels) ? b->su.t_dof[level] : 0; }
 
+// An upload of the page-locked mirrors may still be in flight (hipMemcpyAsync returns at once): wait for it before a mirror is
+// rewritten, so that a pipelined `solve(); set_state(next); solve();` never tears the inputs of the first solve.
+static void wait_uploads(dwbc_batch *b) {
+    if (!b->upload_pending) return;
+    if (b->ev_upload) (void)hipEventSynchronize(b->ev_upload);
+    b->upload_pending = false;
+}
+
 int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot) {
     (void)qddot;  // the reference hands it to RBDL's UpdateKinematicsCustom only; nothing on this path reads accelerations
     if (!q) return fail("q is NULL");
     if (!b->own_q) return fail("q is bound to a device buffer");
+    wait_uploads(b);
     if (q != b->h_q.data()) memcpy(b->h_q.data(), q, b->h_q.size() * sizeof(double));  // (dwbc_batch_host_ptr: already in place)
     b->dirty_q = true;
     if (qdot) {  // B_, link velocities (dump record) and the on-device task reference need it; the torque path does not
@@ -439,6 +449,7 @@ int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags) {
         for (int c = 0; c < ncn; c++) on += flags[(size_t)i * ncn + c] ? 1 : 0;
         if (on > kMaxActiveContacts) return fail("more than 2 simultaneously active contacts in one instance: not supported by the device path");
     }
+    wait_uploads(b);
     if (flags != b->h_flags.data()) memcpy(b->h_flags.data(), flags, b->h_flags.size());
     b->dirty_flags = true;
     return 1;
@@ -448,6 +459,7 @@ int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar) {
     if (level < 0 || level >= b->su.n_levels) return fail("ERROR : task space size overflow");  // src/dwbc.cpp:668-671
     if (b->d_fstar && !b->own_fstar) return fail("f* is bound to a device buffer");
     const int t = b->su.t_dof[level], off = b->su.fstar_off[level], F = b->su.fstar_total;
+    wait_uploads(b);
     if (fstar != b->h_fstar.data() + off)  // (a caller that filled the mirror in place passes host_ptr + off)
         for (int i = 0; i < b->B; i++) memcpy(b->h_fstar.data() + (size_t)i * F + off, fstar + (size_t)i * t, sizeof(double) * t);
     b->dirty_fstar = true;
@@ -455,6 +467,7 @@ int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar) {
 }
 
 void *dwbc_batch_host_ptr(dwbc_batch *b, int field) {
+    wait_uploads(b);  // the caller is about to write into the mirror
     switch (field) {
         case DWBC_IN_Q: return b->h_q.empty() ? nullptr : b->h_q.data();
         case DWBC_IN_CONTACT: return b->h_flags.empty() ? nullptr : b->h_flags.data();
@@ -516,6 +529,7 @@ static int upload_inputs(dwbc_batch *b) {
         HIP_OK(hipMemcpyAsync(b->d_ctime, b->h_ctime.data(), b->h_ctime.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
         b->dirty_ctime = false;
     }
+    const bool qdot_copied = b->dirty_qdot;
     if (b->dirty_qdot) {
         if (!b->d_qdot) HIP_OK(hipMalloc(&b->d_qdot, (size_t)b->B * b->n * sizeof(double)));
         HIP_OK(hipMemcpyAsync(b->d_qdot, b->h_qdot.data(), b->h_qdot.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -524,7 +538,13 @@ static int upload_inputs(dwbc_batch *b) {
     if (b->dirty_q && b->own_q) HIP_OK(hipMemcpyAsync(b->d_q, b->h_q.data(), b->h_q.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     if (b->dirty_flags && b->own_flags) HIP_OK(hipMemcpyAsync(b->d_flags, b->h_flags.data(), b->h_flags.size(), hipMemcpyHostToDevice, b->stream));
     if (b->dirty_fstar && b->own_fstar) HIP_OK(hipMemcpyAsync(b->d_fstar, b->h_fstar.data(), b->h_fstar.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    const bool copied = (b->dirty_q && b->own_q) || (b->dirty_flags && b->own_flags) || (b->dirty_fstar && b->own_fstar) || qdot_copied;
     b->dirty_q = b->dirty_flags = b->dirty_fstar = false;
+    if (copied) {
+        if (!b->ev_upload) HIP_OK(hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming));
+        HIP_OK(hipEventRecord(b->ev_upload, b->stream));
+        b->upload_pending = true;
+    }
     return 1;
 }
 
@@ -669,6 +689,7 @@ int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src) {
     if (dst == src) return 1;
     if (dst->B != src->B || dst->n != src->n || dst->su.nb != src->su.nb) return fail("CopyKinematicsData: batch size / model mismatch");
     HIP_OK(hipSetDevice(dst->device));
+    wait_uploads(dst);  // the target's mirrors are rewritten below
     dst->su = src->su;
     auto clone = [&](double *&dd, bool &own, const double *sd, size_t count, PinnedVec<double> &hd, const PinnedVec<double> &hs, bool &dirty,
                      bool src_own) -> int {

@@ -93,6 +93,10 @@ struct dwbc_batch {
     double *d_jacc_nc = nullptr;              // B x jacc_nc_rec_size (dwbc_batch_solve_jacc_r_nc)
     int *d_jacc_nc_status = nullptr;
     bool dirty_q = false, dirty_fstar = false, dirty_flags = false;
+    // the mirrors are page-locked, so an upload returns before the DMA engine has read them: this event is recorded behind the
+    // host-to-device copies of a solve and waited for before anything rewrites a mirror (dwbc_batch_set_*, dwbc_batch_host_ptr)
+    hipEvent_t ev_upload = nullptr;
+    bool upload_pending = false;
     bool attr_set = false;
     int n_cu = 0;
     dwbc::DumpLayout dl{};

@@ -88,6 +88,12 @@ constexpr real_t kQpTol = kF32 ? real_t(DWBC_F32_TOL) : real_t(1.0e-9);
 constexpr real_t kQpZeroRow = kF32 ? real_t(1.0e-5) : real_t(1.0e-9);     // rows with a smaller norm are the constraint 0 <= hi
 constexpr real_t kQpFeasTol = kF32 ? real_t(DWBC_F32_FEAS) : real_t(1.0e-7);     // acceptance of the lexicographic point (slack / |row|)
 constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
+constexpr real_t kQpReorth = real_t(1.0e-2);  // |H n|^2 below which the new direction is projected a second time (dwbc_qp_wave.h)
+#ifndef DWBC_QP_REFINE
+#define DWBC_QP_REFINE 10
+#endif
+constexpr int kQpRefine = DWBC_QP_REFINE;   // most iterated-Tikhonov steps towards the lexicographic point (dwbc_qp_wave.h)
+constexpr real_t kQpRefineTol = kF32 ? real_t(1.0e-5) : real_t(1.0e-12);  // a step's change / |x| below which the sequence has settled
 }  // namespace dwbc
 #include "dwbc_qp_wave.h"
 namespace dwbc {

@@ -319,8 +319,8 @@ DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real
 // pivot is not positive (rank deficient block => status 0, where the reference would return a pseudo-inverse).
 // n <= 6: the Cholesky factor is computed redundantly by every lane on uniform (LDS-broadcast) data -- 56 FMAs, no
 // cross-lane traffic -- and lane c < n then solves L L^T x = e_c for column c of the inverse with 30 FMAs.  About half
-// the fp64 instructions of the 12-wide register sweep, which matters because one wave issues an fp64 VALU op only
-// every ~12 cycles (tools/ubench).
+// the instructions of the 12-wide register sweep and none of its v_readlane broadcasts (a lone wave issues one instruction of
+// any kind per ~5 cycles, a readlane-fed FMA costs ~21: profiles/r02_ubench3_instruction_costs.txt).
 DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, int ldo) {
     DWBC_LANE_DECL;
     real_t Lc[6][6], ri[6];
@@ -815,6 +815,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             base[i] = acc;
         }
         DWBC_SYNC();
+        if (qi == 0) DWBC_FSTAMP(42);  // level 0: base torque
         // contact wrench map in the contact frame: F = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
             const int i = fdt1.div(idx), j = idx - i * (t + 1);
@@ -830,6 +831,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             L[S::t_s1 + i * (T + 1) + j] = acc;
         }
         DWBC_SYNC();
+        if (qi == 0) DWBC_FSTAMP(43);  // level 0: wrench map
         for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
             const int i = fdt1.div(idx), j = idx - i * (t + 1);
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;

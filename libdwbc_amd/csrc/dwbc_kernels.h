@@ -114,7 +114,11 @@ inline const KernelEntry *lookup_kernel(int n, int nb, int nlv, int which, int t
 }
 #endif
 
-// what a pack and the library that loads it must agree on (both are built from this header)
-inline unsigned kernel_abi_tag() { return (unsigned)(sizeof(Setup) * 2654435761u) ^ (unsigned)(sizeof(BatchIO) * 40503u) ^ (unsigned)(DG_COUNT * 97u) ^ (unsigned)sizeof(KernelEntry); }
+// what a pack and the library that loads it must agree on (both are built from this header): the sizes of the shared structures
+// and a hash of the kernel sources (Makefile: DWBC_SRC_HASH), so that a pack left over from older kernel code is refused
+#ifndef DWBC_SRC_HASH
+#define DWBC_SRC_HASH 0u
+#endif
+inline unsigned kernel_abi_tag() { return (unsigned)(DWBC_SRC_HASH) ^ (unsigned)(sizeof(Setup) * 2654435761u) ^ (unsigned)(sizeof(BatchIO) * 40503u) ^ (unsigned)(DG_COUNT * 97u) ^ (unsigned)sizeof(KernelEntry); }
 
 }  // namespace dwbc

@@ -16,6 +16,8 @@
 // The final point (DESIGN.md "QP canon") comes from a column-pivoted Householder QR of the weighted working-set
 // normals done in place in the owner lanes (no gather), fully unrolled over the elimination step.
 #pragma once
+#include <type_traits>
+
 #include "dwbc_wave.h"
 
 namespace dwbc {
@@ -115,6 +117,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LV(m) = real_t(0.0);
         LV(dz) = real_t(0.0);
     }
+    DWBC_QPT(6);  // rows normalised, operators initialised
     // ---- Goldfarb-Idnani dual active set on min 1/2 |x|^2 (scaled variables), x = 0 start
     int used = 0, q = 0, it = 0, status = 1, p = 0, side = 0, kmin = 0;
     bool pick = true;
@@ -194,7 +197,28 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             LV(dz) = s_;  // change of g.x per unit step along z
             LV(val) = side ? LV(R.lo) + LV(d) : LV(R.hi) - LV(d);
         }
-        const real_t zg = sgn * BCAST(dz, p);  // n.z = |z|^2
+        real_t zg = sgn * BCAST(dz, p);  // n.z = |z|^2
+        // z = H n loses digits when n lies close to the span of the working set (the rows are unit vectors, so |z|^2 is the squared
+        // sine of that angle): H is kept by rank-one updates, i.e. classical Gram-Schmidt.  "Twice is enough": project once more.
+        // Without it the final point carries ~1e-9 relative round-off on tilted feet (3e-7 Nm against the oracle instead of 2e-8);
+        // about one step in five takes this branch.
+        if (zg < kQpReorth) {
+            LANES {
+                real_t s_ = real_t(0.0);
+#pragma unroll
+                for (int j = 0; j < NV; j++) s_ += LV(Mx)[j] * zu[j];
+                if (lane < NV) LV(m) = s_;  // (the slot lanes keep r = N^+ n)
+            }
+#pragma unroll
+            for (int i = 0; i < NV; i++) zu[i] = BCAST(m, i);
+            LANES {
+                real_t s_ = real_t(0.0);
+#pragma unroll
+                for (int j = 0; j < NV; j++) s_ += LV(R.g)[j] * zu[j];
+                LV(dz) = s_;
+            }
+            zg = sgn * BCAST(dz, p);
+        }
         const real_t sp = BCAST(val, p);       // slack of the violated side (negative)
         const bool zok = zg > (kF32 ? real_t(1e-10) : real_t(1e-20)) && q < nv;
         DWBC_QPT(2);
@@ -290,116 +314,105 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
 #pragma unroll
     for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
     if (!(k > 0 && t > 0)) return;
-    // ---- lexicographic least-norm point on the working set: contact block weighted by kQpScalePolish.  The weighted
-    //      normal of an active row stays in its owner lane, entries in POSITION order (contact variables first = row
-    //      sorting).  Column-pivoted Householder QR, step s unrolled: pivot lane by wave arg-max of the remaining column
-    //      norm, pivot column broadcast with v_readlane, reflector applied by every pending lane; the forward
-    //      substitution R^T y = b is folded into the same step (acc = b - sum_j R[j] y_j per lane).
+    // ---- lexicographic least-norm point on the working set (min |delta| first, then min |c|) from the operators the search
+    //      already holds.  With N the active normals (scaled variables) the GI iterate is x^ = N^+T b, the minimiser of
+    //      1/2 |delta|^2 + 1/2 |c^|^2 on the working set; the minimiser of 1/2 |delta|^2 + 1/2 |c^ - c^_k|^2 on it is
+    //      x_{k+1} = x^ + H [0; c^_k]  (H = I - N N^+, rows in lanes 0..NV-1).  From c^_0 = 0 this proximal-point sequence
+    //      converges to the minimiser of |delta| whose c is closest to 0 -- the lexicographic point -- i.e. to the solution of
+    //            (I - H_cc) c^ = c^_1        (H_cc: the contact block of the projector; symmetric, eigenvalues in [0, 1]),
+    //      then delta = delta^ + H_dc c^.  On a well-posed contact block I - H_cc is the identity up to
+    //      |g_delta|^2 / (s^2 |g_c|^2) ~ 1e-8 (s = kQpScaleGI); tilted feet bring eigenvalues down to 1e-2.  Conjugate gradients on
+    //      the 6 x 6 system -- one 6-term dot product per lane and 6 broadcasts per step, the vector recurrences on uniform data --
+    //      end in one or two steps in the first case and in at most k steps in any.  A residual that has not settled by then is
+    //      the block on which the lexicographic point blows up (DESIGN.md "QP canon" rule 3): the Tikhonov point stands.
+    //      (Replaces the column-pivoted Householder QR of the weighted normals of rounds 1-2, ~13 k cycles per QP.)
     {
-        const real_t wsc = kQpScalePolish / kQpScaleGI;
-        PLA(real_t, c, NV);
-        PL(real_t, acc);
-        PL(int, pend);
-        LANES {
-            const real_t sgw = LV(actf) ? ((LV(actf) & 2) ? -real_t(1.0) : real_t(1.0)) : real_t(0.0);  // row as (sg g).x = b
-            if (t == 6 && k == 6) { DWBC_QP_PERM_CASE(6, 6) }
-            else if (t == 3 && k == 6) { DWBC_QP_PERM_CASE(3, 6) }
-            else {
-#pragma unroll
-                for (int i = 0; i < NV; i++) {
-                    const int var = (i < k) ? t + i : i - k;
-                    real_t gv = real_t(0.0);
-#pragma unroll
-                    for (int j = 0; j < NV; j++) gv = (j == var) ? LV(R.g)[j] : gv;
-                    LV(c)[i] = (i < nv) ? sgw * gv * ((i < k) ? wsc : real_t(1.0)) : real_t(0.0);
-                }
-            }
-            LV(acc) = LV(actf) ? ((LV(actf) & 2) ? LV(R.lo) : LV(R.hi)) : real_t(0.0);
-            LV(pend) = LV(actf) ? 1 : 0;
-        }
-        real_t y[NV];
-#pragma unroll
-        for (int i = 0; i < NV; i++) y[i] = real_t(0.0);
-        WSYNC();
-#pragma unroll
-        for (int s = 0; s < NV; s++) {
-            if (s < q) {
-                LANES {
-                    real_t c2 = real_t(0.0);
-#pragma unroll
-                    for (int j = s; j < NV; j++) c2 += LV(c)[j] * LV(c)[j];
-                    LV(val) = LV(pend) ? -c2 : DWBC_QP_INF;
-                }
-                int jp;
-                WAVE_ARGMIN_F32(val, jp);
-                real_t v[NV];
-#pragma unroll
-                for (int j = s; j < NV; j++) v[j] = BCASTA(c, j, jp);
-                const real_t nrm2 = -BCAST(val, jp);
-                const real_t a0 = v[s];
-                const real_t nrm = sqrt(nrm2);
-                const real_t alpha = a0 > 0 ? -nrm : nrm;
-                const real_t vs0 = a0 - alpha;
-                const real_t vn2 = nrm2 - a0 * a0 + vs0 * vs0;
-                const real_t bt = vn2 > real_t(0.0) ? real_t(2.0) * fast_rcp(vn2) : real_t(0.0);
-                v[s] = vs0;
-                LANES {
-                    if (LV(pend)) {
-                        real_t dd = real_t(0.0);
-#pragma unroll
-                        for (int j = s; j < NV; j++) dd += v[j] * LV(c)[j];
-                        dd *= bt;
-#pragma unroll
-                        for (int j = s; j < NV; j++) LV(c)[j] -= dd * v[j];
-                    }
-                    if (lane == 0) {
-#pragma unroll
-                        for (int j = s; j < NV; j++) V[s * NV + j] = v[j];
-                        V[NV * NV + s] = bt;
-                    }
-                }
-                const real_t ys = BCAST(acc, jp) * fast_rcp(alpha);
-                y[s] = ys;
-                LANES {
-                    if (lane == jp) LV(pend) = 0;
-                    if (LV(pend)) LV(acc) -= LV(c)[s] * ys;
-                }
-            }
-        }
-        DWBC_QPT(5);
-        WSYNC();
-        // x~ = Q [y; 0] = H_0 ... H_{q-1} [y; 0] on a uniform 12-vector
-#pragma unroll
-        for (int s = NV - 1; s >= 0; s--) {
-            if (s < q) {
-                real_t dd = real_t(0.0);
-                real_t v[NV];
-#pragma unroll
-                for (int j = s; j < NV; j++) { v[j] = V[s * NV + j]; dd += v[j] * y[j]; }
-                dd *= V[NV * NV + s];
-#pragma unroll
-                for (int j = s; j < NV; j++) y[j] -= dd * v[j];
-            }
-        }
-        DWBC_QPT(6);
-        // back to variable order, in the GI scaling (for the slack test) and unscaled (result)
         real_t xs[NV];
-        if (t == 6 && k == 6) {
+        constexpr int KC = 6;  // contact-null variables: k <= 6 (one or two 6D contacts)
+        static_assert(NV >= KC, "variable blocks");
+        bool settled = false;
+        // STD: the layout every lean launch has when it gets here (t = NV - 6 task variables, then 6 contact-null ones): the
+        // contact block sits at compile-time positions.  Any other (t, k) -- TASK_CUSTOM levels of the full build -- picks its
+        // entries with uniform selects.
+        auto lex_point = [&](auto std_tag) {
+            constexpr bool STD = decltype(std_tag)::value;
+            real_t cx[KC], cr[KC], cp[KC], cb[KC];
 #pragma unroll
-            for (int j = 0; j < NV; j++) xs[j] = (j < 6) ? y[(6 + j) < NV ? 6 + j : 0] : y[j >= 6 ? j - 6 : 0] * wsc;
-        } else if (t == 3 && k == 6) {
+            for (int i = 0; i < KC; i++) {
+                real_t v = real_t(0.0);
+                if constexpr (STD) {
+                    v = xu[NV - KC + i];
+                } else {
 #pragma unroll
-            for (int j = 0; j < NV; j++) xs[j] = (j < 3) ? y[(6 + j) < NV ? 6 + j : 0] : (j < 9 ? y[j >= 3 ? j - 3 : 0] * wsc : real_t(0.0));
-        } else {
-#pragma unroll
-            for (int j = 0; j < NV; j++) {
-                const int pos = (j >= t) ? j - t : k + j;
-                real_t yv = real_t(0.0);
-#pragma unroll
-                for (int i = 0; i < NV; i++) yv = (i == pos) ? y[i] : yv;
-                xs[j] = (j < nv) ? yv * ((j >= t) ? wsc : real_t(1.0)) : real_t(0.0);
+                    for (int j = 0; j < NV; j++) v = (j == t + i && i < k) ? xu[j] : v;
+                }
+                cb[i] = v;    // c^_1
+                cx[i] = v;    // start at the Tikhonov point: I - H_cc ~ I
             }
-        }
+            // one product with H: lanes 0..NV-1 get (H [0; v])_lane
+            auto hmul = [&](const real_t (&v)[KC]) {
+                LANES {
+                    real_t s_ = real_t(0.0);
+                    if constexpr (STD) {
+#pragma unroll
+                        for (int i = 0; i < KC; i++) s_ += LV(Mx)[NV - KC + i] * v[i];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NV; j++) {
+                            real_t vj = real_t(0.0);
+#pragma unroll
+                            for (int i = 0; i < KC; i++) vj = (j == t + i && i < k) ? v[i] : vj;
+                            s_ += LV(Mx)[j] * vj;
+                        }
+                    }
+                    LV(m) = s_;
+                }
+            };
+            auto hcc = [&](int i) -> real_t {  // entry i of the contact block of the last product
+                real_t h_;
+                if constexpr (STD) h_ = BCAST(m, NV - KC + i);
+                else h_ = (i < k) ? BCAST(m, t + i) : real_t(0.0);
+                return h_;
+            };
+            hmul(cx);
+            real_t rs = real_t(0.0), bn = real_t(0.0);
+#pragma unroll
+            for (int i = 0; i < KC; i++) {
+                cr[i] = cb[i] - (cx[i] - hcc(i));  // r = b - (I - H_cc) x
+                cp[i] = cr[i];
+                rs += cr[i] * cr[i];
+                bn += cb[i] * cb[i];
+            }
+            const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
+            for (int r = 0; r < kQpRefine && rs > rtol2; r++) {
+                hmul(cp);
+                real_t ap[KC], pap = real_t(0.0);
+#pragma unroll
+                for (int i = 0; i < KC; i++) {
+                    ap[i] = cp[i] - hcc(i);
+                    pap += cp[i] * ap[i];
+                }
+                if (!(pap > real_t(0.0))) break;
+                const real_t al = rs * fast_rcp(pap);
+                real_t rs2 = real_t(0.0);
+#pragma unroll
+                for (int i = 0; i < KC; i++) {
+                    cx[i] += al * cp[i];
+                    cr[i] -= al * ap[i];
+                    rs2 += cr[i] * cr[i];
+                }
+                const real_t be = rs2 * fast_rcp(rs);
+#pragma unroll
+                for (int i = 0; i < KC; i++) cp[i] = cr[i] + be * cp[i];
+                rs = rs2;
+            }
+            settled = !(rs > rtol2);
+            hmul(cx);  // x = x^ + H [0; c^]  (its contact block reproduces c^ when the residual is zero)
+#pragma unroll
+            for (int i = 0; i < NV; i++) xs[i] = xu[i] + BCAST(m, i);
+        };
+        if (!WS || (t == NV - KC && k == KC)) lex_point(std::true_type{}); else lex_point(std::false_type{});
+        DWBC_QPT(5);
         // worst slack of the lexicographic point, normalised by the unscaled row norm
         LANES {
             real_t dd = real_t(0.0);
@@ -413,7 +426,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         WAVE_ARGMIN_F32(val, wi);
         const real_t wv = BCAST(val, wi);
         DWBC_QPT(7);
-        if (!(wv < -kQpFeasTol)) {
+        if (settled && !(wv < -kQpFeasTol)) {
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
             for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);

@@ -17,7 +17,7 @@ struct TopoDense {
     static constexpr unsigned long long relatives(int) { return ~0ull; }
 };
 
-// TOCABI (tests/golden/dyros_tocabi.urdf; the robot of every reference test, example and BASELINE config): pelvis 0, left leg
+// TOCABI (libdwbc_amd/data/dyros_tocabi.urdf; the robot of every reference test, example and BASELINE config): pelvis 0, left leg
 // 1-6, right leg 7-12, waist 13-15, left arm 16-23, head 24-25, right arm 26-33.  RBDL body order = URDF depth-first order.
 struct TopoTocabi {
     static constexpr int nb = 34;

@@ -47,7 +47,11 @@ def mujoco_to_rbdl_q(qpos):
 class RlWBCBridge:
     def __init__(self, n_envs, urdf, device=0, torque_limit=300.0, dtype="f64", hqp=False):
         """dtype="f32": the fp32 kernels -- the bridge returns float32 torques either way.
-        hqp=False: the reference bridge's effective behaviour (module docstring); hqp=True: QP cascade every step."""
+        hqp=False: the reference bridge's effective behaviour (module docstring); hqp=True: QP cascade every step.
+        torque_limit only enters the QP rows: with hqp=False (the default, as in the reference bridge) it has NO effect -- the
+        plain hierarchy and the closed-form redistribution know no torque limit or friction cone.  With hqp=True every step after
+        the first is a hot start (init=False), which runs the full kernel build (working sets carried in HBM), about 10 % slower
+        per launch than the lean build a cold solve uses."""
         self.n_envs = int(n_envs)
         self.hqp = bool(hqp)
         self.model = Model.from_urdf(urdf)

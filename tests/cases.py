@@ -1,38 +1,19 @@
 """Shared test inputs: the reference's asserted states (tests/dwbc_test.cpp:48-77,152-181,262-308 in
-/root/reference) and the seeded synthetic TOCABI batches of SURVEY.md section 8d."""
+/root/reference) and the seeded synthetic TOCABI batches of SURVEY.md section 8d.  The set-up and the input recipe live in the
+package (libdwbc_amd/workloads.py: the bench's product engine imports nothing under tests/); this module re-exports them and adds
+what only the tests need (golden readers, the oracle's model, pack / URDF-variant helpers)."""
 import os
 
-import numpy as np
+import numpy as np  # noqa: F401
+
+from libdwbc_amd.workloads import (  # noqa: F401
+    CONTACTS_2, CONTACTS_4, FOOT_POINT, FSTAR_CASE, Q_CASE, TASK_LINK_6D, TASK_LINK_ROTATION, TASKS_2LEVEL, TASKS_3LEVEL_SWING_L,
+    TASKS_3LEVEL_SWING_R, TAU_LIM, TOCABI_URDF, synth_batch, yaw_quat,
+)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-URDF = os.path.join(GOLDEN, "dyros_tocabi.urdf")
-
-TASK_LINK_6D, TASK_LINK_ROTATION = 0, 6
-
-# reference tests/dwbc_test.cpp:48-54 (case 1) and :152-158 (case 2)
-Q_CASE = {
-    1: [0, 0, 0.92983, 0, 0, 0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0.0, 0.0, -0.24, 0.6, -0.36, 0.0, 0, 0, 0,
-        0.3, 0.3, 1.5, -1.27, -1, 0, -1, 0, 0, 0, -0.3, -0.3, -1.5, 1.27, 1, 0, 1, 0, 1],
-    2: [0, 0, 0.92983, 0, 0, 0, 0.1, 0.0, -0.24, 0.5, -0.6, 0.0, 0.05, 0.0, -0.21, 0.7, -0.31, 0.0, 0, 0, 0,
-        0.2, 0.5, 1.5, -1.27, -1.2, 0, -1, 0, 0, 0, -0.3, -0.3, -1.5, 1.27, 1.3, 0.1, 1.3, 0, 1],
-}
-FSTAR_CASE = {1: ([0.1, 4.0, 0.1, 0.1, -0.1, 0.1], [0.1, -0.1, 0.1]), 2: ([0.4, 2.0, 0.1, 0.3, -0.1, 0.1], [0.1, 0.1, 0.1])}
-
-FOOT_POINT = (0.03, 0.0, -0.1585)
-# reference tests/dwbc_test.cpp:66-69: four registered contacts, only the feet are ever enabled
-CONTACTS_4 = [
-    dict(link=6, point=FOOT_POINT, lx=0.15, ly=0.075, mu=0.2, muz=0.2),
-    dict(link=12, point=FOOT_POINT, lx=0.15, ly=0.075, mu=0.2, muz=0.2),
-    dict(link=23, point=FOOT_POINT, lx=0.04, ly=0.04, mu=0.2, muz=0.2),
-    dict(link=31, point=FOOT_POINT, lx=0.04, ly=0.04, mu=0.2, muz=0.2),
-]
-CONTACTS_2 = CONTACTS_4[:2]
-TASKS_2LEVEL = [[(TASK_LINK_6D, 0, (0, 0, 0))], [(TASK_LINK_ROTATION, 15, (0, 0, 0))]]
-# single support + swing foot as a third level
-TASKS_3LEVEL_SWING_R = TASKS_2LEVEL + [[(TASK_LINK_6D, 12, (0, 0, 0))]]
-TASKS_3LEVEL_SWING_L = TASKS_2LEVEL + [[(TASK_LINK_6D, 6, (0, 0, 0))]]
-TAU_LIM = [300.0] * 33
+URDF = TOCABI_URDF
 
 
 def tocabi_model():
@@ -48,61 +29,6 @@ def golden(case, name):
     from oracle.dwbc_np import read_golden
 
     return read_golden(os.path.join(GOLDEN, "cases", str(case), name))
-
-
-def yaw_quat(yaw, roll=0.0, pitch=0.0):
-    """quaternion (x,y,z,w) of Rx(roll)*Ry(pitch)*Rz(yaw) -- the composition used by reference
-    tests/dwbc_test.cpp:268-271 (AngleAxis X * Y * Z)."""
-    def q_axis(a, ang):
-        s = np.sin(ang / 2)
-        return np.array([a[0] * s, a[1] * s, a[2] * s, np.cos(ang / 2)])
-
-    def qmul(p, q):
-        px, py, pz, pw = p
-        qx, qy, qz, qw = q
-        return np.array([
-            pw * qx + px * qw + py * qz - pz * qy,
-            pw * qy - px * qz + py * qw + pz * qx,
-            pw * qz + px * qy - py * qx + pz * qw,
-            pw * qw - px * qx - py * qy - pz * qz,
-        ])
-
-    return qmul(qmul(q_axis((1, 0, 0), roll), q_axis((0, 1, 0), pitch)), q_axis((0, 0, 1), yaw))
-
-
-def synth_batch(B, seed=20251226, yaw=False, contact_mode="LR", levels=2):
-    """Seeded synthetic TOCABI states: q = nominal stance + 0.01 U(-1,1), identity or random-yaw
-    base orientation, f* = fixture values + 0.1 U.  contact_mode: 'LR' | 'L' | 'R' | 'mixed'.
-    Returns q (B,40), flags (B,2) uint8, fstar (B, 9 or 15)."""
-    rng = np.random.Generator(np.random.Philox(seed))
-    q0 = np.array(Q_CASE[1], dtype=np.float64)
-    q = q0[None, :] + 0.01 * rng.uniform(-1, 1, size=(B, 40))
-    q[:, 3:6] = 0.0
-    q[:, 39] = 1.0
-    if yaw:
-        ya = rng.uniform(-np.pi, np.pi, size=B)
-        ro = rng.uniform(-0.1, 0.1, size=B)
-        pi = rng.uniform(-0.1, 0.1, size=B)
-        for b in range(B):
-            qu = yaw_quat(ya[b], ro[b], pi[b])
-            q[b, 3:6] = qu[:3]
-            q[b, 39] = qu[3]
-    f0 = np.array(FSTAR_CASE[1][0]) + 0.1 * rng.uniform(-1, 1, size=(B, 6))
-    f1 = np.array(FSTAR_CASE[1][1]) + 0.1 * rng.uniform(-1, 1, size=(B, 3))
-    fs = [f0, f1]
-    if levels == 3:
-        fs.append(np.array([0, 0, 0.5, 0, 0, 0.0]) + 0.1 * rng.uniform(-1, 1, size=(B, 6)))
-    fstar = np.concatenate(fs, axis=1)
-    flags = np.ones((B, 2), dtype=np.uint8)
-    if contact_mode == "L":
-        flags[:, 1] = 0
-    elif contact_mode == "R":
-        flags[:, 0] = 0
-    elif contact_mode == "mixed":
-        u = rng.uniform(0, 1, size=B)
-        flags[(u >= 0.5) & (u < 0.75), 1] = 0
-        flags[u >= 0.75, 0] = 0
-    return q, flags, fstar
 
 
 def ensure_pack(model, tree=False):

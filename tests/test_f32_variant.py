@@ -122,16 +122,30 @@ def test_gpu_f32_reduced_kernel_config5_within_envelope():
     t64, w64, s64 = out["f64"]
     # (1) seeded subset against the oracle (numpy restatement, seconds per 100 instances)
     tau, wr, st = oracle_batch(q[:NS], fl[:NS], fs[:NS])
-    assert (s32[:NS] == st).mean() >= 0.9
     ok = (st == 1) & (s32[:NS] == 1)
-    assert ok.mean() > 0.5
-    assert np.abs(t32[:NS][ok][:, :2] - tau[ok][:, :2]).max() < TOL_F32  # gravity and task torque
-    assert np.median(np.abs(t32[:NS][ok][:, 2] - tau[ok][:, 2]).max(axis=1)) < 1.0  # redistribution: H_temp^T H_temp is ill conditioned in fp32
-    # (2) full batch: fp32 against the fp64 kernel (itself checked against the oracle in tests/test_reduced_path.py)
-    assert (s32 == s64).mean() >= 0.9
     both = (s32 == 1) & (s64 == 1)
-    assert both.mean() > 0.5
-    assert np.abs(t32[:, 0] - t64[:, 0]).max() < 0.05  # gravity torque: no QP involved
-    assert np.abs(t32[both][:, 1] - t64[both][:, 1]).max() < TOL_F32
+    e_gt = np.abs(t32[:NS][ok][:, :2] - tau[ok][:, :2]).max(axis=(1, 2))
+    e_rd = np.abs(t32[:NS][ok][:, 2] - tau[ok][:, 2]).max(axis=1)
+    e_rd64 = np.abs(t32[both][:, 2] - t64[both][:, 2]).max(axis=1)
+    e_tk64 = np.abs(t32[both][:, 1] - t64[both][:, 1]).max(axis=1)
+    m = dict(status_vs_oracle=float((s32[:NS] == st).mean()), ok_fraction_subset=float(ok.mean()), status_vs_f64=float((s32 == s64).mean()),
+             ok_fraction_batch=float(both.mean()), grav_task_max=float(e_gt.max()), redis_p50=float(np.median(e_rd)), redis_p99=float(np.percentile(e_rd, 99)),
+             redis_max=float(e_rd.max()), redis_vs_f64_p50=float(np.median(e_rd64)), redis_vs_f64_p99=float(np.percentile(e_rd64, 99)),
+             task_vs_f64_p99=float(np.percentile(e_tk64, 99)), task_vs_f64_max=float(e_tk64.max()),
+             grav_vs_f64_max=float(np.abs(t32[:, 0] - t64[:, 0]).max()))
+    print("config5 fp32 x reduced, B = 8192, measured:", {k: round(v, 6) for k, v in m.items()})
+    # thresholds = what was measured on MI355X in round 3 (printed above on every run) with a margin of ~4x, not "anything goes":
+    #   status_vs_oracle 1.0, ok_fraction_subset 1.0, grav_task_max 4.5e-3 Nm, redis p50 / p99 / max 1.3e-3 / 3.9e-3 / 4.4e-3 Nm,
+    #   status_vs_f64 0.99988, ok_fraction_batch 0.9990, task_vs_f64_max 2.9e-3 Nm, grav_vs_f64_max 5.7e-3 Nm
+    # (1) seeded subset against the fp64 restatement of the reduced path
+    assert m["status_vs_oracle"] >= 0.98
+    assert m["ok_fraction_subset"] > 0.95
+    assert m["grav_task_max"] < 0.02          # gravity and task torque, Nm
+    assert m["redis_p99"] < 0.02 and m["redis_max"] < 0.05  # redistribution torque (H_temp^T H_temp is the ill-conditioned part in fp32)
+    # (2) full batch: fp32 against the fp64 kernel (itself checked against the oracle in tests/test_reduced_path.py)
+    assert m["status_vs_f64"] >= 0.995
+    assert m["ok_fraction_batch"] > 0.99
+    assert m["grav_vs_f64_max"] < 0.02        # gravity torque: no QP involved
+    assert m["task_vs_f64_max"] < 0.02 and m["redis_vs_f64_p99"] < 0.02
     assert np.isfinite(t32).all() and np.isfinite(w32).all()
     assert (w32[s32 == 1][:, 2] < 0).all() and (w32[s32 == 1][:, 8] < 0).all()  # both feet loaded (f_z < 0 convention)

@@ -92,8 +92,9 @@ def test_case3_yaw_invariance_on_device():
 
 @pytest.mark.parametrize("yaw", [False, True])
 def test_double_support_batch_vs_oracle(yaw):
-    """BASELINE config 2 shape (double support, 2-level HQP, tau limit) at a size the oracle finishes in seconds."""
-    B = 512
+    """BASELINE configs[1] at its full size (batch = 1024, double support, 2-level HQP, tau limit): every instance against the
+    oracle (the C restatement does 1024 cycles in a fraction of a second)."""
+    B = 1024
     q, flags, fstar = cases.synth_batch(B, seed=20251226 + 2, yaw=yaw)
     wbc = _make(B)
     tau, wr, st = _run(wbc, q, flags, fstar)
@@ -530,3 +531,36 @@ def test_warm_start_sequence_on_device():
             steps_c += int(dc[:, 4:9].sum())
     assert 0 < steps_w <= steps_c
     assert "false" in ref.kernel_name() and "true" in wbc.kernel_name()  # cold = lean build, warm = full build (carries the sets)
+
+
+def test_pipelined_set_state_does_not_tear_the_previous_upload():
+    """the host mirrors are page-locked, so dwbc_batch_solve returns while the DMA engine is still reading
+    them.  Rewriting a mirror right behind a solve -- through dwbc_batch_set_state / set_fstar or in place through
+    dwbc_batch_host_ptr -- must wait for that upload: the first solve's results are those of ITS inputs, bit for bit."""
+    B = 65536  # 21 MB of q: the upload is still in flight when the next call comes
+    q, flags, fstar = cases.synth_batch(B, seed=20251226 + 9)
+    ref = _make(B)
+    tau_ref, wr_ref, st_ref = _run(ref, q, flags, fstar)
+    junk_q = np.full_like(q, 7.0)
+    junk_f = np.full_like(fstar, -3.0)
+    for mode in ("set", "host_view"):
+        wbc = _make(B)
+        wbc.set_contact(flags)
+        if mode == "set":
+            wbc.set_state(q)
+            wbc.set_fstar_all(fstar)
+            wbc.solve()
+            wbc.set_state(junk_q)       # no read-back, no sync in between
+            wbc.set_fstar_all(junk_f)
+        else:
+            v = wbc.host_view("in_q")
+            v[:] = q
+            wbc.set_state(v)
+            wbc.set_fstar_all(fstar)
+            wbc.solve()
+            v2 = wbc.host_view("in_q")  # the documented way to rewrite the mirror in place: waits for the pending upload
+            v2[:] = junk_q
+        tau, wr, st = wbc.get("tau"), wbc.get("wrench"), wbc.get("status")
+        assert (st == st_ref).all(), mode
+        assert np.array_equal(tau, tau_ref), mode
+        assert np.array_equal(wr, wr_ref), mode

@@ -464,3 +464,60 @@ def test_gpu_jacc_matches_oracle_and_keeps_its_constraints():
         assert np.abs(np.einsum("bij,bj->bi", JC, acc)).max() < 1e-8      # contact constraint
         assert np.abs(acc[:, 6:]).max() < 10 + 1e-6 and np.abs(tau).max() < 200 + 1e-6
         assert (f[:, 2] < 1e-4).all() and (f[:, 8] < 1e-4).all()  # unilateral (implied by the cone rows, each held to 1e-6 on the normalised row)
+
+
+# ------------------------------------------------------------------------------------------- capacity of the device solver
+def _capacity_problem(nrow, nv=40):
+    """one level whose optimum keeps EVERY inequality row active: B x = 0 asks the eight sums of five variables to vanish while
+    the rows ask x_i <= -1; least squares on both gives x_i = -1/2, slack 1/2 on all `nrow` rows (the working set of the exact
+    active-set solve then holds nrow rows)"""
+    A = np.zeros((nrow, nv))
+    A[np.arange(nrow), np.arange(nrow)] = 1.0
+    return dict(m=nrow, e=8, A=A, a=np.ones(nrow), B=np.kron(np.eye(8), np.ones((1, 5))) / np.sqrt(5.0), b=np.zeros(8))
+
+
+def test_emulated_hqp_level_beyond_working_set_capacity_fails_with_status_0():
+    """kHqpMaxQ = 32 working-set rows (dwbc_hqp.h) is a capacity of the device solver.  A level that needs
+    30 active rows is solved; one that needs 40 returns status 0 and a zero answer -- never a truncated working set's point."""
+    from tests.emu.emu import EmuHQP
+
+    nv = 40
+    for nrow, want in ((30, 1), (40, 0)):
+        d = _capacity_problem(nrow, nv)
+        hq, ok = _oracle_generic([d], nv)
+        assert ok == 1 and len(hq.hqp_hs_[0].working_set_) == nrow  # the restatement has no capacity: all rows are active
+        h = hq.hqp_hs_[0]
+        eh = EmuHQP(1, nv, [nrow], [8], [0], share_cost=False, solve_first=True)
+        eh.block(0, 0, (nrow, nv))[0] = h.A_
+        eh.block(0, 1, (nrow,))[0] = h.a_
+        eh.block(0, 2, (8, nv))[0] = h.B_
+        eh.block(0, 3, (8,))[0] = h.b_
+        eh.solve()
+        assert eh.status(0)[0] == want
+        if want:
+            assert np.abs(eh.block(0, 5, (nv,))[0] - h.y_ans_).max() < TOL
+        else:
+            assert np.abs(eh.block(0, 5, (nv,))[0]).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_hqp_level_beyond_working_set_capacity_fails_with_status_0():
+    import libdwbc_amd as D
+    from libdwbc_amd import hqp as Hq
+
+    nv, B = 40, 4
+    for nrow, want in ((30, 1), (40, 0)):
+        d = _capacity_problem(nrow, nv)
+        ref, ok = _oracle_generic([d], nv)
+        hq = D.HQP(B, nv, 0, 0)
+        hq.addHierarchy(nrow, 8)
+        rep = lambda x: np.repeat(x[None], B, axis=0)
+        hq.updateConstraintMatrix(0, rep(d["A"]), rep(d["a"]), rep(d["B"]), rep(d["b"]))
+        hq.normalizeConstraintMatrix(0)
+        hq.prepare()
+        hq.solvefirst()
+        assert (hq.get(0, Hq.STATUS) == want).all()
+        if want:
+            assert np.abs(hq.y_ans(0) - ref.hqp_hs_[0].y_ans_[None]).max() < TOL
+        else:
+            assert np.abs(hq.y_ans(0)).max() == 0.0

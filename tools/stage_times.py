@@ -58,14 +58,15 @@ if d.shape[1] >= 90 + 64:
     st = np.median(d[:, 90:90 + 64].astype(np.float64), axis=0)
     fn = {0: "stage 1 starts", 1: "J_C", 2: "Y = J_C A^-1", 3: "Lambda_c", 5: "Jbar^T, A^-1 N_c update", 6: "gravity pre-vector, P_C", 7: "Vb", 8: "Jbar Vb",
           12: "Gram matrix, NwJw, VG", 13: "FNl", 14: "level-0 J_t + T1", 15: "level-0 J A J^T", 16: "level-0 Lambda_t", 17: "all task levels",
-          18: "W + alpha P", 19: "W sweep", 20: "W^+ correction + gravity torque", 21: "level-0 Q, Q W^+", 22: "level-0 Q W^+ Q^T inverse"}
+          18: "W + alpha P", 19: "W sweep", 20: "W^+ correction + gravity torque", 21: "level-0 Q, Q W^+", 22: "level-0 Q W^+ Q^T inverse",
+          42: "level-0 QP: base torque", 43: "level-0 QP: wrench map"}
     rows = sorted((st[i], fn[i]) for i in fn if st[i] > 0)
     prev = rows[0][0] if rows else 0.0
     print("fine stamps:")
     for v, n in rows:
         print(f"  {n:36s} {v - prev:10.0f} {v:12.0f}")
         prev = v
-    qn = ["post-loop", "slack + arg-min", "publish n, r, z", "step / drop", "commit", "rows + QR", "R^T y", "reflect + feasibility"]
+    qn = ["post-loop", "slack + arg-min", "publish n, r, z", "step / drop", "commit", "lexicographic point (CG)", "normalise rows, init", "feasibility of the point"]
     print("level-0 QP solver sections (cycles, summed over iterations):")
     for i, n in enumerate(qn):
         print(f"  {n:24s} {st[23 + i]:10.0f}")
