@@ -16,7 +16,7 @@
 
 using namespace dwbc;
 
-extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, int topo, const void **fn, const void **fn_wide, int *lds_bytes, int *topo_out);
+extern "C" int dwbc_f32_lookup(int n, int nb, int nlv, int which, int lean, int topo, const void **fn, const void **fn_wide, int *lds_bytes, int *lds_bytes_wide, int *topo_out);
 
 // DWBC_F32 batches: the fp32 kernels (dwbc_kernels_f32.hip) work on the double buffers of the boundary; the model table is
 // converted to float once
@@ -553,6 +553,11 @@ static bool lean_ok(const dwbc_batch *b) {
     return b->hqp && !b->warm && b->su.n_traj == 0 && !b->su.has_com_task && b->su.n_custom == 0 && !b->dump_on && !getenv("DWBC_NO_LEAN");
 }
 
+// dynamic LDS of one flavour of an entry: the lean capped build may be laid out on the compact map (Lds3)
+static int entry_lds(const KernelEntry *ke, void (*fn)(const Setup, const BatchIO)) {
+    return (fn == ke->fn_lean && ke->lds_bytes_lean) ? ke->lds_bytes_lean : ke->lds_bytes;
+}
+
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
     if (const KernelEntry *ke = lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind)) return ke;
@@ -566,10 +571,10 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     const int lean = lean_ok(b) ? 1 : 0;
     const int key = ((which * 16 + b->su.n_levels) * 2 + lean) * 2 + (b->su.topo_kind ? 1 : 0);
     if (key != b->f32_key) {
-        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, lean, b->su.topo_kind, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds, &b->f32_topo))
+        if (!dwbc_f32_lookup(b->n, b->su.nb, b->su.n_levels, which, lean, b->su.topo_kind, &b->f32_fn, &b->f32_fn_wide, &b->f32_lds, &b->f32_lds_wide, &b->f32_topo))
             return fail("no fp32 kernel for this model / number of task levels");
         HIP_OK(hipFuncSetAttribute(b->f32_fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
-        if (b->f32_fn_wide) HIP_OK(hipFuncSetAttribute(b->f32_fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds));
+        if (b->f32_fn_wide) HIP_OK(hipFuncSetAttribute(b->f32_fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, b->f32_lds_wide));
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, b->device));
         b->n_cu = prop.multiProcessorCount;
@@ -615,7 +620,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     b->ws_valid = !lean;  // the full build leaves every QP's working set in the diagnostics record
     const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     void *args[] = {(void *)&b->su, (void *)&io};
-    HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, b->f32_lds, b->stream));
+    HIP_OK(hipLaunchKernel(wide ? b->f32_fn_wide : b->f32_fn, dim3(b->B), dim3(kNT), args, wide ? b->f32_lds_wide : b->f32_lds, b->stream));
     return 1;
 }
 
@@ -647,7 +652,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     io.warm = (b->warm && b->ws_valid) ? 1 : 0;
     if (!b->attr_set) {
         for (auto fn : {b->kern->fn, b->kern->fn_wide, b->kern->fn_lean, b->kern->fn_wide_lean})
-            if (fn) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes));
+            if (fn) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, entry_lds(b->kern, fn)));
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, b->device));
         b->n_cu = prop.multiProcessorCount;
@@ -657,7 +662,7 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     const bool lean = b->kern->fn_lean && lean_ok(b);
     b->ws_valid = !lean && !reduced;  // the full build leaves every QP's working set in the diagnostics record (DG_QP_ACT)
     auto fn = wide ? (lean ? b->kern->fn_wide_lean : b->kern->fn_wide) : (lean ? b->kern->fn_lean : b->kern->fn);
-    hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), b->kern->lds_bytes, b->stream, b->su, io);
+    hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), entry_lds(b->kern, fn), b->stream, b->su, io);
     HIP_OK(hipGetLastError());
     return 1;
 }
@@ -895,14 +900,21 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     }
     const bool wide = ke->fn_wide && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
     name = pre + (wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + sz + ", " + std::to_string(ke->nlv) + ", 64" +
-           (ke->fn_lean && lean_ok(b) ? ", false" : ", true") + topo + ">";
+           (ke->fn_lean && lean_ok(b) ? ", false" : ", true") + topo + ((!wide && ke->fn_lean && lean_ok(b) && ke->lds_bytes_lean) ? ", true" : "") + ">";
     return name.c_str();
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     if (threads) *threads = kNT;
-    if (lds) *lds = b->dtype == DWBC_F32 && b->f32_lds ? b->f32_lds : (ke ? ke->lds_bytes : 0);
+    int n_cu = b->n_cu;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    }
+    const bool wide = ke && ke->fn_wide && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
+    const bool compact = ke && !wide && !b->last_reduced && ke->fn_lean && lean_ok(b) && ke->lds_bytes_lean;
+    if (lds) *lds = b->dtype == DWBC_F32 && b->f32_lds ? (wide ? b->f32_lds_wide : b->f32_lds) : (ke ? (compact ? ke->lds_bytes_lean : ke->lds_bytes) : 0);
     return 1;
 }
 

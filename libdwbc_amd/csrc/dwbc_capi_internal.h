@@ -75,7 +75,7 @@ struct dwbc_batch {
     int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
     float *f_body = nullptr;
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
-    int f32_lds = 0, f32_key = -1, f32_topo = 0;
+    int f32_lds = 0, f32_lds_wide = 0, f32_key = -1, f32_topo = 0;
     int hqp = 1;
     int warm = 0;           // last solve flags had DWBC_SOLVE_INIT clear
     bool ws_valid = false;  // diag holds the working sets of a full-build launch

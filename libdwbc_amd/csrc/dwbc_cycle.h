@@ -407,15 +407,44 @@ DWBC_DEV void com_task_rows(Thr th, const real_t *Jcm, real_t *Jtt, int row0, in
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053)
 // W1/W2/fv are the contact wrench maps already rotated into the contact frames (A_rot applied).
 // ----------------------------------------------------------------------------------------------
+// what a lane needs of the problem set-up to fill its QP row: fetched ONCE per cycle, ahead of the cascade (the set-up is a kernel
+// argument, and a per-lane index into it is a vector memory load -- a trip to L2 in each of the three QPs when taken inside the fill)
+struct QpLaneConst {
+    PL(real_t, taul);       // torque limit of row `lane` (lane < M)
+    PL(real_t, c2);         // cone lanes: the row is  c2 * w[2] + sg * w[oi]  on the local wrench of contact a (reference src/wbd.cpp:59-97)
+    PL(real_t, sg);
+    PL(int, row2);
+    PL(int, rowo);
+};
+template <int N>
+DWBC_DEV void qp_lane_consts(const Setup &su, int ci0, int ci1, QpLaneConst &qc) {
+    constexpr int M = N - 6;
+    DWBC_LANE_DECL;
+    LANES {
+        LV(qc.taul) = lane < M ? (real_t)su.tau_lim[lane] : real_t(0.0);
+        const int rr = lane >= M ? lane - M : 0, a = rr >= 10 ? 1 : 0, r10 = rr - 10 * a;
+        const int ci = a ? ci1 : ci0;
+        const int pr = r10 >> 1;
+        LV(qc.c2) = -(real_t)(pr == 0 ? su.c_lx[ci] : pr == 1 ? su.c_ly[ci] : pr == 4 ? su.c_muz[ci] : su.c_mu[ci]);
+        const int oi = pr == 0 ? 4 : pr == 1 ? 3 : pr == 2 ? 0 : pr == 3 ? 1 : 5;
+        LV(qc.sg) = (pr < 2) ? ((r10 & 1) ? real_t(1.0) : -real_t(1.0)) : ((r10 & 1) ? -real_t(1.0) : real_t(1.0));
+        LV(qc.row2) = 6 * a + 2;
+        LV(qc.rowo) = 6 * a + oi;
+    }
+}
+
 template <int N, int NB, int WS = 1>
 DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone, int ci0, int ci1, const real_t *P1, int ld1,
                                 int t1, const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1,
                                 const real_t *W2, int ldw2, const real_t *fv, const real_t *base, int tvars, int max_iter,
-                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr) {
+                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr, const QpLaneConst *qcp = nullptr) {
     constexpr int M = N - 6;
     DWBC_LANE_DECL;
     QpRows R;
     const int nv = t1 + t2;
+    QpLaneConst qloc;
+    if (!qcp) qp_lane_consts<N>(su, ci0, ci1, qloc);  // (callers that solve one QP only)
+    const QpLaneConst &qc = qcp ? *qcp : qloc;
     LANES {
 #pragma unroll
         for (int j = 0; j < kQpN; j++) LV(R.g)[j] = real_t(0.0);
@@ -432,20 +461,16 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
                     else if (j < nv) v = P2[lane * ld2 + (j - t1)] * s2;
                     LV(R.g)[j] = v;
                 }
-                LV(R.hi) = su.tau_lim[lane] - base[lane];
-                LV(R.lo) = su.tau_lim[lane] + base[lane];
+                LV(R.hi) = LV(qc.taul) - base[lane];
+                LV(R.lo) = LV(qc.taul) + base[lane];
                 LV(R.id_hi) = lane;
                 LV(R.id_lo) = M + lane;
             }
         } else if (lane - M < ncone) {
             // cone row r10 of contact a acts on the local wrench w as  c2 * w[2] + sg * w[oi]   (reference src/wbd.cpp:59-97)
-            const int rr = lane - M, a = rr / 10, r10 = rr - 10 * a;
-            const int ci = a ? ci1 : ci0;
-            const int pr = r10 >> 1;
-            const real_t c2 = -(pr == 0 ? su.c_lx[ci] : pr == 1 ? su.c_ly[ci] : pr == 4 ? su.c_muz[ci] : su.c_mu[ci]);
-            const int oi = pr == 0 ? 4 : pr == 1 ? 3 : pr == 2 ? 0 : pr == 3 ? 1 : 5;
-            const real_t sg = (pr < 2) ? ((r10 & 1) ? real_t(1.0) : -real_t(1.0)) : ((r10 & 1) ? -real_t(1.0) : real_t(1.0));
-            const int row2 = 6 * a + 2, rowo = 6 * a + oi;
+            const int rr = lane - M;
+            const real_t c2 = LV(qc.c2), sg = LV(qc.sg);
+            const int row2 = LV(qc.row2), rowo = LV(qc.rowo);
 #pragma unroll
             for (int j = 0; j < kQpN; j++) {
                 real_t v = real_t(0.0);

@@ -91,13 +91,137 @@ struct Lds2 {
     static constexpr int t_s1 = t_fv + C;                      // C x (T+1)
     static constexpr int qp_V = t_s1 + C * (T + 1);
     static constexpr int qp_x = qp_V + kQpLd * kQpLd + 32;
-    static constexpr int t_end = qp_x + kQpLd;
+    static constexpr int WLD = 32;                             // row stride of the wrench maps: 1 + sum t_l + k <= 31 columns
+    static constexpr int wm = ev(qp_x + kQpLd);                // C x WLD: A_rot Jbar[:,6:] [tg | U_0 .. | NwJw]  (wrench_maps below)
+    static constexpr int t_wacc = wm + C * WLD;                // C: wrench of the torque committed so far, minus A_rot P_C
+    static constexpr int t_cl = t_wacc + C;                    // K: contact_qp_ of the last task level that was solved
+    static constexpr int t_end = ev(t_cl + K);
     static constexpr int total0 = max2(max2(k_end, c_end), t_end);
     // Jacobian of the COM link + com_pos (6 N + 3), for COM task levels: written at the end of stage 0 and read while the task
     // Jacobians are built, i.e. before stage 3a first writes U -- so it borrows the U block when that is large enough
     static constexpr bool jcm_in_U = NLV * M * T >= 6 * N + 4;
     static constexpr int Jcm = jcm_in_U ? U : ev(total0);
     static constexpr int total = jcm_in_U ? total0 : ev(total0) + 6 * N + 4;
+    static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
+    // names the compact map (Lds3 below) gives a place of their own
+    static constexpr bool compact = false;
+    static constexpr int k_anc = k_Ic;                         // ancestor indices of the pointer-jumping rounds (2 x NB)
+    static constexpr int Rw0 = Rw;                             // pelvis rotation for the base columns of the point Jacobians
+    static constexpr int c_QWp = c_Jt;                         // Q W^+ of stage 3a (c_Jt / c_T1 are free again by then)
+    static constexpr int c_s2b = c_s2;                         // input of the small SPD inverses of stage 3a
+    static constexpr int Pt = 0, c_Gi = 0;                     // (compact map only)
+    static constexpr int xl(int lv) { return Xl + lv * M * T; }  // X = J_kt Lambda of level lv < NLV - 1
+};
+
+// The COMPACT map of the lean, register-capped kernel (`_v2`, EXTRAS = false; batches beyond four instances per CU): the same
+// blocks under the same names, laid out by life time so that two task levels fit 20 KB -- EIGHT workgroups per CU (two waves per
+// SIMD) where Lds2's 31.6 KB allows five (profiles/r01_final_lds_coresidency.txt: <= 20 480 B for 8).  What changes against Lds2:
+//   * the staged mass matrix is the row-packed lower triangle (as Lds2 does beyond 41 dof) and overlays the kinematics scratch
+//     that is dead by then; the local rotations of the FK rounds overlay the inertia buffers that are written after them;
+//   * J_C lives where Jbar^T will: the internal-wrench basis Vb, the only later reader of J_C, is formed right behind J_C;
+//   * the link rotations die with stage 1's prologue: the task points are taken there (Pt), the point Jacobians keep pw, aw and
+//     the pelvis rotation (Rw0);
+//   * T1 = J_t A^-1 N_c goes straight to its M-wide home (T1r of the level, c_Q for the last) plus its six base columns (c_T1);
+//   * VG = Vb G^-1 is not stored (G^-1, 36 doubles, is: c_Gi); X of level 0 IS U of level 0 (nothing projects it).
+// Life times (region : stage 0 | stage 1 | NwJw | task Jacobians | W^+ | stage 3a | QP):
+//   JbT  : k_S k_F | J_C, then Jbar^T ...........................................................
+//   U    : Rw      | Rw (frames, task points) | . | J_t^T, T1 base columns | . | U ..............
+//   RE   : pw aw ......................................................... | . | Q    | QP scratch
+//   RF   : k_Iw k_Ic (k_Rl, k_A over them) | Vb ...... c_Gi ................... | Q W^+ | QP scratch
+//   RG/RH: (k_Ic, k_A)   | Y            | . | Lambda_t, T1r, c_Q .......................... | .
+//   RX   : (k_A)         | small-inverse scratch ...... | sweep column | Pi, Z, small inverses | .
+template <int N, int NB, int NLV>
+struct Lds3 {
+    static constexpr bool compact = true;
+    static constexpr int M = N - 6;
+    static constexpr int C = 6 * kMaxActiveContacts;
+    static constexpr int K = C - 6;
+    static constexpr int T = kMaxTaskDof;
+    static constexpr int max2(int a, int b) { return a > b ? a : b; }
+    static constexpr int ev(int a) { return (a + 1) & ~1; }
+    static constexpr int NL2 = NLV < 2 ? 2 : NLV;              // the U / T1r regions are sized for at least two levels (they host stage-0/1 data)
+    // ---- head: alive for the whole cycle
+    static constexpr int tg = 0;
+    static constexpr int tt = tg + M;
+    static constexpr int tc = tt + M;
+    static constexpr int PC = tc + M;
+    static constexpr int Rc = PC + C;
+    static constexpr int Pc = Rc + kMaxActiveContacts * 9;
+    static constexpr int fs = Pc + kMaxActiveContacts * 3;
+    static constexpr int comp = fs + kMaxLevels * kMaxTaskDof;
+    static constexpr int q = ev(comp + 4);                     // N+1, stage 0 only; then the gravity pre-vector (c_vec)
+    static constexpr int G = q + ev(N + 1);                    // N, stages 0-1; then the diagonal of W (c_col)
+    static constexpr int hend = G + ev(N);
+    static constexpr int c_vec = q;
+    static constexpr int c_col = G;
+    // ---- long-lived blocks
+    static constexpr int JbT = hend;                           // C x N
+    static constexpr int c_JC = JbT;                           // N x C, until Jbar^T is written over it
+    static constexpr int NwJw = JbT + C * N;                   // M x K
+    static constexpr int FNl = NwJw + M * K;                   // C x K
+    static constexpr int U = FNl + C * K;                      // levels x (M x T)
+    static constexpr int RE = U + NL2 * M * T;
+    static constexpr int pw = RE;
+    static constexpr int aw = pw + NB * 3;
+    static constexpr int Rw0 = aw + NB * 3;                    // 9 (+1)
+    static constexpr int Pt = Rw0 + 10;                        // task points, kMaxLevels x kMaxTaskLinks x 3
+    static constexpr int RF = ev(Pt + kMaxLevels * kMaxTaskLinks * 3);
+    static constexpr int c_Vb = RF;                            // M x K
+    static constexpr int c_Gi = c_Vb + M * K;                  // K x K
+    static constexpr int c_VG = c_Vb;                          // (not stored in this map)
+    static constexpr int RG = c_Gi + K * K;
+    static constexpr int c_Lt = RG;                            // levels x T x T
+    static constexpr int T1r = c_Lt + NL2 * T * T;             // (levels-1) x (T x M)
+    static constexpr int c_Q = T1r + (NL2 - 1) * T * M;        // T x M
+    static constexpr int RX = c_Q + T * M;                     // phase-local scratch
+    static constexpr int rx_size = max2(max2(C * K, 64) + C * C, 64 + 3 * T * T + 8);
+    static constexpr int RXend = RX + ev(rx_size);
+    static constexpr int Xl = RXend;                           // X of levels 1 .. NLV-2 (level 0: U)
+    static constexpr int total = Xl + (NLV > 2 ? (NLV - 2) * M * T : 0);
+    static constexpr int xl(int lv) { return lv == 0 ? U : Xl + (lv - 1) * M * T; }
+    // ---- stage 0
+    static constexpr int Rw = U;                               // NB x 9, until the contact frames and task points are taken
+    static_assert(NL2 * M * T >= NB * 9, "the link rotations borrow the U region");
+    static constexpr int k_S = JbT;                            // N x 6
+    static constexpr int k_F = k_S + N * 6;                    // N x 6
+    static_assert(2 * N * 6 <= C * N, "S and F borrow the Jbar^T region");
+    static constexpr int k_Iw = RF;                            // NB x 10 (first the ping-pong partner of pw)
+    static constexpr int k_Ic = k_Iw + NB * 10;                // NB x 10
+    static constexpr int k_Rl = k_Iw + NB * 3;                 // NB x 9: local rotations / ping-pong partner of Rw, dead before Iw and Ic are written
+    static constexpr int k_anc = k_Ic + NB * 10 - 2 * NB;      // ancestor indices at the tail of k_Ic
+    static_assert(k_Rl + NB * 9 <= k_anc, "local rotations must not reach the ancestor indices");
+    static constexpr bool a_overlay = false, a_packed = true;
+    static constexpr int k_A = RF;                             // N (N + 1) / 2, written after Ic has been consumed
+    static_assert(k_Ic + NB * 10 <= total && k_A + N * (N + 1) / 2 <= total, "stage-0 scratch");
+    // ---- stage 1
+    static constexpr int c_Y = RG;                             // N x C, dead before Lambda_t / T1r / c_Q are written
+    static_assert(c_Y + C * N <= RX, "Y borrows the Lambda_t / T1r / c_Q region");
+    static constexpr int c_s1 = RX;                            // max(C x K, 64): wrench-map scratch, sweep column (one double per lane)
+    static constexpr int c_s2 = c_s1 + max2(C * K, 64);        // C x C
+    static constexpr int c_Lam = c_s2;
+    // ---- task Jacobians
+    static constexpr int c_Jt = U;                             // N x T (J_task transposed)
+    static constexpr int c_T1 = c_Jt + N * T;                  // T x 6: the base columns of T1
+    static_assert(c_T1 + T * 6 <= RE, "J_t^T and the base columns of T1 borrow the U region");
+    // ---- stage 3a
+    static constexpr int c_QW = RE;                            // Q, T x M
+    static constexpr int c_QWp = RF;                           // Q W^+, T x M
+    static_assert(T * M <= RF - RE && T * M <= RG - RF, "Q / Q W^+");
+    static constexpr int c_Pi = c_s1 + 64;                     // T x T
+    static constexpr int c_Z = c_Pi + T * T;                   // T x T
+    static constexpr int c_s2b = c_Z + T * T;                  // T x T: input of the small SPD inverses of stage 3a
+    // ---- QP scratch (RE .. RG)
+    static constexpr int WLD = 32;
+    static constexpr int t_base = RE;                          // M
+    static constexpr int wm = ev(t_base + M);                  // C x WLD
+    static constexpr int t_fv = wm + C * WLD;                  // C
+    static constexpr int t_wacc = t_fv + C;                    // C
+    static constexpr int t_cl = t_wacc + C;                    // K
+    static constexpr int qp_V = t_cl + K;                      // kQpLd (the row a drop step passes through LDS)
+    static constexpr int qp_x = qp_V + kQpLd;
+    static constexpr int t_F = wm, t_s1 = wm;                  // (names of the Lds2 map the lean cascade does not use)
+    static_assert(qp_x + kQpLd <= RG, "QP scratch");
+    static constexpr int Jcm = 0;                              // (COM task levels: full build only)
     static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
 };
 
@@ -398,12 +522,113 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     return ok;
 }
 
+// Internal-wrench basis mapped to joint torques: Vb[r][a] = (J_C[:, 6 + r])^T lambda_a, where lambda_a (a < 6) is the wrench pair
+// "unit wrench e_a on the second contact, the balancing wrench on the first" -- null(W) = { J_C[:,6:]^T lambda : J_C[:,:6]^T lambda = 0 }
+// (closed form instead of the complete orthogonal decomposition of src/wbd.cpp:32-53).  JCt is J_C transposed (N x C), Pc the contact points.
+template <int N, int NT>
+DWBC_DEV void internal_wrench_basis(Thr th, const real_t *Pc, const real_t *JCt, real_t *Vb) {
+    static_assert(kMaxActiveContacts == 2, "k in {0, 6}");
+    constexpr int M = N - 6, C = 6 * kMaxActiveContacts, K6 = 6;
+    for (int idx = th.tid; idx < M * K6; idx += NT) {
+        const int r = idx / 6, a = idx - r * 6;  // k == 6 here
+        const int ci = 1 + a / 6, e = a % 6;
+        real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+        if (e < 3) f2[e] = real_t(1.0); else m2[e - 3] = real_t(1.0);
+        const real_t d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
+        const real_t m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
+        const real_t m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
+        const real_t m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
+        const int col = 6 + r;
+        const real_t *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
+        const int o1 = 6 * ci;
+        real_t acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
+        acc += m1x * Jc[3] + m1y * Jc[4] + m1z * Jc[5];
+        acc += f2[0] * Jc[o1 + 0] + f2[1] * Jc[o1 + 1] + f2[2] * Jc[o1 + 2];
+        acc += m2[0] * Jc[o1 + 3] + m2[1] * Jc[o1 + 4] + m2[2] * Jc[o1 + 5];
+        Vb[idx] = acc;
+    }
+}
+
+// The contact wrench maps of EVERY QP of the cascade in one product, taken once after stage 3a:
+//     WM = A_rot Jbar[:, 6:] [ tg | U_0 | U_1 ... | NwJw ]        (C x (1 + sum t_l + k), row stride WLD, contact-local frames)
+// Column 0 is the wrench of the gravity torque, the U_l blocks are the maps F of CalcSingleTaskTorqueWithQP (dwbc.cpp:1018-1040),
+// the last block is the map of the contact-null variables (dwbc.cpp:1041-1053 and CalcContactRedistribute :1458-1517).  Every
+// right-hand side the cascade needs is a combination of these columns with the f* / QP answers of the levels (see the cascade), so
+// the per-QP products `Jbar U`, `Jbar base`, `Jbar NwJw` of rounds 1-2 (three passes per QP, ~25 k cycles per cycle) are gone.
+// fp64 device build: one 16 x 16 accumulator tile per 16 columns, v_mfma_f64_16x16x4_f64 over K = 33 (9 steps); the A operand is the
+// ROTATED row of Jbar, formed on the fly from three LDS reads (operand layout verified on gfx950 by tools/ubench/mfma_stage.hip:
+// A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[i = (l >> 4) + 4 r][j = l & 15]).  BASELINE configs[1] has exactly 16 columns.
+template <int N, int NT, class S>
+DWBC_DEV void wrench_maps(Thr th, const Setup &su, real_t *L, const real_t *JbT, int cd, int k, real_t *WM) {
+    constexpr int M = N - 6, T = S::T, WLD = S::WLD;
+    DWBC_LANE_DECL;
+    const int ftot = su.fstar_total, ncols = 1 + ftot + k;
+    // element (c, col) of the right-hand operand sits at L[bb + bs * c]
+    auto col_src = [&](int col, int &bb, int &bs) {
+        bb = S::tg; bs = 1;
+        if (col >= 1 && col - 1 < ftot) {
+            int l = 0;
+            for (int q = 1; q < su.n_levels; q++) l = (col - 1 >= su.fstar_off[q]) ? q : l;
+            bb = S::U + l * M * T + (col - 1 - su.fstar_off[l]);
+            bs = T;
+        } else if (col - 1 - ftot >= 0 && col - 1 - ftot < k) {
+            bb = S::NwJw + (col - 1 - ftot);
+            bs = 6;
+        }
+    };
+#if !defined(DWBC_HOST_EMU)
+    if constexpr (sizeof(real_t) == 8) {
+        typedef double wm_d4 __attribute__((ext_vector_type(4)));
+        const int li = lane & 15, lk = lane >> 4;
+        const int a_ = li >= 6 ? 1 : 0, h = (li % 6) / 3, x = li % 3;   // (rows 12..15 of the tile are padding: any finite data)
+        const real_t *R = L + S::Rc + a_ * 9;
+        const real_t r0 = R[x], r1 = R[3 + x], r2 = R[6 + x];          // column x of R_a: row of A_rot = blockdiag(R^T, R^T)
+        const real_t *J0 = JbT + (6 * a_ + 3 * h) * N + 6;
+        const int ntile = (ncols + 15) >> 4;
+        for (int tile = 0; tile < ntile; tile++) {
+            const int col = 16 * tile + li;
+            int bb, bs;
+            col_src(col, bb, bs);
+            wm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < (M + 3) / 4; s++) {
+                const int c = 4 * s + lk;
+                const bool in = c < M;
+                const int cc = in ? c : M - 1;
+                real_t av = r0 * J0[cc] + r1 * J0[N + cc] + r2 * J0[2 * N + cc];
+                av = in ? av : 0.0;
+                const real_t bv = L[bb + bs * cc];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) WM[(lk + 4 * r) * WLD + col] = acc[r];  // rows lk + 4 r < 12
+        }
+        DWBC_SYNC();
+        return;
+    }
+#endif
+    for (int idx = th.tid; idx < cd * ncols; idx += NT) {
+        const int i = idx / ncols, col = idx - i * ncols;
+        const int a_ = i / 6, h = (i % 6) / 3, x = i % 3;
+        const real_t *R = L + S::Rc + a_ * 9;
+        const real_t *J0 = JbT + (6 * a_ + 3 * h) * N + 6;
+        int bb, bs;
+        col_src(col, bb, bs);
+        real_t acc = real_t(0.0);
+        for (int c = 0; c < M; c++) acc += (R[x] * J0[c] + R[3 + x] * J0[N + c] + R[6 + x] * J0[2 * N + c]) * L[bb + bs * c];
+        WM[i * WLD + col] = acc;
+    }
+    DWBC_SYNC();
+}
+
 // EXTRAS = false compiles the optional paths out (task-link trajectories, qdot outputs, COM / TASK_CUSTOM levels, hqp = false):
 // merely having them inlined costs the common cycle 2 % (register allocation around the 39-column register matrix), so the
 // launcher picks the lean instantiation whenever none of them is in use.
-template <int N, int NB, int NLV, int NT, bool EXTRAS = true, class Topo = TopoGeneric>
+// COMPACT = true: the 20 KB LDS map Lds3 (lean build only; same arithmetic, blocks laid out by life time)
+template <int N, int NB, int NLV, int NT, bool EXTRAS = true, class Topo = TopoGeneric, bool COMPACT = false>
 DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L, int *iL) {
-    using S = Lds2<N, NB, NLV>;
+    static_assert(!(COMPACT && EXTRAS), "the compact LDS map has no room for the optional paths");
+    using S = typename std::conditional<COMPACT, Lds3<N, NB, NLV>, Lds2<N, NB, NLV>>::type;
     constexpr bool kExtras = EXTRAS;
     constexpr int M = S::M, C = S::C, T = S::T;
     DWBC_LANE_DECL;
@@ -432,25 +657,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         // unroll with compile-time strides after inlining
         static_assert(kMaxActiveContacts == 2, "k in {0, 6}");
         constexpr int K6 = 6;
-        const real_t *Pc = L + S::Pc;
-        for (int idx = th.tid; idx < M * K6; idx += NT) {
-            const int r = idx / 6, a = idx - r * 6;  // k == 6 here
-            const int ci = 1 + a / 6, e = a % 6;
-            real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-            if (e < 3) f2[e] = real_t(1.0); else m2[e - 3] = real_t(1.0);
-            const real_t d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
-            const real_t m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
-            const real_t m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
-            const real_t m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
-            const int col = 6 + r;
-            const real_t *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
-            const int o1 = 6 * ci;
-            real_t acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
-            acc += m1x * Jc[3] + m1y * Jc[4] + m1z * Jc[5];
-            acc += f2[0] * Jc[o1 + 0] + f2[1] * Jc[o1 + 1] + f2[2] * Jc[o1 + 2];
-            acc += m2[0] * Jc[o1 + 3] + m2[1] * Jc[o1 + 4] + m2[2] * Jc[o1 + 5];
-            Vb[idx] = acc;
-        }
+        if constexpr (!S::compact) internal_wrench_basis<N, NT>(th, L + S::Pc, JCt, Vb);  // (compact map: formed in stage 1, before Jbar^T overwrites J_C)
         DWBC_SYNC();
         DWBC_FSTAMP(7);  // Vb
         for (int idx = th.tid; idx < K6 * K6; idx += NT) {
@@ -469,7 +676,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
             DWBC_SYNC();
             spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::c_s1);                   // G^-1
-            mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1   (projector P = VG Vb^T)
+            if constexpr (!S::compact) mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);  // VG = Vb G^-1   (projector P = VG Vb^T)
+            else for (int idx = th.tid; idx < K6 * K6; idx += NT) L[S::c_Gi + idx] = Gi[idx];  // (compact map: G^-1 is kept instead of VG)
             mm_nn<NT>(th, Bm, K6, JV, K6, Gi, K6, K6, K6, K6);                       // B = JV G^-1
             DWBC_SYNC();
             mm_nt<NT>(th, Sm6, K6, Bm, K6, JV, K6, K6, K6, K6);                      // S = B JV^T  (SPD)
@@ -477,11 +685,19 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (!spd_inverse_small(Sm6, K6, K6, Sm6, K6, L + S::c_s1)) st_contact = 0;
             mm_nn<NT>(th, Bm, K6, Sm6, K6, JV, K6, K6, K6, K6);                      // X = S^-1 JV
             DWBC_SYNC();
-            mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
+            if constexpr (!S::compact) {
+                mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);          // NwJw = VG X^T
+            } else {
+                mm_nt<NT>(th, JV, K6, Gi, K6, Bm, K6, K6, K6, K6);                   // G^-1 X^T (JV is dead)
+                DWBC_SYNC();
+                mm_nn<NT>(th, L + S::NwJw, K6, Vb, K6, JV, K6, M, K6, K6);          // NwJw = Vb (G^-1 X^T)
+            }
             DWBC_SYNC();
         }
         DWBC_FSTAMP(12);  // VG
-        // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame
+        // FNl = A_rot * (J̄[:,6:] NwJw)   (cd x k), contact-local frame: the QP cascade takes it from the wrench maps (wrench_maps(),
+        // below); only the closed-form redistribution of hqp = false reads this block
+        if (kExtras && !io.hqp)
         for (int idx = th.tid; idx < cd * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             real_t acc = real_t(0.0);
@@ -490,6 +706,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             L[S::c_s1 + idx] = acc;
         }
         DWBC_SYNC();
+        if (kExtras && !io.hqp)
         for (int idx = th.tid; idx < cd * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;  // k == 6 here
             const int a = i / 6, h = (i % 6) / 3, x = i % 3;
@@ -509,6 +726,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         constexpr int TTL = decltype(ttl)::value;
         const int t = kExtras ? su.t_dof[lv] : TTL;
         real_t *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
+        // compact map: T1 holds the six base columns only (T x 6); the joint columns go straight to T1r of the level / c_Q of the last
+        real_t *T1x = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
         const unsigned long long tm = su.t_dofmask[lv];
         DWBC_SYNC();
         for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = real_t(0.0);
@@ -529,10 +748,14 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (kExtras && link == nb) {  // the COM link: jac_ = jac_com_ (dwbc.cpp:352-353)
                 com_task_rows<N, NT>(th, L + S::Jcm, Jtt, row, rsel, T);
             } else {
-                const real_t *R = L + S::Rw + link * 9;
                 real_t P[3];
-                for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
-                point_jacobian<N, NB, NT>(th, L + S::Rw, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
+                if constexpr (S::compact) {  // taken in stage 1, while the link rotations were alive
+                    for (int a = 0; a < 3; a++) P[a] = L[S::Pt + (lv * kMaxTaskLinks + li) * 3 + a];
+                } else {
+                    const real_t *R = L + S::Rw + link * 9;
+                    for (int a = 0; a < 3; a++) P[a] = L[S::pw + link * 3 + a] + R[a * 3] * pl[0] + R[a * 3 + 1] * pl[1] + R[a * 3 + 2] * pl[2];
+                }
+                point_jacobian<N, NB, NT>(th, L + S::Rw0, L + S::pw, L + S::aw, topo, nb, link, P, Jtt, 1, row, rsel == 0 ? 6 : 3, rsel, T);
             }
             row += rsel == 0 ? 6 : 3;
         }
@@ -556,8 +779,13 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 }
 #pragma unroll
                 for (int r = 0; r < TT; r++) {
-                    if (lane < N) T1[r * N + lane] = tc_[r];
-                    if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
+                    if constexpr (S::compact) {
+                        if (lane < 6) T1[r * 6 + lane] = tc_[r];
+                        else if (lane < N) T1x[r * M + (lane - 6)] = tc_[r];
+                    } else {
+                        if (lane < N) T1[r * N + lane] = tc_[r];
+                        if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
+                    }
                 }
             }
         };
@@ -569,7 +797,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             real_t acc = real_t(0.0);
 #pragma unroll
             for (int c = 0; c < N; c++)
-                if ((tm >> c) & 1) acc += T1[i * N + c] * Jtt[c * T + j];
+                if ((tm >> c) & 1) acc += (S::compact ? (c < 6 ? T1[i * 6 + c] : T1x[i * M + (c < 6 ? 0 : c - 6)]) : T1[i * N + c]) * Jtt[c * T + j];
             L[S::c_s2 + idx] = acc;
         }
         if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
@@ -577,7 +805,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
         if (lv == 0) DWBC_FSTAMP(16);  // level 0: Lambda_task
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
-        if (lv == NLV - 1)
+        if (!S::compact && lv == NLV - 1)
             for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
         if (dump) {
             for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jtt[(idx % N) * T + idx / N];
@@ -617,11 +845,23 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (k > 0) {
             DWBC_LANE_OPAQUE(lw);
             real_t dp = real_t(0.0);
+            real_t gv[6] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+            if constexpr (S::compact) {
+#pragma unroll
+                for (int b = 0; b < 6; b++)
+#pragma unroll
+                    for (int a = 0; a < 6; a++) gv[b] += L[S::c_Gi + b * 6 + a] * LV(vbr)[a];
+            }
 #pragma unroll
             for (int i = 0; i < M; i++) {
                 real_t pij = real_t(0.0);
+                if constexpr (S::compact) {  // P = Vb G^-1 Vb^T with gv = G^-1 (row `lane` of Vb)
 #pragma unroll
-                for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
+                    for (int a = 0; a < 6; a++) pij += Vb[i * 6 + a] * gv[a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
+                }
                 LV(pc)[i] = pij;
                 LV(w)[i] += alpha * pij;
                 dp = (i == lw) ? pij : dp;
@@ -680,7 +920,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const real_t *Lt = L + S::c_Lt + lv * T * T;
         const FastDiv fdt(t);
         const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
-        real_t *Q = L + S::c_QW, *QW = L + S::c_Jt, *Pi = L + S::c_Pi;  // c_Jt/c_T1 are free again
+        real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;  // (Lds2: c_Jt/c_T1 are free again)
         DWBC_SYNC();
         for (int idx = th.tid; idx < t * M; idx += NT) {  // Q = Lambda T1[:,6:]
             const int i = idx / M, j = idx - i * M;
@@ -692,7 +932,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         real_t *Ul = L + S::U + lv * M * T;
-        real_t *Xs = (lv < NLV - 1) ? L + S::Xl + lv * M * T : Ul;
+        real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
         int cond = 1;
         auto jkt_rows = [&](auto ttc) {
             constexpr int TT = decltype(ttc)::value;
@@ -707,8 +947,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             if (lv == 0) DWBC_FSTAMP(21);  // level 0: Q, QW
-            mm_nt<NT>(th, L + S::c_s2, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
-            cond = spd_inverse_small(L + S::c_s2, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
+            mm_nt<NT>(th, L + S::c_s2b, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
+            cond = spd_inverse_small(L + S::c_s2b, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
             DWBC_SYNC();
             if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
             // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
@@ -751,7 +991,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
             const int tp = su.t_dof[pl];
-            const real_t *Xp = L + S::Xl + pl * M * T, *Yp = L + S::T1r + pl * T * M;
+            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1r + pl * T * M;
             for (int idx = th.tid; idx < tp * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
                 real_t acc = real_t(0.0);
@@ -783,7 +1023,27 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     const int ncone = 10 * nc;
     int st_task = 1, fail_level = -1, st_redis = 1;
     const real_t *fs_in = L + S::fs;  // filled by task_reference() after stage 0
-    real_t *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
+    real_t *base = L + S::t_base, *fv = L + S::t_fv, *WM = L + S::wm, *wacc = L + S::t_wacc, *clast = L + S::t_cl;
+    constexpr int WLD = S::WLD;
+    const int colN = 1 + su.fstar_total;  // first column of the contact-null block of the wrench maps
+    QpLaneConst qc;
+    if (kExtras ? io.hqp != 0 : true) {
+        qp_lane_consts<N>(su, act_c[0], act_c[1], qc);
+        wrench_maps<N, NT, S>(th, su, L, JbT, cd, k, WM);
+        // wacc = wrench of the torque committed so far (gravity torque to begin with) minus A_rot P_C, contact-local frames
+        for (int i = th.tid; i < C; i += NT) {
+            real_t acc = real_t(0.0);
+            if (i < cd) {
+                const int a = i / 6, h = (i % 6) / 3, x = i % 3;
+                const real_t *R = L + S::Rc + a * 9;
+                const real_t *pc3 = L + S::PC + 6 * a + 3 * h;
+                acc = WM[i * WLD] - (R[x] * pc3[0] + R[3 + x] * pc3[1] + R[6 + x] * pc3[2]);
+            }
+            wacc[i] = acc;
+            if (i < S::K) clast[i] = real_t(0.0);
+        }
+        DWBC_SYNC();
+    }
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;  // cascade aborted (dwbc.cpp:836,845): later levels are skipped
@@ -793,9 +1053,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
         const int t = is_task ? su.t_dof[qi] : 0;
-        const FastDiv fdt1(t + 1);
         const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
+        const int colL = 1 + (is_task ? su.fstar_off[qi] : 0);  // this level's block of the wrench maps
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }  // rank-deficient task block
         if (kExtras && is_task && !io.hqp) {  // CalcTaskControlTorque(hqp = false): torque_task_ += Null_{i-1} J_kt Lambda f* (dwbc.cpp:856-873)
             DWBC_SYNC();
@@ -808,53 +1068,37 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             continue;
         }
         DWBC_SYNC();
-        for (int i = th.tid; i < M; i += NT) {
-            real_t acc = L[S::tg + i] + L[S::tt + i];
-            if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
-            else acc += L[S::tc + i];
-            base[i] = acc;
-        }
-        DWBC_SYNC();
-        if (qi == 0) DWBC_FSTAMP(42);  // level 0: base torque
-        // contact wrench map in the contact frame: F = A_rot J̄[:,6:] U ; fv = A_rot (J̄[:,6:] base - P_C)
-        for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-            const int i = fdt1.div(idx), j = idx - i * (t + 1);
-            real_t acc = real_t(0.0);
-            if (j < t) {
-                _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Ul[c * T + j];
+        // torque the level starts from (dwbc.cpp:1001-1016) and its contact wrench minus P_C in the contact frames, both from
+        // what is already there: fv = wacc + F_l f*_l (task level) or wacc + F_N contact_qp_ (redistribution)
+        for (int i = th.tid; i < M + C; i += NT) {
+            if (i < M) {
+                real_t acc = L[S::tg + i] + L[S::tt + i];
+                if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
+                else acc += L[S::tc + i];
+                base[i] = acc;
             } else {
-                _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * base[c];
-                acc -= L[S::PC + i];
+                const int r = i - M;
+                real_t acc = wacc[r];
+                if (is_task) { for (int j = 0; j < t; j++) acc += WM[r * WLD + colL + j] * fs[j]; }
+                else { for (int j = 0; j < k; j++) acc += WM[r * WLD + colN + j] * clast[j]; }
+                fv[r] = acc;
             }
-            L[S::t_s1 + i * (T + 1) + j] = acc;
         }
         DWBC_SYNC();
-        if (qi == 0) DWBC_FSTAMP(43);  // level 0: wrench map
-        for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-            const int i = fdt1.div(idx), j = idx - i * (t + 1);
-            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
-            const real_t *R = L + S::Rc + a * 9;
-            const real_t *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
-            const real_t v = R[0 * 3 + x] * src[0] + R[1 * 3 + x] * src[T + 1] + R[2 * 3 + x] * src[2 * (T + 1)];
-            if (j < t) F[i * kQpLd + j] = v; else fv[i] = v;
-        }
-        DWBC_SYNC();
+        if (qi == 0) DWBC_FSTAMP(42);  // level 0: base torque and wrench
         if (is_task) DWBC_STAMP(7 + 3 * qi);
         QpResult qres;
         {
             // task level: x = [f*_qp (t) ; contact_qp (k)], rows [U | s NwJw];  redistribution: x = c (k), rows [NwJw]
             const real_t *P1 = is_task ? Ul : L + S::NwJw;
-            // strides of NwJw / FNl: k is 0 (blocks unused) or 6, so the constant 6 serves both and folds after inlining
+            // strides of NwJw: k is 0 (block unused) or 6, so the constant 6 serves both and folds after inlining
             static_assert(T == 6, "stride of U equals the stride of NwJw");
             const int n1 = is_task ? t : k, n2 = is_task ? k : 0;
-            const real_t *W1 = is_task ? F : L + S::FNl;
-            const int ldw1 = is_task ? kQpLd : 6;
+            const real_t *W1 = WM + (is_task ? colL : colN);
             qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
-                                     is_task ? kQpScaleGI : real_t(1.0), W1, ldw1, L + S::FNl, 6, fv, base, n1,
+                                     is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x,
-                                     (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr);
+                                     (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr, &qc);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
@@ -881,6 +1125,13 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[t + j];
                 L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+            }
+            for (int i = th.tid; i < C; i += NT) {  // the wrench of what this level commits; contact_qp_ for the redistribution's start
+                real_t acc = wacc[i];
+                _Pragma("unroll 8")
+                for (int j = 0; j < t; j++) acc += WM[i * WLD + colL + j] * (fs[j] + x[j]);
+                wacc[i] = acc;
+                if (i < S::K) clast[i] = i < k ? x[t + i] : real_t(0.0);
             }
             if (dump) {
                 for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + qi * T + j] = x[j];

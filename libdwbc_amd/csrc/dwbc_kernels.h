@@ -12,26 +12,30 @@ namespace dwbc {
 //   _v2   amdgpu_waves_per_eu(2): VGPR + AGPR <= 256, so a fifth workgroup of a CU (the LDS map allows 5 at <= 31 KB) can
 //         share a SIMD -- the throughput build for batches larger than 4 instances per CU
 //   _v2w  no register cap (one wave per SIMD): ~7 % shorter single-instance latency -- used while B <= 4 x CUs
-#define DWBC_V2_BODY                                                                     \
+#define DWBC_V2_BODY(COMPACT)                                                            \
     static_assert(NT == 64, "one wavefront per instance");                               \
     extern __shared__ __attribute__((aligned(16))) real_t lds[];                         \
     const int inst = blockIdx.x;                                                         \
     if (inst >= io.B) return;                                                            \
     Thr th{(int)threadIdx.x};                                                            \
-    int *iL = reinterpret_cast<int *>(lds + Lds2<N, NB, NLV>::total);                    \
-    cycle_instance_v2<N, NB, NLV, NT, EXTRAS, Topo>(th, su, io, inst, lds, iL);
+    int *iL = reinterpret_cast<int *>(lds + V2Lds<N, NB, NLV, COMPACT>::type::total);    \
+    cycle_instance_v2<N, NB, NLV, NT, EXTRAS, Topo, COMPACT>(th, su, io, inst, lds, iL);
 // EXTRAS: see cycle_instance_v2 -- false = the lean build the launcher uses when no optional path is requested
 // Topo: a constant kinematic tree (dwbc_topo.h) whose sparsity the A^-1 sweep uses, or TopoGeneric
-template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
+// COMPACT: the 20 KB LDS map (Lds3, dwbc_cycle2.h) -- the lean capped build of a constant-tree model takes it: eight workgroups
+// share a CU (two waves per SIMD) instead of five
+template <int N, int NB, int NLV, bool COMPACT>
+struct V2Lds { using type = typename std::conditional<COMPACT, Lds3<N, NB, NLV>, Lds2<N, NB, NLV>>::type; };
+template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo, bool COMPACT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2(const Setup su, const BatchIO io) {
-    DWBC_V2_BODY
+    DWBC_V2_BODY(COMPACT)
 }
 #ifndef DWBC_WIDE_ATTR
 #define DWBC_WIDE_ATTR
 #endif
 template <int N, int NB, int NLV, int NT, bool EXTRAS, class Topo>
 __global__ __launch_bounds__(NT) DWBC_WIDE_ATTR void dwbc_cycle_kernel_v2w(const Setup su, const BatchIO io) {
-    DWBC_V2_BODY
+    DWBC_V2_BODY(false)
 }
 
 // reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
@@ -56,6 +60,7 @@ struct KernelEntry {
     void (*fn_wide)(const Setup, const BatchIO);  // uncapped-register build for batches of at most 4 instances per CU
     void (*fn_lean)(const Setup, const BatchIO);       // the same two without the optional paths (EXTRAS = false), or nullptr
     void (*fn_wide_lean)(const Setup, const BatchIO);
+    int lds_bytes_lean;  // dynamic LDS of fn_lean when it differs from lds_bytes (the compact map), else 0
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
 // flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).  Other model sizes come
@@ -65,7 +70,7 @@ struct KernelEntry {
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
     {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>},
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes},
 };
 const KernelEntry kKernelsReduced[] = {
     {39, 34, 2, 1, dwbc_cycle_kernel_reduced<39, 34, 2, kNT, TopoTocabi>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
@@ -73,13 +78,13 @@ const KernelEntry kKernelsReduced[] = {
 #else
 const KernelEntry kKernels[] = {
     {39, 34, 1, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true, TopoTocabi>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false, TopoTocabi>},
+     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false, TopoTocabi>, Lds3<39, 34, 1>::total_bytes},
     {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>},
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes},
     {39, 34, 3, 1, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true, TopoTocabi>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 3, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false, TopoTocabi>},
+     dwbc_cycle_kernel_v2<39, 34, 3, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false, TopoTocabi>, Lds3<39, 34, 3>::total_bytes},
     {39, 34, 4, 1, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true, TopoTocabi>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 4, kNT, false, TopoTocabi>, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, false, TopoTocabi>},
+     dwbc_cycle_kernel_v2<39, 34, 4, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, false, TopoTocabi>, Lds3<39, 34, 4>::total_bytes},
     {39, 34, 1, 0, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true, TopoGeneric>, Lds2<39, 34, 1>::total_bytes, nullptr, nullptr, nullptr},
     {39, 34, 2, 0, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoGeneric>, Lds2<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
     {39, 34, 3, 0, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true, TopoGeneric>, Lds2<39, 34, 3>::total_bytes, nullptr, nullptr, nullptr},

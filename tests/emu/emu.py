@@ -77,7 +77,7 @@ class Emu:
         g = np.ascontiguousarray(gains15, np.float64)
         self.L.emu_set_traj(C.c_void_p(self.h), level, link_index, slot, C.c_void_p(g.ctypes.data))
 
-    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None, custom_J=None, hqp=True, dense=False, warm_diag=None):
+    def run(self, q, flags, fstar, dump=False, reduced=False, qdot=None, traj=None, ctime=None, custom_J=None, hqp=True, dense=False, warm_diag=None, compact=False):
         B = q.shape[0]
         q = np.ascontiguousarray(q, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
@@ -94,6 +94,7 @@ class Emu:
         qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
         self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))
         self.L.emu_set_hqp(1 if hqp else 0)
+        self.L.emu_set_compact(1 if compact else 0)  # lean build on the compact LDS map (Lds3), LDS NaN-poisoned per instance
         self.L.emu_set_dense(1 if dense else 0)  # two-level runs: TopoGeneric instantiation (dense A^-1 sweep)
         cj = None if custom_J is None else np.ascontiguousarray(custom_J, np.float64)  # (B, n_custom, 6, n)
         self.L.emu_set_custom(C.c_void_p(cj.ctypes.data if cj is not None else None))

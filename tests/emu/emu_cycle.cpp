@@ -6,6 +6,8 @@
 #define DWBC_HOST_EMU 1
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -147,6 +149,11 @@ void emu_set_traj(EmuCtx *c, int level, int link_index, int slot, const double *
 void emu_set_traj_data(const double *traj, const double *ctime) { g_emu_traj = traj; g_emu_ctime = ctime; }
 static int g_emu_warm = 0;
 void emu_set_warm(int on) { g_emu_warm = on; }
+// 1: the lean build on the compact LDS map (Lds3: the throughput kernel of batches beyond four instances per CU); LDS is
+// poisoned with NaN before every instance, so a read of a block that nothing has written yet shows up in the result
+static int g_emu_compact = 0;
+void emu_set_compact(int on) { g_emu_compact = on; }
+int emu_lds_bytes_compact(int nlv) { return nlv == 1 ? Lds3<39, 34, 1>::total_bytes : nlv == 2 ? Lds3<39, 34, 2>::total_bytes : nlv == 3 ? Lds3<39, 34, 3>::total_bytes : Lds3<39, 34, 4>::total_bytes; }
 static const double *g_emu_qdot = nullptr;
 void emu_set_qdot(const double *qd) { g_emu_qdot = qd; }
 
@@ -178,6 +185,24 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.warm = g_emu_warm;
     std::vector<real_t> lds(Lds2<39, 34, 4>::total + 64);
     std::vector<int> ilds(64);
+    if (g_emu_compact) {
+        if (dump) { c->err = "the compact (lean) build has no dump record"; return 0; }
+        io.diag = diag;
+        for (int b = 0; b < B; b++) {
+            Thr th{0};
+            const real_t nan_ = std::numeric_limits<real_t>::quiet_NaN();
+            auto run = [&](auto nlv) {
+                constexpr int NLV = decltype(nlv)::value;
+                std::fill(lds.begin(), lds.end(), nan_);
+                cycle_instance_v2<39, 34, NLV, 1, false, TopoTocabi, true>(th, c->su, io, b, lds.data(), ilds.data());
+            };
+            if (c->su.n_levels == 1) run(std::integral_constant<int, 1>{});
+            else if (c->su.n_levels == 2) run(std::integral_constant<int, 2>{});
+            else if (c->su.n_levels == 3) run(std::integral_constant<int, 3>{});
+            else run(std::integral_constant<int, 4>{});
+        }
+        return 1;
+    }
     for (int b = 0; b < B; b++) {
         Thr th{0};
         if (c->su.n_levels == 1) cycle_instance_v2<39, 34, 1, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());

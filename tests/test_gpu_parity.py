@@ -564,3 +564,33 @@ def test_pipelined_set_state_does_not_tear_the_previous_upload():
         assert (st == st_ref).all(), mode
         assert np.array_equal(tau, tau_ref), mode
         assert np.array_equal(wr, wr_ref), mode
+
+
+@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "mixed", "ss_L"])
+def test_compact_throughput_kernel_vs_oracle(cfg, monkeypatch):
+    """The lean register-capped kernel on the compact 20 KB LDS map (Lds3) is what every batch beyond four instances per CU
+    runs -- configs[2..4] and the 8-GPU shards of 8192.  Forced here at a size the oracle finishes in seconds (DWBC_NO_WIDE: the
+    launcher skips the one-wave-per-SIMD build), every instance against the oracle."""
+    monkeypatch.setenv("DWBC_NO_WIDE", "1")
+    B = 1536
+    tasks, kw = cases.TASKS_2LEVEL, dict(seed=20251226 + 11)
+    if cfg == "ds_yaw":
+        kw["yaw"] = True
+    elif cfg == "mixed":
+        kw["contact_mode"] = "mixed"
+    elif cfg == "ss_L":
+        kw.update(contact_mode="L", levels=3)
+        tasks = cases.TASKS_3LEVEL_SWING_R
+    q, flags, fstar = cases.synth_batch(B, **kw)
+    wbc = _make(B, tasks=tasks)
+    tau, wr, st = _run(wbc, q, flags, fstar)
+    name = wbc.kernel_name()
+    assert "dwbc_cycle_kernel_v2<" in name and name.endswith("TopoTocabi, true>"), name
+    nt, lds = wbc.launch_info()
+    assert lds <= (20480 if len(tasks) == 2 else 26624), lds
+    tau_r, wr_r, st_r, _ = _oracle(B, q, flags, fstar, tasks=tasks)
+    assert (st == st_r).all()
+    ok = st_r == 1
+    assert ok.mean() > 0.9
+    assert np.abs(tau[ok] - tau_r[ok]).max() < TOL
+    assert np.abs(wr[ok] - wr_r[ok]).max() < 1e-5

@@ -37,8 +37,11 @@ def test_emulated_kernel_on_golden_cases(case):
     assert er(r["tau"][0, 2], g("torque_contact_")[:, 0]) < (1e-8 if case == 1 else 1e-3)
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit"])
-def test_emulated_kernel_vs_oracle_batches(cfg):
+def test_emulated_kernel_vs_oracle_batches(cfg, compact):
+    """compact = True: the lean build on the 20 KB LDS map (Lds3 of dwbc_cycle2.h: the throughput kernel of batches beyond four
+    instances per CU) with LDS poisoned by NaN before every instance -- a block read before anything wrote it shows in the result."""
     B = 48
     contacts, tasks, lim = cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM
     kw = dict(seed=1234)
@@ -56,11 +59,12 @@ def test_emulated_kernel_vs_oracle_batches(cfg):
         lim = None
     q, fl, fs = cases.synth_batch(B, **kw)
     e = Emu(cases.URDF, contacts, tasks, lim)
-    r = e.run(q, fl, fs)
+    r = e.run(q, fl, fs, compact=compact)
     tau_r, wr_r, st_r, _ = _oracle(q, fl, fs, contacts, tasks, lim)
     assert (r["status"] == st_r).all()
     ok = st_r == 1
     assert ok.mean() > 0.5
+    assert np.isfinite(r["tau"]).all()
     assert np.abs(r["tau"][ok] - tau_r[ok]).max() < 1e-6
     assert np.abs(r["wrench"][ok] - wr_r[ok][:, :12]).max() < 1e-5
 
@@ -370,3 +374,19 @@ def test_redistribution_torque_is_an_internal_wrench(hqp):
         assert np.abs(mom).max() < 1e-7 * scale
         moved += int(np.abs(tc).max() > 1e-6)
     assert moved > 0
+
+
+def test_compact_lds_map_fits_eight_workgroups_per_cu():
+    """two task levels on the compact map: <= 20 480 B, the measured limit for eight single-wave workgroups per CU
+    (profiles/r01_final_lds_coresidency.txt); the regular map stays the 31.6 KB it was"""
+    import ctypes as C
+
+    from tests.emu.emu import lib
+
+    L = lib(False)
+    L.emu_lds_bytes_compact.argtypes = [C.c_int]
+    L.emu_lds_bytes_v2.argtypes = [C.c_int]
+    assert L.emu_lds_bytes_compact(2) <= 20480 and L.emu_lds_bytes_compact(1) <= 20480
+    assert L.emu_lds_bytes_compact(3) <= 26624   # six per CU
+    assert L.emu_lds_bytes_compact(4) <= 31744   # five per CU
+    assert L.emu_lds_bytes_v2(2) <= 31744
