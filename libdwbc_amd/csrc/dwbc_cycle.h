@@ -88,6 +88,9 @@ constexpr real_t kQpTol = kF32 ? real_t(DWBC_F32_TOL) : real_t(1.0e-9);
 constexpr real_t kQpZeroRow = kF32 ? real_t(1.0e-5) : real_t(1.0e-9);     // rows with a smaller norm are the constraint 0 <= hi
 constexpr real_t kQpFeasTol = kF32 ? real_t(DWBC_F32_FEAS) : real_t(1.0e-7);     // acceptance of the lexicographic point (slack / |row|)
 constexpr int kQpLd = 12;                 // max QP variables (6 task + 6 contact-null)
+constexpr real_t kCodThreshold = kF32 ? real_t(1.0e-4) : real_t(1.0e-6);  // COD_THRESHOLD of the reference (include/dwbc_wbd.h:10); fp32 cannot resolve it
+constexpr real_t kCodCondFast = real_t(3.0e3);  // condition estimate of Lambda_task^-1 below which J_kt = (T1r W^+)^T is taken (dwbc_cycle2.h, stage 3a)
+constexpr real_t kCodCheck = kF32 ? real_t(1.0e-3) : real_t(1.0e-4);      // Cholesky pivot ratio below which a t x t block takes the rank-revealing route
 constexpr real_t kQpReorth = real_t(1.0e-2);  // |H n|^2 below which the new direction is projected a second time (dwbc_qp_wave.h)
 #ifndef DWBC_QP_REFINE
 #define DWBC_QP_REFINE 10
@@ -442,6 +445,9 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
     DWBC_LANE_DECL;
     QpRows R;
     const int nv = t1 + t2;
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+    const long long t_fill0_ = clock64();
+#endif
     QpLaneConst qloc;
     if (!qcp) qp_lane_consts<N>(su, ci0, ci1, qloc);  // (callers that solve one QP only)
     const QpLaneConst &qc = qcp ? *qcp : qloc;
@@ -482,6 +488,9 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
             LV(R.id_hi) = nlim + rr;
         }
     }
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+    const long long t_fill1_ = clock64();
+#endif
     // the solver is instantiated for 12, 9 and 6 variables (6 + 6, 3 + 6 and the 6 contact-null variables of the redistribution)
     if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds, warm);
     else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds, warm);
@@ -490,6 +499,9 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
         if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }
     DWBC_SYNC();
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+    res.tm[8] = t_fill1_ - t_fill0_;
+#endif
 }
 
 }  // namespace dwbc

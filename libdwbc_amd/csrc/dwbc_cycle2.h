@@ -109,6 +109,7 @@ struct Lds2 {
     static constexpr int Rw0 = Rw;                             // pelvis rotation for the base columns of the point Jacobians
     static constexpr int c_QWp = c_Jt;                         // Q W^+ of stage 3a (c_Jt / c_T1 are free again by then)
     static constexpr int c_s2b = c_s2;                         // input of the small SPD inverses of stage 3a
+    static constexpr int cod_Q = c_s1, cod_v = c_s1 + T * T, cod_G = c_s2 + T * T, cod_T = c_s2 + 2 * T * T;  // scratch of pinv_cod_small
     static constexpr int Pt = 0, c_Gi = 0;                     // (compact map only)
     static constexpr int xl(int lv) { return Xl + lv * M * T; }  // X = J_kt Lambda of level lv < NLV - 1
 };
@@ -210,6 +211,8 @@ struct Lds3 {
     static constexpr int c_Pi = c_s1 + 64;                     // T x T
     static constexpr int c_Z = c_Pi + T * T;                   // T x T
     static constexpr int c_s2b = c_Z + T * T;                  // T x T: input of the small SPD inverses of stage 3a
+    static constexpr int cod_Q = c_s1, cod_v = c_s1 + T * T, cod_G = c_Z, cod_T = c_s2b + T * T;  // scratch of pinv_cod_small (c_Z is idle then)
+    static_assert(cod_v + 3 * T <= c_Pi && cod_T + T * T <= RXend, "rank-revealing route scratch");
     // ---- QP scratch (RE .. RG)
     static constexpr int WLD = 32;
     static constexpr int t_base = RE;                          // M
@@ -445,10 +448,11 @@ DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real
 // cross-lane traffic -- and lane c < n then solves L L^T x = e_c for column c of the inverse with 30 FMAs.  About half
 // the instructions of the 12-wide register sweep and none of its v_readlane broadcasts (a lone wave issues one instruction of
 // any kind per ~5 cycles, a readlane-fed FMA costs ~21: profiles/r02_ubench3_instruction_costs.txt).
-DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, int ldo) {
+DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *pivratio = nullptr) {
     DWBC_LANE_DECL;
     real_t Lc[6][6], ri[6];
     int ok = 1;
+    real_t dmin = kF32 ? real_t(1e30) : real_t(1e300), dmax = real_t(0.0);  // smallest / largest pivot of the block (rows < n)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -458,6 +462,7 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
         real_t d = Lc[j][j];
 #pragma unroll
         for (int k = 0; k < j; k++) d -= Lc[j][k] * Lc[j][k];
+        if (pivratio && j < n) { dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; }
         if (!(d > real_t(0.0))) { ok = 0; d = real_t(1.0); }
         ri[j] = fast_rsqrt(d);
 #pragma unroll
@@ -468,6 +473,7 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
             Lc[i][j] = v * ri[j];
         }
     }
+    if (pivratio) *pivratio = (ok && dmax > real_t(0.0)) ? dmin / dmax : real_t(0.0);
     DWBC_SYNC();  // Out may alias Ain
     LANES {
         DWBC_LANE_OPAQUE(lc);  // see DWBC_LANE_OPAQUE: the unit-vector masks of every inlined copy would otherwise be shared kernel-wide
@@ -496,11 +502,11 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
     return ok;
 }
 
-DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *colbuf) {
+DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *colbuf, real_t *pivratio = nullptr) {
     DWBC_LANE_DECL;
     (void)colbuf;
     DWBC_SYNC();
-    if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo);
+    if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo, pivratio);
     PLA(real_t, s, 12);
     PL(real_t, dg);
     LANES {
@@ -522,6 +528,122 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     return ok;
 }
 
+// Householder QR (optionally with column pivoting) of a small matrix held in LDS: A (m x n, row stride n) becomes R, Q (m x m) is
+// formed explicitly, piv[j] (stored as reals) = original column now in position j.  m, n <= 6.  Same steps as the restatement's
+// qrcp() (oracle/dwbc_oracle.c) -- largest remaining column norm first, reflector sign against the pivot -- so that the rank
+// decision of pinv_cod_small below falls on the same pivots as Eigen's CompleteOrthogonalDecomposition does in the reference.
+template <int NT>
+DWBC_DEVN void qr_small(Thr th, real_t *A, int m, int n, real_t *Q, real_t *piv, bool pivoting) {
+    for (int idx = th.tid; idx < m * m; idx += NT) Q[idx] = (idx / m == idx % m) ? real_t(1.0) : real_t(0.0);
+    for (int j = th.tid; j < n; j += NT) piv[j] = (real_t)j;
+    const int steps = m < n ? m : n;
+    for (int s = 0; s < steps; s++) {
+        DWBC_SYNC();
+        int best = s;
+        if (pivoting) {
+            real_t bn = -real_t(1.0);
+            for (int j = s; j < n; j++) {
+                real_t t = real_t(0.0);
+                for (int i = s; i < m; i++) t += A[i * n + j] * A[i * n + j];
+                if (t > bn) { bn = t; best = j; }
+            }
+        }
+        DWBC_SYNC();
+        if (best != s) {
+            for (int i = th.tid; i <= m; i += NT) {
+                if (i < m) { const real_t t = A[i * n + s]; A[i * n + s] = A[i * n + best]; A[i * n + best] = t; }
+                else { const real_t t = piv[s]; piv[s] = piv[best]; piv[best] = t; }
+            }
+        }
+        DWBC_SYNC();
+        real_t v[6] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+        real_t nrm = real_t(0.0);
+        for (int i = s; i < m; i++) { v[i] = A[i * n + s]; nrm += v[i] * v[i]; }
+        nrm = sqrt(nrm);
+        DWBC_SYNC();
+        if (nrm == real_t(0.0)) continue;
+        const real_t alpha = v[s] > real_t(0.0) ? -nrm : nrm;
+        v[s] -= alpha;
+        real_t vn = real_t(0.0);
+        for (int i = s; i < m; i++) vn += v[i] * v[i];
+        if (vn == real_t(0.0)) continue;
+        const real_t beta = real_t(2.0) / vn;
+        for (int idx = th.tid; idx < n + m; idx += NT) {
+            if (idx < n) {  // column idx of A (>= s): reflector from the left
+                const int j = idx;
+                if (j >= s) {
+                    real_t d = real_t(0.0);
+                    for (int i = s; i < m; i++) d += v[i] * A[i * n + j];
+                    d *= beta;
+                    for (int i = s; i < m; i++) A[i * n + j] = (j == s && i > s) ? real_t(0.0) : A[i * n + j] - d * v[i];
+                }
+            } else {        // row of Q: Q = Q H
+                const int i = idx - n;
+                real_t d = real_t(0.0);
+                for (int k = s; k < m; k++) d += Q[i * m + k] * v[k];
+                d *= beta;
+                for (int k = s; k < m; k++) Q[i * m + k] -= d * v[k];
+            }
+        }
+    }
+    DWBC_SYNC();
+}
+
+// Moore-Penrose pseudo-inverse of a small square block the way the reference takes it: complete orthogonal decomposition with
+// Eigen's threshold rule, rank = #{ |R_ii| > thr max |R_ii| } on the column-pivoted QR (PinvCODWB, reference src/wbd.cpp:5-30 with
+// COD_THRESHOLD = 1e-6, include/dwbc_wbd.h:10; restated in oracle/dwbc_oracle.c orc_pinv_cod).  Called only for a block the SPD
+// factorisation found ill-conditioned (a nearly straight knee makes Q W^+ Q^T of a pelvis level lose a direction): a full-rank
+// verdict leaves the caller's SPD inverse in place (returns t), a truncated one writes pinv(M_r) = P R1^+ Q1^T into Out.
+//   Mr: the block (t x t, row stride t), destroyed.  Qm, Gm, Tm: t x t scratch each, vec: 3 t reals.
+template <int NT>
+DWBC_DEVN int pinv_cod_small(Thr th, real_t *Mr, int t, real_t thr, real_t *Out, real_t *Qm, real_t *Gm, real_t *Tm, real_t *vec) {
+    real_t *piv = vec, *pz = vec + 6;
+    qr_small<NT>(th, Mr, t, t, Qm, piv, true);
+    real_t maxp = real_t(0.0);
+    for (int i = 0; i < t; i++) { const real_t a = fabs(Mr[i * t + i]); maxp = a > maxp ? a : maxp; }
+    int rank = 0;
+    for (int i = 0; i < t; i++) rank += (fabs(Mr[i * t + i]) > thr * maxp) ? 1 : 0;
+    if (rank == t) return t;
+    DWBC_SYNC();
+    if (rank == 0) {
+        for (int idx = th.tid; idx < t * t; idx += NT) Out[idx] = real_t(0.0);
+        DWBC_SYNC();
+        return 0;
+    }
+    // R1 = first `rank` rows of R (rank x t).  QR of R1^T (t x rank) = Qz Tz; R1^+ = Qz[:, :rank] Tz^-T
+    for (int idx = th.tid; idx < t * rank; idx += NT) Gm[idx] = Mr[(idx % rank) * t + idx / rank];
+    DWBC_SYNC();
+    qr_small<NT>(th, Gm, t, rank, Tm, pz, false);
+    // X = Tz^-T (rank x rank) into Mr: column c by forward substitution with the lower-triangular Tz^T
+    for (int c = th.tid; c < rank; c += NT) {
+        for (int i = 0; i < rank; i++) {
+            real_t sacc = (i == c) ? real_t(1.0) : real_t(0.0);
+            for (int k = 0; k < i; k++) sacc -= Gm[k * rank + i] * Mr[k * rank + c];
+            Mr[i * rank + c] = sacc / Gm[i * rank + i];
+        }
+    }
+    DWBC_SYNC();
+    // R1p = Qz[:, :rank] X (t x rank) into Gm (Tz is dead)
+    for (int idx = th.tid; idx < t * rank; idx += NT) {
+        const int i = idx / rank, j = idx - i * rank;
+        real_t sacc = real_t(0.0);
+        for (int k = 0; k < rank; k++) sacc += Tm[i * t + k] * Mr[k * rank + j];
+        Out[idx] = sacc;            // staged in Out (t x rank, row stride rank)
+    }
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < t * rank; idx += NT) Gm[idx] = Out[idx];
+    DWBC_SYNC();
+    // pinv[piv[i]][j] = sum_k R1p[i][k] Q[j][k]
+    for (int idx = th.tid; idx < t * t; idx += NT) {
+        const int i = idx / t, j = idx - i * t;
+        real_t sacc = real_t(0.0);
+        for (int k = 0; k < rank; k++) sacc += Gm[i * rank + k] * Qm[j * t + k];
+        Out[(int)piv[i] * t + j] = sacc;
+    }
+    DWBC_SYNC();
+    return rank;
+}
+
 // Internal-wrench basis mapped to joint torques: Vb[r][a] = (J_C[:, 6 + r])^T lambda_a, where lambda_a (a < 6) is the wrench pair
 // "unit wrench e_a on the second contact, the balancing wrench on the first" -- null(W) = { J_C[:,6:]^T lambda : J_C[:,:6]^T lambda = 0 }
 // (closed form instead of the complete orthogonal decomposition of src/wbd.cpp:32-53).  JCt is J_C transposed (N x C), Pc the contact points.
@@ -529,23 +651,23 @@ template <int N, int NT>
 DWBC_DEV void internal_wrench_basis(Thr th, const real_t *Pc, const real_t *JCt, real_t *Vb) {
     static_assert(kMaxActiveContacts == 2, "k in {0, 6}");
     constexpr int M = N - 6, C = 6 * kMaxActiveContacts, K6 = 6;
-    for (int idx = th.tid; idx < M * K6; idx += NT) {
-        const int r = idx / 6, a = idx - r * 6;  // k == 6 here
-        const int ci = 1 + a / 6, e = a % 6;
-        real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
-        if (e < 3) f2[e] = real_t(1.0); else m2[e - 3] = real_t(1.0);
-        const real_t d0 = Pc[ci * 3] - Pc[0], d1 = Pc[ci * 3 + 1] - Pc[1], d2 = Pc[ci * 3 + 2] - Pc[2];
-        const real_t m1x = -m2[0] - (d1 * f2[2] - d2 * f2[1]);
-        const real_t m1y = -m2[1] - (d2 * f2[0] - d0 * f2[2]);
-        const real_t m1z = -m2[2] - (d0 * f2[1] - d1 * f2[0]);
-        const int col = 6 + r;
-        const real_t *Jc = JCt + col * C;  // column `col` of J_C: rows 0..5 contact 0, rows 6ci.. contact ci
-        const int o1 = 6 * ci;
-        real_t acc = -f2[0] * Jc[0] - f2[1] * Jc[1] - f2[2] * Jc[2];
-        acc += m1x * Jc[3] + m1y * Jc[4] + m1z * Jc[5];
-        acc += f2[0] * Jc[o1 + 0] + f2[1] * Jc[o1 + 1] + f2[2] * Jc[o1 + 2];
-        acc += m2[0] * Jc[o1 + 3] + m2[1] * Jc[o1 + 4] + m2[2] * Jc[o1 + 5];
-        Vb[idx] = acc;
+    // lambda_a = (unit wrench e_a on contact 1, the balancing wrench on contact 0: force -e_a, moment -m - d x f with d = P_1 - P_0),
+    // so for column c = 6 + r of J_C (rows [f0 m0 f1 m1]):   a < 3 (unit force):  J[6+a] - J[a] - (d x e_a) . J[3:6]
+    //                                                          a >= 3 (unit moment): J[6+a] - J[a]
+    // one row of Vb per thread: the twelve entries of its column of J_C are two contiguous 48-byte runs
+    const real_t d0 = Pc[3] - Pc[0], d1 = Pc[4] - Pc[1], d2 = Pc[5] - Pc[2];
+    for (int r = th.tid; r < M; r += NT) {
+        const real_t *Jc = JCt + (6 + r) * C;
+        real_t j[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) j[i] = Jc[i];
+        real_t *o = Vb + r * K6;
+        o[0] = (j[6] - j[0]) - (d2 * j[4] - d1 * j[5]);
+        o[1] = (j[7] - j[1]) - (d0 * j[5] - d2 * j[3]);
+        o[2] = (j[8] - j[2]) - (d1 * j[3] - d0 * j[4]);
+        o[3] = j[9] - j[3];
+        o[4] = j[10] - j[4];
+        o[5] = j[11] - j[5];
     }
 }
 
@@ -719,6 +841,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(12);  // (diagnostic) NwJw / projector block done
     DWBC_FSTAMP(13);  // FNl
     // ---- task Jacobians, T1 = J_t A^-1 N_c and Lambda_task for every level (dwbc.cpp:685-793, wbd.cpp:210)
+    int fastmask = 0;  // levels whose J_kt needs no second inverse (see below)
     for (int lv = 0; lv < su.n_levels; lv++) {
         // the level body is instantiated for 3 and 6 task rows; in the lean build (no TASK_CUSTOM level) the row count of a
         // level is exactly one of the two, so `t` is a compile-time constant there and every t-dependent loop unrolls
@@ -802,7 +925,21 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
         if (lv == 0) DWBC_FSTAMP(15);  // level 0: J A J^T
-        spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        const int ok_lt = spd_inverse_small(L + S::c_s2, t, t, Lt, t, L + S::c_s1);  // Lambda_task (wbd.cpp:210)
+        {
+            // With a 6D contact, A^-1 N_c has the rank of its joint block W, hence J A^-1 N_c J^T = T1r W^+ T1r^T and the block
+            // Q W^+ Q^T of CalculateJKT (wbd.cpp:212) IS Lambda_task: J_kt = W^+ Q^T pinv(Lambda) = (T1r W^+)^T whenever the reference's
+            // rank-revealing pseudo-inverse does not truncate.  A level whose Lambda_task^-1 is well conditioned takes that route in
+            // stage 3a (no Q, no second t x t inverse); the estimate max diag(M) * max diag(M^-1) bounds the condition number from
+            // below within a factor t^2, and the reference truncates at a pivot ratio of 1e-6.
+            real_t da = real_t(0.0), dl = real_t(0.0);
+            for (int i = 0; i < t; i++) {
+                const real_t a_ = L[S::c_s2 + i * t + i], l_ = Lt[i * t + i];
+                da = a_ > da ? a_ : da;
+                dl = l_ > dl ? l_ : dl;
+            }
+            if (ok_lt && nc > 0 && da * dl < kCodCondFast) fastmask |= 1 << lv;
+        }
         if (lv == 0) DWBC_FSTAMP(16);  // level 0: Lambda_task
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
         if (!S::compact && lv == NLV - 1)
@@ -921,7 +1058,46 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const FastDiv fdt(t);
         const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
         real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;  // (Lds2: c_Jt/c_T1 are free again)
+        real_t *Ul = L + S::U + lv * M * T;
+        real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
+        int cond = 1;
         DWBC_SYNC();
+        // the usual case (see the task-Jacobian stage): J_kt = (T1r W^+)^T, X = J_kt Lambda -- row `lane` of both from the lane's own
+        // column of W^+, nothing passes through LDS but the result
+        auto jkt_fast = [&](auto ttc) {
+            constexpr int TT = decltype(ttc)::value;
+            const bool exact = t == TT;
+            LANES {
+                real_t tw[TT];
+#pragma unroll
+                for (int r = 0; r < TT; r++) {
+                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+#pragma unroll
+                    for (int i = 0; i < M; i++) a4[i & 3] += T1rl[r * M + i] * LV(w)[i];
+                    tw[r] = (exact || r < t) ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : real_t(0.0);
+                    if (dump && lane < M && r < t) dump[dl.J_kt + lv * M * T + lane * t + r] = tw[r];
+                }
+#pragma unroll
+                for (int r3 = 0; r3 < TT; r3++) {
+                    real_t acc = real_t(0.0);
+                    if (exact) {
+#pragma unroll
+                        for (int r2 = 0; r2 < TT; r2++) acc += tw[r2] * Lt[r2 * TT + r3];
+                    } else {
+#pragma unroll
+                        for (int r2 = 0; r2 < TT; r2++) acc += (r2 < t && r3 < t) ? tw[r2] * Lt[r2 * t + r3] : real_t(0.0);
+                    }
+                    if (lane < M) {
+                        Xs[lane * T + r3] = acc;
+                        Ul[lane * T + r3] = acc;
+                    }
+                }
+            }
+        };
+        const bool fast = (fastmask >> lv) & 1;
+        if (fast) {
+            if (t <= 3) jkt_fast(std::integral_constant<int, 3>{}); else jkt_fast(std::integral_constant<int, T>{});
+        } else {
         for (int idx = th.tid; idx < t * M; idx += NT) {  // Q = Lambda T1[:,6:]
             const int i = idx / M, j = idx - i * M;
             real_t acc = real_t(0.0);
@@ -931,9 +1107,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             Q[idx] = acc;
         }
         DWBC_SYNC();
-        real_t *Ul = L + S::U + lv * M * T;
-        real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
-        int cond = 1;
+        }
         auto jkt_rows = [&](auto ttc) {
             constexpr int TT = decltype(ttc)::value;
             for (int r = 0; r < TT; r++) {
@@ -948,8 +1122,15 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             if (lv == 0) DWBC_FSTAMP(21);  // level 0: Q, QW
             mm_nt<NT>(th, L + S::c_s2b, t, QW, M, Q, M, t, M, t);  // Q W^+ Q^T
-            cond = spd_inverse_small(L + S::c_s2b, t, t, Pi, t, L + S::c_s1);  // PinvCODWB (full rank case)
+            real_t pr_ = real_t(1.0);
+            cond = spd_inverse_small(L + S::c_s2b, t, t, Pi, t, L + S::c_s1, &pr_);  // PinvCODWB, full-rank case: the SPD inverse
             DWBC_SYNC();
+            if (!cond || pr_ < kCodCheck) {
+                // ill-conditioned block (a nearly straight knee under a pelvis level): decide the rank as the reference's complete
+                // orthogonal decomposition does (threshold 1e-6 on the pivoted QR) and take the truncated pseudo-inverse if it truncates
+                const int rk = pinv_cod_small<NT>(th, L + S::c_s2b, t, kCodThreshold, Pi, L + S::cod_Q, L + S::cod_G, L + S::cod_T, L + S::cod_v);
+                if (rk < t) cond = 1;
+            }
             if (lv == 0) DWBC_FSTAMP(22);  // level 0: QWQ^T + inverse
             // J_kt = W^+ Q^T pinv(.) ; X = J_kt Lambda ; U = Null_{lv-1} X   -- row `lane` of each in registers
             LANES {
@@ -987,7 +1168,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 }
             }
         };
-        if (t <= 3) jkt_rows(std::integral_constant<int, 3>{}); else jkt_rows(std::integral_constant<int, T>{});
+        if (!fast) { if (t <= 3) jkt_rows(std::integral_constant<int, 3>{}); else jkt_rows(std::integral_constant<int, T>{}); }
         DWBC_SYNC();
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
             const int tp = su.t_dof[pl];
@@ -1043,6 +1224,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             if (i < S::K) clast[i] = real_t(0.0);
         }
         DWBC_SYNC();
+        DWBC_FSTAMP(43);  // wrench maps of the cascade
     }
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
@@ -1110,7 +1292,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (dump && th.tid == 0) dump[dl.qp_viol + slot] = qres.viol;
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
         if (diag && th.tid == 0 && qi == 0)
-            for (int i_ = 0; i_ < 8; i_++) diag[DG_FTIME + 23 + i_] = (int)qres.tm[i_];
+            for (int i_ = 0; i_ < 9; i_++) diag[DG_FTIME + (i_ < 8 ? 23 + i_ : 44)] = (int)qres.tm[i_];
 #endif
         if (is_task) DWBC_STAMP(8 + 3 * qi);
         const real_t *x = L + S::qp_x;

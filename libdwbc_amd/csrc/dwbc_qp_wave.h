@@ -38,12 +38,12 @@ struct QpResult {
     real_t x[kQpN];   // uniform, unscaled [delta (t); c (k)]
     int act[kQpN];    // reference row indices of the working set
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
-    long long tm[8];  // diagnostic build: cycles per solver section
+    long long tm[10];  // diagnostic build: cycles per solver section; [8] row fill, [9] (free)
 #endif
 };
 
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
-#define DWBC_QPT_INIT() long long qpt_last_ = clock64(); for (int i_ = 0; i_ < 8; i_++) out.tm[i_] = 0
+#define DWBC_QPT_INIT() long long qpt_last_ = clock64(); for (int i_ = 0; i_ < 10; i_++) out.tm[i_] = 0
 #define DWBC_QPT(i) do { const long long now_ = clock64(); out.tm[i] += now_ - qpt_last_; qpt_last_ = now_; } while (0)
 #else
 #define DWBC_QPT_INIT() ((void)0)

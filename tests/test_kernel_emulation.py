@@ -390,3 +390,51 @@ def test_compact_lds_map_fits_eight_workgroups_per_cu():
     assert L.emu_lds_bytes_compact(3) <= 26624   # six per CU
     assert L.emu_lds_bytes_compact(4) <= 31744   # five per CU
     assert L.emu_lds_bytes_v2(2) <= 31744
+
+
+def _straight_knee_states(knees):
+    """CASE 1 stance with the LEFT knee `kn` rad from straight (hip and ankle pitch follow so that the foot stays flat)"""
+    q = np.tile(np.array(cases.Q_CASE[1], dtype=np.float64), (len(knees), 1))
+    for i, kn in enumerate(knees):
+        q[i, 9], q[i, 8], q[i, 10] = kn, -kn / 2, -kn / 2
+    fl = np.ones((len(knees), 2), np.uint8)
+    fs = np.tile(np.array(list(cases.FSTAR_CASE[1][0]) + list(cases.FSTAR_CASE[1][1])), (len(knees), 1))
+    return q, fl, fs
+
+
+KNEES = [1e-2, 3e-3, 1e-3, 3e-4, 1e-4, 1e-5, 1e-6]
+
+
+def test_emulated_near_singular_knee_takes_the_references_truncated_pseudo_inverse():
+    """VERDICT r2 missing #3 / next 4(c): a nearly straight knee makes the pelvis level's Q W^+ Q^T lose a direction (pivot ratio
+    2.8e-6 at 1e-2 rad, 2.5e-7 at 3e-3 rad).  The reference takes PinvCODWB of it -- Eigen's complete orthogonal decomposition with
+    threshold 1e-6 (src/wbd.cpp:5-30,212) -- i.e. below 3e-3 rad it TRUNCATES the block to rank 5.  Rounds 1-2 inverted it (SPD
+    Cholesky) and were 0.06 .. 36 Nm away from the restatement there; the kernel now decides the rank on the same pivoted QR and
+    takes pinv(M_r).  Envelope: 2e-9 Nm down to 1e-3 rad; below that Lambda_task = (J A^-1 N_c J^T)^-1 itself (a plain .inverse() in
+    the reference, wbd.cpp:210) has condition 1e10 .. 1e14 and both sides carry ~6e-6 Nm of its round-off; at 1e-8 rad and below
+    the reference's own inverse is undefined."""
+    q, fl, fs = _straight_knee_states(KNEES)
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    tau_r, wr_r, st_r, _ = _oracle(q, fl, fs, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    for compact in (False, True):
+        r = e.run(q, fl, fs, compact=compact)
+        assert (r["status"] == st_r).all() and st_r.all()
+        err = np.abs(r["tau"] - tau_r).max(axis=(1, 2))
+        assert err[:3].max() < 1e-6, err     # 1e-2 .. 1e-3 rad: the bar of every other parity test
+        assert err[3:].max() < 5e-5, err     # 3e-4 .. 1e-6 rad: the round-off of Lambda_task at condition 1e10 .. 1e14
+    # the truncation is really what is exercised: at 3e-3 rad the restatement's block has rank 5 of 6
+    from oracle import dwbc_np as Dn
+
+    c = Dn.Cycle(cases.tocabi_model())
+    for cc in cases.CONTACTS_2:
+        c.add_contact(cc["link"], cc["point"], cc["lx"], cc["ly"], cc["mu"], cc["muz"])
+    c.add_task(0, 0, 0)
+    c.update_kinematics(q[1])
+    c.set_contact([1, 1])
+    c.calc_contact_constraint()
+    Jt = c.task_jacobian(0)
+    AiNc = c.A_inv @ c.N_C
+    Q = (np.linalg.inv(Jt @ AiNc @ Jt.T) @ Jt @ AiNc)[:, 6:]
+    M = Q @ c.W_inv @ Q.T
+    assert np.abs(Dn.pinv_cod(M) @ M - np.eye(6)).max() > 0.1          # not an inverse: a direction was dropped
+    assert np.abs(np.linalg.inv(M) @ M - np.eye(6)).max() < 1e-6       # while the block itself is invertible in double precision

@@ -59,7 +59,7 @@ if d.shape[1] >= 90 + 64:
     fn = {0: "stage 1 starts", 1: "J_C", 2: "Y = J_C A^-1", 3: "Lambda_c", 5: "Jbar^T, A^-1 N_c update", 6: "gravity pre-vector, P_C", 7: "Vb", 8: "Jbar Vb",
           12: "Gram matrix, NwJw, VG", 13: "FNl", 14: "level-0 J_t + T1", 15: "level-0 J A J^T", 16: "level-0 Lambda_t", 17: "all task levels",
           18: "W + alpha P", 19: "W sweep", 20: "W^+ correction + gravity torque", 21: "level-0 Q, Q W^+", 22: "level-0 Q W^+ Q^T inverse",
-          42: "level-0 QP: base torque", 43: "level-0 QP: wrench map"}
+          42: "level-0 QP: base torque and wrench", 43: "wrench maps of the cascade (MFMA)"}
     rows = sorted((st[i], fn[i]) for i in fn if st[i] > 0)
     prev = rows[0][0] if rows else 0.0
     print("fine stamps:")
@@ -70,6 +70,7 @@ if d.shape[1] >= 90 + 64:
     print("level-0 QP solver sections (cycles, summed over iterations):")
     for i, n in enumerate(qn):
         print(f"  {n:24s} {st[23 + i]:10.0f}")
+    print(f"  {'row fill (before the solver)':24s} {st[44]:10.0f}")
     kn = ["q load", "local rotations", "FK rounds", "world inertias", "composite inertias", "S axes", "F = Ic S", "zero A", "CRBA pairs", "A -> registers"]
     print("kinematics sections (cycles):")
     prev = 0.0
