@@ -32,11 +32,11 @@ if ROOT not in sys.path:
 F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit (SURVEY 8d / BASELINE.md 3)
 PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak (public spec), for --dtype f32 runs
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
 # The governing roof is fp64 arithmetic throughput: 78.6 TFLOP/s whether issued as VALU FMAs or as MFMA f64 (same rate on
 # MI355X).  The contract knows two classes of roof, "hbm" and "mfma" (= compute); this kernel belongs to the compute class, and the
 # label says which pipe its fp64 work is actually issued on so that nobody reads it as a claim of matrix-core use.
-ROOF_BOUND = "fp64-fma (compute roof: the contract's 'mfma' class; issued on the VALU)"
+ROOF_BOUND = "fp64-fma (compute roof: the contract's 'mfma' class; VALU FMAs + two MFMA f64 tile products per cycle)"
 ROOF_NOTE = ("compute roof = fp64 FMA throughput, 78.6 TFLOP/s public spec (vector rate = matrix rate on MI355X); algorithmic flop of the "
              "reference's dense formulas; kernel_ms = HIP-event average over max(steps, 200) back-to-back launches")
 
@@ -62,7 +62,8 @@ def hbm_traffic_per_launch(kernel_name, batch):
     try:
         pm = json.load(open(PMC_SUMMARY))
         k = pm["_kernel"]
-        if not kernel_name.startswith(k["kernel"].split("<")[0].replace("void ", "")) or int(k["grid"]) != batch * 64:
+        wg = int(k.get("wg", 64) or 64)  # 64 threads per instance, 128 for the two-wave kernel
+        if not kernel_name.startswith(k["kernel"].split("<")[0].replace("void ", "")) or int(k["grid"]) != batch * wg:
             return None
         return (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     except Exception:
@@ -250,6 +251,22 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
     line = None
     if rank == 0:
         line = make_line(args, world, dt, kern_ms, status_ok, eng.info(), backend)
+        if args.workload == "reduced" and engine_factory is HipEngine:
+            # configs[4] names a "reduced centroidal-dynamics fast path": on this kernel it is NOT one (the 39-wide sweeps are shared,
+            # the reduced blocks come on top) -- the full-model kernel at the same batch and dtype is timed beside it so that nobody
+            # reads the reduced rate as an acceleration
+            import copy
+
+            fa = copy.copy(args)
+            fa.workload = "ds2"
+            full = HipEngine(fa, rank, local_rank)
+            for _ in range(args.warmup):
+                full.solve()
+            fms = full.kernel_ms(args.steps)
+            line["config"]["full_model_same_batch"] = {
+                "cycles_per_s": args.batch / (fms * 1e-3), "kernel_ms": fms, "kernel": full.info()["kernel"],
+                "note": "the reduced (centroidal) path is a coverage row, not a fast path, on this design: reduced / full = "
+                        + f"{(args.batch / (kern_ms * 1e-3)) / (args.batch / (fms * 1e-3)):.2f}"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

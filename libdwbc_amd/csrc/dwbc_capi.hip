@@ -558,6 +558,11 @@ static int entry_lds(const KernelEntry *ke, void (*fn)(const Setup, const BatchI
     return (fn == ke->fn_lean && ke->lds_bytes_lean) ? ke->lds_bytes_lean : ke->lds_bytes;
 }
 
+// the paired kernel serves the lean full-model cycle of small batches (one instance per SIMD); DWBC_NO_PAIR switches it off
+static bool pair_ok(const dwbc_batch *b, const KernelEntry *ke, bool wide, bool lean, bool reduced) {
+    return ke && ke->fn_pair && wide && lean && !reduced && b->dtype != DWBC_F32 && !getenv("DWBC_NO_PAIR");
+}
+
 static const KernelEntry *pick_kernel(const dwbc_batch *b, bool reduced) {
     const int which = reduced ? 2 : 0;
     if (const KernelEntry *ke = lookup_kernel(b->n, b->su.nb, b->su.n_levels, which, b->su.topo_kind)) return ke;
@@ -597,7 +602,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
         float *dump;
         const float *body;
         const int *topo;
-        int hqp, warm;
+        int hqp, pair_swap_bit, warm;
     } io{};
     static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
     io.B = b->B;
@@ -616,6 +621,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     io.body = b->f_body;
     io.topo = b->d_topo;
     io.hqp = b->hqp;
+    io.pair_swap_bit = -1;
     io.warm = (b->warm && b->ws_valid) ? 1 : 0;
     b->ws_valid = !lean;  // the full build leaves every QP's working set in the diagnostics record
     const bool wide = b->f32_fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
@@ -653,6 +659,8 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     if (!b->attr_set) {
         for (auto fn : {b->kern->fn, b->kern->fn_wide, b->kern->fn_lean, b->kern->fn_wide_lean})
             if (fn) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, entry_lds(b->kern, fn)));
+        if (b->kern->fn_pair)
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(b->kern->fn_pair), hipFuncAttributeMaxDynamicSharedMemorySize, b->kern->lds_bytes_pair));
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, b->device));
         b->n_cu = prop.multiProcessorCount;
@@ -661,6 +669,16 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     const bool wide = b->kern->fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     const bool lean = b->kern->fn_lean && lean_ok(b);
     b->ws_valid = !lean && !reduced;  // the full build leaves every QP's working set in the diagnostics record (DG_QP_ACT)
+    if (pair_ok(b, b->kern, wide, lean, reduced)) {
+        // two waves per instance, side chains on the helper wave (dwbc_cycle2p.h).  Which wave of a workgroup is the main one can be
+        // swapped per workgroup (DWBC_PAIR_SWAP_BIT = bit of the workgroup index) to steer the main waves of a CU's four workgroups
+        // onto different SIMDs; measured at B = 1024 (profiles/r03e_pair_roles.txt): no swap 82.3 us per launch, bit 8 / bit 9 99 - 102 us
+        // (the dispatcher already spreads wave 0 of consecutive workgroups), so the default is no swap.
+        const char *sb = getenv("DWBC_PAIR_SWAP_BIT");
+        io.pair_swap_bit = sb ? atoi(sb) : -1;
+        hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->B), dim3(2 * kNT), b->kern->lds_bytes_pair, b->stream, b->su, io);
+        return hipGetLastError() == hipSuccess ? 1 : fail("paired kernel launch failed");
+    }
     auto fn = wide ? (lean ? b->kern->fn_wide_lean : b->kern->fn_wide) : (lean ? b->kern->fn_lean : b->kern->fn);
     hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), entry_lds(b->kern, fn), b->stream, b->su, io);
     HIP_OK(hipGetLastError());
@@ -899,6 +917,10 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
         if (hipGetDeviceProperties(&prop, b->device) == hipSuccess) n_cu = prop.multiProcessorCount;
     }
     const bool wide = ke->fn_wide && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
+    if (pair_ok(b, ke, wide, ke->fn_lean && lean_ok(b), false)) {
+        name = pre + "dwbc_cycle_kernel_v2p<" + sz + ", " + std::to_string(ke->nlv) + topo + ">";
+        return name.c_str();
+    }
     name = pre + (wide ? "dwbc_cycle_kernel_v2w<" : "dwbc_cycle_kernel_v2<") + sz + ", " + std::to_string(ke->nlv) + ", 64" +
            (ke->fn_lean && lean_ok(b) ? ", false" : ", true") + topo + ((!wide && ke->fn_lean && lean_ok(b) && ke->lds_bytes_lean) ? ", true" : "") + ">";
     return name.c_str();
@@ -914,6 +936,11 @@ int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
     }
     const bool wide = ke && ke->fn_wide && b->B <= 4 * n_cu && !getenv("DWBC_NO_WIDE");
     const bool compact = ke && !wide && !b->last_reduced && ke->fn_lean && lean_ok(b) && ke->lds_bytes_lean;
+    if (pair_ok(b, ke, wide, ke && ke->fn_lean && lean_ok(b), b->last_reduced)) {
+        if (threads) *threads = 2 * kNT;
+        if (lds) *lds = ke->lds_bytes_pair;
+        return 1;
+    }
     if (lds) *lds = b->dtype == DWBC_F32 && b->f32_lds ? (wide ? b->f32_lds_wide : b->f32_lds) : (ke ? (compact ? ke->lds_bytes_lean : ke->lds_bytes) : 0);
     return 1;
 }

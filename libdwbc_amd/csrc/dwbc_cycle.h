@@ -440,7 +440,8 @@ template <int N, int NB, int WS = 1>
 DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone, int ci0, int ci1, const real_t *P1, int ld1,
                                 int t1, const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1,
                                 const real_t *W2, int ldw2, const real_t *fv, const real_t *base, int tvars, int max_iter,
-                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr, const QpLaneConst *qcp = nullptr) {
+                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr, const QpLaneConst *qcp = nullptr,
+                                real_t vtol = kQpTol) {
     constexpr int M = N - 6;
     DWBC_LANE_DECL;
     QpRows R;
@@ -492,9 +493,9 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
     const long long t_fill1_ = clock64();
 #endif
     // the solver is instantiated for 12, 9 and 6 variables (6 + 6, 3 + 6 and the 6 contact-null variables of the redistribution)
-    if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds, warm);
-    else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds, warm);
-    else qp_solve_wave<WS, 12>(R, nv, tvars, max_iter, res, Vlds, warm);
+    if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
+    else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
+    else qp_solve_wave<WS, 12>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
     LANES {
         if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }

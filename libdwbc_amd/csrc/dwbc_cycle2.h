@@ -419,7 +419,7 @@ DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real
     if constexpr (sizeof(real_t) != 8 || NN < 16) {  // fp32 build; small matrices: the register sweep
         return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
     } else {
-        const int lane = (int)threadIdx.x;
+        const int lane = (int)(threadIdx.x & 63u);
         int ok = 1;
         {
             DWBC_LANE_OPAQUE(lp);
@@ -1280,7 +1280,8 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             qp_rows_and_solve<N, NB, EXTRAS ? 1 : 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
                                      is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x,
-                                     (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr, &qc);
+                                     (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr, &qc,
+                                     is_task ? kQpTol : kQpFeasTol);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {

@@ -121,9 +121,17 @@ struct Lds4 {
 };
 
 #if defined(DWBC_HOST_EMU)
-#define DWBC_PAIR_BARRIER() ((void)0)
+#define DWBC_PAIR_BARRIER(i) ((void)0)
+#elif defined(DWBC_STAGE_TIMERS)
+// diagnostic build: when each wave reaches barrier i and when the main wave leaves it (shader cycles since kernel start)
+#define DWBC_PAIR_BARRIER(i)                                                                      \
+    do {                                                                                          \
+        if (diag && th.tid == 0) diag[(is_main ? DG_TIME : DG_FTIME) + (i)] = (int)(clock64() - t_start_); \
+        __syncthreads();                                                                          \
+        if (diag && th.tid == 0 && is_main) diag[DG_FTIME + 8 + (i)] = (int)(clock64() - t_start_); \
+    } while (0)
 #else
-#define DWBC_PAIR_BARRIER() __syncthreads()
+#define DWBC_PAIR_BARRIER(i) __syncthreads()
 #endif
 
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
@@ -141,6 +149,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     const int *topo = io.topo;
     const io_t *qin = io.q + (size_t)inst * (N + 1);
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
+    DWBC_STAMP_INIT();
     // ---- contact flags: both waves (uniform loads)
     const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
     int act_c[kMaxActiveContacts] = {0, 0};
@@ -252,7 +261,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         for (int i = th.tid; i < su.fstar_total; i += NT) L[S::fs + i] = (real_t)fin[i];
         if (th.tid == 0) { flg[0] = real_t(1.0); flg[1] = real_t(0.0); }
     }
-    DWBC_PAIR_BARRIER();  // ---- B0: Rw, pw, aw
+    DWBC_PAIR_BARRIER(0);  // ---- B0: Rw, pw, aw
 
     // ================= phase 1 =================
     if (is_main) {
@@ -428,7 +437,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             DWBC_SYNC();
         }
     }
-    DWBC_PAIR_BARRIER();  // ---- B1: A^-1 in the main wave's registers; J_C, Vb, VG, J_t in LDS
+    DWBC_PAIR_BARRIER(1);  // ---- B1: A^-1 in the main wave's registers; J_C, Vb, VG, J_t in LDS
 
     // ================= phase 2 (main): Y = J_C A^-1, Lambda_c, Jbar^T =================
     const unsigned long long cm0 = nc > 0 ? su.c_dofmask[act_c[0]] : 0ull, cm1 = nc > 1 ? su.c_dofmask[act_c[1]] : 0ull;
@@ -519,7 +528,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 if (lane < N) JbT[p * N + lane] = LV(jbk)[p];
         }
     }
-    DWBC_PAIR_BARRIER();  // ---- B2: Jbar^T in LDS
+    DWBC_PAIR_BARRIER(2);  // ---- B2: Jbar^T in LDS
 
     // ================= phase 3 =================
     if (is_main) {
@@ -598,7 +607,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
         DWBC_SYNC();
     }
-    DWBC_PAIR_BARRIER();  // ---- B3: T1 of every level, NwJw in LDS
+    DWBC_PAIR_BARRIER(3);  // ---- B3: T1 of every level, NwJw in LDS
 
     // ================= phase 4 =================
     PLA(real_t, w, M);  // main wave: column `lane` of W -> W^+
@@ -691,7 +700,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         DWBC_SYNC();
         if (th.tid == 0) flg[1] = (real_t)fm;
     }
-    DWBC_PAIR_BARRIER();  // ---- B4: W^+ in the main wave's registers; Lambda_task, the fast-route mask in LDS
+    DWBC_PAIR_BARRIER(4);  // ---- B4: W^+ in the main wave's registers; Lambda_task, the fast-route mask in LDS
     if (!is_main) return;
 
     // ================= phase 5 (main): stage 3a, wrench maps, QP cascade, outputs (dwbc_cycle2.h) =================
@@ -808,6 +817,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
     }
     DWBC_SYNC();
+    DWBC_STAMP(5);  // stage 3a done
 
     // ---- the QP cascade (dwbc.cpp:818-873, 941-1127) and the contact redistribution QP (dwbc.cpp:1372-1568): dwbc_cycle2.h
     const int nlim = su.has_tau_lim ? 2 * M : 0;
@@ -832,6 +842,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (i < S::K) clast[i] = real_t(0.0);
     }
     DWBC_SYNC();
+    DWBC_STAMP(6);  // wrench maps done
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;
@@ -865,13 +876,15 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             const real_t *W1 = WM + (is_task ? colL : colN);
             qp_rows_and_solve<N, NB, 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
                                         is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
-                                        is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x, nullptr, &qc);
+                                        is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x, nullptr, &qc,
+                                        is_task ? kQpTol : kQpFeasTol);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
             diag[DG_QP_ITER + slot] = qres.iters;
             diag[DG_QP_NACT + slot] = qres.nact;
         }
+        if (is_task) DWBC_STAMP(7 + qi);  // QP of level qi solved
         const real_t *x = L + S::qp_x;
         if (is_task) {
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }
@@ -921,6 +934,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         }
         wr[i] = acc;
     }
+    DWBC_STAMP(15);
     if (th.tid == 0) {
         io.status[inst] = (st_contact && st_task && st_redis) ? 1 : 0;
         if (diag) {

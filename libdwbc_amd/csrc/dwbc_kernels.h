@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dwbc_reduced.h"
+#include "dwbc_cycle2p.h"
 
 namespace dwbc {
 
@@ -38,6 +39,20 @@ __global__ __launch_bounds__(NT) DWBC_WIDE_ATTR void dwbc_cycle_kernel_v2w(const
     DWBC_V2_BODY(false)
 }
 
+// two wavefronts per instance (dwbc_cycle2p.h): the lean cycle of batches of at most one instance per SIMD, side chains on a helper wave.
+// roles: wave 0 is the main wave, except in the workgroups whose index has bit io.pair_swap_bit set (see dwbc_batch launch: the
+// waves of consecutive workgroups of a CU land on SIMDs round-robin, and the main waves should not share one)
+template <int N, int NB, int NLV, class Topo>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void dwbc_cycle_kernel_v2p(const Setup su, const BatchIO io) {
+    extern __shared__ __attribute__((aligned(16))) real_t lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    int wave = (int)(threadIdx.x >> 6);
+    if (io.pair_swap_bit >= 0 && ((blockIdx.x >> io.pair_swap_bit) & 1)) wave ^= 1;
+    Thr th{(int)(threadIdx.x & 63u)};
+    cycle_instance_v2p<N, NB, NLV, 64, Topo>(wave, th, su, io, inst, lds);
+}
+
 // reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
 template <int N, int NB, int NLV, int NT, class Topo>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
@@ -51,6 +66,12 @@ __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, 
 }
 
 constexpr int kNT = 64;
+// the paired kernel exists in the fp64 build, for one and two task levels (three levels no longer fit four workgroups per CU)
+#ifdef DWBC_NO_PAIR_KERNEL
+#define DWBC_PAIR_ENTRY(NLV) nullptr, 0
+#else
+#define DWBC_PAIR_ENTRY(NLV) dwbc_cycle_kernel_v2p<39, 34, NLV, TopoTocabi>, Lds4<39, 34, NLV>::total_bytes
+#endif
 
 struct KernelEntry {
     int n, nb, nlv;  // nlv = task levels the LDS map is sized for (0: any)
@@ -61,6 +82,8 @@ struct KernelEntry {
     void (*fn_lean)(const Setup, const BatchIO);       // the same two without the optional paths (EXTRAS = false), or nullptr
     void (*fn_wide_lean)(const Setup, const BatchIO);
     int lds_bytes_lean;  // dynamic LDS of fn_lean when it differs from lds_bytes (the compact map), else 0
+    void (*fn_pair)(const Setup, const BatchIO);  // two waves per instance (128 threads), lean, batches of at most 4 instances per CU; or nullptr
+    int lds_bytes_pair;
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
 // flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).  Other model sizes come
@@ -70,7 +93,8 @@ struct KernelEntry {
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
 const KernelEntry kKernels[] = {
     {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes},
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes,
+     DWBC_PAIR_ENTRY(2)},
 };
 const KernelEntry kKernelsReduced[] = {
     {39, 34, 2, 1, dwbc_cycle_kernel_reduced<39, 34, 2, kNT, TopoTocabi>, LdsR<39, 34, 2>::total_bytes, nullptr, nullptr, nullptr},
@@ -78,9 +102,11 @@ const KernelEntry kKernelsReduced[] = {
 #else
 const KernelEntry kKernels[] = {
     {39, 34, 1, 1, dwbc_cycle_kernel_v2<39, 34, 1, kNT, true, TopoTocabi>, Lds2<39, 34, 1>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false, TopoTocabi>, Lds3<39, 34, 1>::total_bytes},
+     dwbc_cycle_kernel_v2<39, 34, 1, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 1, kNT, false, TopoTocabi>, Lds3<39, 34, 1>::total_bytes,
+     DWBC_PAIR_ENTRY(1)},
     {39, 34, 2, 1, dwbc_cycle_kernel_v2<39, 34, 2, kNT, true, TopoTocabi>, Lds2<39, 34, 2>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, true, TopoTocabi>,
-     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes},
+     dwbc_cycle_kernel_v2<39, 34, 2, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 2, kNT, false, TopoTocabi>, Lds3<39, 34, 2>::total_bytes,
+     DWBC_PAIR_ENTRY(2)},
     {39, 34, 3, 1, dwbc_cycle_kernel_v2<39, 34, 3, kNT, true, TopoTocabi>, Lds2<39, 34, 3>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, true, TopoTocabi>,
      dwbc_cycle_kernel_v2<39, 34, 3, kNT, false, TopoTocabi, true>, dwbc_cycle_kernel_v2w<39, 34, 3, kNT, false, TopoTocabi>, Lds3<39, 34, 3>::total_bytes},
     {39, 34, 4, 1, dwbc_cycle_kernel_v2<39, 34, 4, kNT, true, TopoTocabi>, Lds2<39, 34, 4>::total_bytes, dwbc_cycle_kernel_v2w<39, 34, 4, kNT, true, TopoTocabi>,

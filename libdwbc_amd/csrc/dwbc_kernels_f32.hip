@@ -2,6 +2,7 @@
 // fp64 product kernels (dwbc_kernels.h) with DWBC_REAL = float; the namespace is renamed so that both builds link into
 // libdwbc_hip.so.  dwbc_capi.hip looks the entry points up through dwbc_f32_lookup() and launches them with hipLaunchKernel.
 #define DWBC_REAL float
+#define DWBC_NO_PAIR_KERNEL
 #define dwbc dwbc_f32
 #include "dwbc_kernels.h"
 #undef dwbc

@@ -69,7 +69,10 @@ template <int WS, int NV = kQpN>
 // SolveQPoases(init = false): the search visits those rows first -- each is added as soon as it is violated -- before it falls
 // back to the most-violated rule.  The Tikhonov problem is strictly convex, so the point the search ends at does not depend on
 // the order of the picks; only the path (and the iteration count, when the cold path adds rows it later drops) does.
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, 176 doubles */, const int *warm = nullptr) {
+// vtol: violation (slack / |row|) below which a row counts as satisfied during the search: kQpTol for the task QPs, kQpFeasTol for the
+// contact redistribution QP -- it starts from the point the last task QP handed over, which was accepted at kQpFeasTol (canon rule 5)
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, kQpN doubles */, const int *warm = nullptr,
+                             real_t vtol = kQpTol) {
     DWBC_LANE_DECL;
     const int k = nv - t;
     PLA(real_t, Mx, NV);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
@@ -147,7 +150,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                 WAVE_ARGMIN_F32(val, pl);
                 worst = BCAST(val, pl);
                 kmin = BCASTI(key, pl);
-                if (worst < -kQpTol) got = true;
+                if (worst < -vtol) got = true;
             }
             if (got) {
                 p = kmin >> 1;
@@ -169,7 +172,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             worst = BCAST(val, pl);
             kmin = BCASTI(key, pl);
             DWBC_QPT(1);
-            if (!(worst < -kQpTol)) break;
+            if (!(worst < -vtol)) break;
             p = kmin >> 1;
             side = kmin & 1;
             up = real_t(0.0);

@@ -161,6 +161,8 @@ struct BatchIO {  // device pointers.  Inputs and outputs are io_t (double) in b
     const int *topo;             // parent[nb], depth[nb], subtree[nb]
     int hqp;                     // 1: CalcTaskControlTorque / CalcContactRedistribute with hqp = true (QPs); 0: plain hierarchy +
                                  // closed-form redistribution (dwbc_nohqp.h)
+    int pair_swap_bit;           // paired kernel (dwbc_cycle2p.h): workgroups with this bit of their index set swap the roles of their two
+                                 // waves (-1: never)
     int warm;                    // 1: init = false (reference src/dwbc.cpp:1064-1074, src/qp_wrapper.cpp:249-296): every QP first tries
                                  // the rows of its previous working set (diag[DG_QP_ACT..], written by the previous launch)
 };

@@ -39,7 +39,8 @@
 #else
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")  /* see DWBC_SYNC in dwbc_cycle.h */
 #endif
-#define DWBC_LANE_DECL const int lane = (int)threadIdx.x
+// (the lane inside the wavefront: the paired kernel of dwbc_cycle2p.h runs two wavefronts per workgroup)
+#define DWBC_LANE_DECL const int lane = (int)(threadIdx.x & 63u)
 // a copy of the lane index the optimiser cannot identify with `lane`: comparisons against it are not merged with (and kept
 // alive across) the same comparisons elsewhere -- 39 hoisted `lane == K` masks are 78 SGPRs, i.e. spills through v_writelane
 #define DWBC_LANE_OPAQUE(name) int name = lane; asm volatile("" : "+v"(name))

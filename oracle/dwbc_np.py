@@ -236,7 +236,7 @@ QP_TOL = 1.0e-9
 QP_ZERO_ROW = 1.0e-9  # rows with a smaller norm are treated as 0 . x <= b (their slack is taken unnormalised)
 
 
-def _gi_least_distance(G, b, max_iter):
+def _gi_least_distance(G, b, max_iter, tol=1.0e-9):
     """Goldfarb-Idnani dual active set for  min 1/2|x|^2  s.t. G x <= b.
     Returns (status, x, active list, multipliers).  Written for clarity: every projection is
     recomputed from scratch with lstsq (the HIP kernel updates a QR instead)."""
@@ -252,7 +252,7 @@ def _gi_least_distance(G, b, max_iter):
         viol = s / gnorm
         viol[act] = 0.0
         p = int(np.argmin(viol))
-        if viol[p] >= -QP_TOL:
+        if viol[p] >= -tol:
             return 1, x, act, u
         up = 0.0
         while True:
@@ -339,7 +339,7 @@ def _worst_slack(A, ub, x):
     return float(((ub - A @ x) / nrm).min()) if A.shape[0] else 0.0
 
 
-def solve_qp(A, ub, t, max_iter=1000):
+def solve_qp(A, ub, t, max_iter=1000, tol=None):
     """x = [d (t); c (k)].  Returns (status, x, active_rows).   (DESIGN.md "QP canon")
       1. working set W := active set of  min 1/2|d|^2 + 1/2 eps |c|^2  (eps = QP_SCALE^-2), Goldfarb-Idnani;
       2. x := lexicographic least-norm point on W (min |d| first, then min |c|) if it is feasible to QP_FEAS_TOL,
@@ -348,7 +348,9 @@ def solve_qp(A, ub, t, max_iter=1000):
     k = nv - t
     G = A.copy()
     G[:, t:] *= QP_SCALE
-    st, xh, act, u = _gi_least_distance(G, ub, max_iter)
+    # tol: violation below which a row counts as satisfied during the search: QP_TOL, except for the contact redistribution QP, which
+    # starts from a point the last task QP ACCEPTED at QP_FEAS_TOL and searches with that tolerance (canon rule 5)
+    st, xh, act, u = _gi_least_distance(G, ub, max_iter, QP_TOL if tol is None else tol)
     if st == 0:
         return 0, np.zeros(nv), []
     act_sorted = list(act)
@@ -597,7 +599,7 @@ class Cycle:
         CM = -self.cone_matrix()
         A[nlim:] = CM @ self.J_C_INV_T[:, 6:] @ self.NwJw
         ub[nlim:] = CM @ self.P_C - CM @ self.J_C_INV_T[:, 6:] @ tau_in
-        st, x, act = solve_qp(A, ub, k, 300)  # H = I over all k variables: t := k
+        st, x, act = solve_qp(A, ub, k, 300, tol=QP_FEAS_TOL)  # H = I over all k variables: t := k
         self.redis_qp = (A, ub)
         if st == 0:
             self.tau_contact = np.zeros(m)

@@ -271,7 +271,7 @@ static void ls_project(const double *Ncols, int q, int n, const double *g, doubl
 
 /* Goldfarb-Idnani dual active set on min 1/2|x|^2 s.t. G x <= b (normals n_i = -g_i) */
 static int gi_least_distance(const double *G, const double *b, int m, int n, int max_iter, double *x, int *act,
-                             int *nact_out, double *u, int *iters) {
+                             int *nact_out, double *u, int *iters, double tol) {
     double gnorm[ORC_MAXR];
     double Ncols[ORC_MAXV * ORC_MAXV];
     int q = 0, it = 0;
@@ -284,7 +284,7 @@ static int gi_least_distance(const double *G, const double *b, int m, int n, int
     for (int j = 0; j < n; j++) x[j] = 0.0;
     for (;;) {
         int p = -1;
-        double worst = -QP_TOL;
+        double worst = -tol;
         for (int i = 0; i < m; i++) {
             int in = 0;
             for (int a = 0; a < q; a++) if (act[a] == i) in = 1;
@@ -426,13 +426,23 @@ static void lex_eqp(const double *Ad, const double *Ac, const double *b, int q, 
     }
 }
 
+/* tol: violation (slack / |row|) below which a row counts as satisfied while the working set is searched.  QP_TOL for the task
+ * QPs.  The contact redistribution QP starts from the point the last task QP handed over, and that point was ACCEPTED with the
+ * tolerance QP_FEAS_TOL (rule 2 of the canon): re-examining its active rows at 1e-9 makes the redistribution chase the round-off
+ * of the hand-over (and fail on a degenerate vertex), so it searches with QP_FEAS_TOL -- canon rule 5, DESIGN.md. */
+int orc_solve_qp_tol(const double *A, const double *ub, int rows, int nv, int t, int max_iter, double *x, int *act,
+                     int *nact, int *iters, double tol);
 int orc_solve_qp(const double *A, const double *ub, int rows, int nv, int t, int max_iter, double *x, int *act,
                  int *nact, int *iters) {
+    return orc_solve_qp_tol(A, ub, rows, nv, t, max_iter, x, act, nact, iters, QP_TOL);
+}
+int orc_solve_qp_tol(const double *A, const double *ub, int rows, int nv, int t, int max_iter, double *x, int *act,
+                     int *nact, int *iters, double tol) {
     double G[ORC_MAXR * ORC_MAXV], u[ORC_MAXV], xh[ORC_MAXV];
     int k = nv - t, q = 0;
     for (int i = 0; i < rows; i++)
         for (int j = 0; j < nv; j++) G[i * nv + j] = A[i * nv + j] * (j >= t ? QP_SCALE : 1.0);
-    int st = gi_least_distance(G, ub, rows, nv, max_iter, xh, act, &q, u, iters);
+    int st = gi_least_distance(G, ub, rows, nv, max_iter, xh, act, &q, u, iters, tol);
     *nact = q;
     if (!st) {
         for (int j = 0; j < nv; j++) x[j] = 0.0;
@@ -984,7 +994,7 @@ void orc_cycle(const orc_model *mdl, const orc_setup *su, const double *q, const
             Qub[nlim + r] = s;
         }
         /* the reference pads contact_link_num_*rows zero rows (dwbc.cpp:1420): dropped */
-        int ok = orc_solve_qp(QA, Qub, rows, k, k, 300, x, out->qp_act[L], &out->qp_nact[L], &out->qp_iter[L]);
+        int ok = orc_solve_qp_tol(QA, Qub, rows, k, k, 300, x, out->qp_act[L], &out->qp_nact[L], &out->qp_iter[L], QP_FEAS_TOL);
         if (dbg) {
             memcpy(dbg->qpA[L], QA, sizeof(double) * rows * k);
             memcpy(dbg->qpub[L], Qub, sizeof(double) * rows);

@@ -94,7 +94,9 @@ class Emu:
         qd = None if qdot is None else np.ascontiguousarray(qdot, np.float64)
         self.L.emu_set_qdot(C.c_void_p(qd.ctypes.data if qd is not None else None))
         self.L.emu_set_hqp(1 if hqp else 0)
-        self.L.emu_set_compact(1 if compact else 0)  # lean build on the compact LDS map (Lds3), LDS NaN-poisoned per instance
+        # compact: True = lean build on the compact LDS map (Lds3); "pair" = the two-wave kernel of dwbc_cycle2p.h, roles run in turn;
+        # LDS NaN-poisoned per instance in both
+        self.L.emu_set_compact(2 if compact == "pair" else (1 if compact else 0))
         self.L.emu_set_dense(1 if dense else 0)  # two-level runs: TopoGeneric instantiation (dense A^-1 sweep)
         cj = None if custom_J is None else np.ascontiguousarray(custom_J, np.float64)  # (B, n_custom, 6, n)
         self.L.emu_set_custom(C.c_void_p(cj.ctypes.data if cj is not None else None))

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../libdwbc_amd/csrc/dwbc_reduced.h"
+#include "../../libdwbc_amd/csrc/dwbc_cycle2p.h"
 #include "../../libdwbc_amd/csrc/dwbc_hqp.h"
 #include "../../libdwbc_amd/csrc/dwbc_model.h"
 #include "../../libdwbc_amd/csrc/dwbc_setup.h"
@@ -153,6 +154,7 @@ void emu_set_warm(int on) { g_emu_warm = on; }
 // poisoned with NaN before every instance, so a read of a block that nothing has written yet shows up in the result
 static int g_emu_compact = 0;
 void emu_set_compact(int on) { g_emu_compact = on; }
+int emu_lds_bytes_pair(int nlv) { return nlv == 1 ? Lds4<39, 34, 1>::total_bytes : Lds4<39, 34, 2>::total_bytes; }
 int emu_lds_bytes_compact(int nlv) { return nlv == 1 ? Lds3<39, 34, 1>::total_bytes : nlv == 2 ? Lds3<39, 34, 2>::total_bytes : nlv == 3 ? Lds3<39, 34, 3>::total_bytes : Lds3<39, 34, 4>::total_bytes; }
 static const double *g_emu_qdot = nullptr;
 void emu_set_qdot(const double *qd) { g_emu_qdot = qd; }
@@ -185,6 +187,19 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
     io.warm = g_emu_warm;
     std::vector<real_t> lds(Lds2<39, 34, 4>::total + 64);
     std::vector<int> ilds(64);
+    if (g_emu_compact == 2) {
+        // the paired kernel of dwbc_cycle2p.h with both roles run one after the other in every phase (wave = -1), LDS poisoned
+        if (dump) { c->err = "the paired (lean) build has no dump record"; return 0; }
+        if (c->su.n_levels > 2) { c->err = "the paired kernel is built for one and two task levels"; return 0; }
+        std::vector<real_t> l4(Lds4<39, 34, 2>::total + 64);
+        for (int b = 0; b < B; b++) {
+            Thr th{0};
+            std::fill(l4.begin(), l4.end(), std::numeric_limits<real_t>::quiet_NaN());
+            if (c->su.n_levels == 1) cycle_instance_v2p<39, 34, 1, 1, TopoTocabi>(-1, th, c->su, io, b, l4.data());
+            else cycle_instance_v2p<39, 34, 2, 1, TopoTocabi>(-1, th, c->su, io, b, l4.data());
+        }
+        return 1;
+    }
     if (g_emu_compact) {
         if (dump) { c->err = "the compact (lean) build has no dump record"; return 0; }
         io.diag = diag;

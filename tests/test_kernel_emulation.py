@@ -37,11 +37,13 @@ def test_emulated_kernel_on_golden_cases(case):
     assert er(r["tau"][0, 2], g("torque_contact_")[:, 0]) < (1e-8 if case == 1 else 1e-3)
 
 
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, True, "pair"])
 @pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit"])
 def test_emulated_kernel_vs_oracle_batches(cfg, compact):
     """compact = True: the lean build on the 20 KB LDS map (Lds3 of dwbc_cycle2.h: the throughput kernel of batches beyond four
     instances per CU) with LDS poisoned by NaN before every instance -- a block read before anything wrote it shows in the result."""
+    if compact == "pair" and cfg in ("ss_L", "ss_R"):
+        pytest.skip("the paired (two-wave) kernel is built for one and two task levels")  # "pair": dwbc_cycle2p.h, both roles in turn
     B = 48
     contacts, tasks, lim = cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM
     kw = dict(seed=1234)
@@ -390,6 +392,8 @@ def test_compact_lds_map_fits_eight_workgroups_per_cu():
     assert L.emu_lds_bytes_compact(3) <= 26624   # six per CU
     assert L.emu_lds_bytes_compact(4) <= 31744   # five per CU
     assert L.emu_lds_bytes_v2(2) <= 31744
+    L.emu_lds_bytes_pair.argtypes = [C.c_int]
+    assert L.emu_lds_bytes_pair(2) <= 40960 and L.emu_lds_bytes_pair(1) <= 40960  # paired kernel: four workgroups per CU
 
 
 def _straight_knee_states(knees):
@@ -416,7 +420,7 @@ def test_emulated_near_singular_knee_takes_the_references_truncated_pseudo_inver
     q, fl, fs = _straight_knee_states(KNEES)
     e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
     tau_r, wr_r, st_r, _ = _oracle(q, fl, fs, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
-    for compact in (False, True):
+    for compact in (False, True, "pair"):  # the wide map, the compact map, the two-wave kernel
         r = e.run(q, fl, fs, compact=compact)
         assert (r["status"] == st_r).all() and st_r.all()
         err = np.abs(r["tau"] - tau_r).max(axis=(1, 2))
@@ -438,3 +442,24 @@ def test_emulated_near_singular_knee_takes_the_references_truncated_pseudo_inver
     M = Q @ c.W_inv @ Q.T
     assert np.abs(Dn.pinv_cod(M) @ M - np.eye(6)).max() > 0.1          # not an inverse: a direction was dropped
     assert np.abs(np.linalg.inv(M) @ M - np.eye(6)).max() < 1e-6       # while the block itself is invertible in double precision
+
+
+def test_redistribution_qp_searches_with_the_acceptance_tolerance():
+    """QP canon rule 5.  Large task accelerations (PD references of tests/test_task_reference.py: |f*| of several
+    m/s^2) drive the level QPs onto degenerate vertices -- nine active rows on nine variables.  The point such a QP hands over
+    was accepted with tolerance 1e-7 (rule 2), so its active cone rows sit at +-1e-9 .. 1e-8 for the contact redistribution QP
+    that follows; re-examining them at 1e-9 made the redistribution chase that round-off and FAIL (status 0) on this batch in
+    every lean build after round 3 changed the summation order of the wrench right-hand sides (instance 12 / 13, whichever way
+    the last bits fell).  Restatement and kernels now search the redistribution QP with the acceptance tolerance."""
+    from tests.test_task_reference import _setup
+
+    q, qd, fl, fs, ctime, traj0, traj1, fexp = _setup(16, 32)
+    assert np.abs(fexp).max() > 3.0
+    tau_r, wr_r, st_r, diag_r = _oracle(q, fl, fexp, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    assert st_r.all()
+    e = Emu(cases.URDF, cases.CONTACTS_2, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    for compact in (False, True, "pair"):
+        r = e.run(q, fl, fexp, compact=compact)
+        assert (r["status"] == 1).all(), compact
+        assert np.abs(r["tau"] - tau_r).max() < 1e-6, compact
+        assert r["diag"][:, 5].max() >= 20  # the level-1 QPs really are hard ones (20+ active-set steps somewhere)
