@@ -436,12 +436,33 @@ DWBC_DEV void qp_lane_consts(const Setup &su, int ci0, int ci1, QpLaneConst &qc)
     }
 }
 
+// norm of the lane's row of the contact redistribution QP (torque rows: NwJw[lane, :]; cone rows: c2 FN[row2, :] + sg FN[rowo, :]), with
+// the zero-row rule of the canon (a row below kQpZeroRow is the constraint 0 <= hi: its slack is taken as it is)
+template <int N, class S>
+DWBC_DEV void redis_row_norms(const real_t *L, int nlim, int ncone, int k, const QpLaneConst &qc, const real_t *FN, PL_REF(real_t, grn)) {
+    constexpr int M = N - 6, WLD = S::WLD;
+    DWBC_LANE_DECL;
+    LANES {
+        const bool tq = lane < M && nlim != 0, cn = lane >= M && lane - M < ncone;
+        const real_t *pa = tq ? L + S::NwJw + lane * 6 : FN + (cn ? LV(qc.row2) : 0) * WLD;
+        const real_t *pb = FN + (cn ? LV(qc.rowo) : 0) * WLD;
+        const real_t ca = tq ? real_t(1.0) : LV(qc.c2), cb = tq ? real_t(0.0) : LV(qc.sg);
+        real_t s2 = real_t(0.0);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const real_t v = j < k ? ca * pa[j] + cb * pb[j] : real_t(0.0);
+            s2 += v * v;
+        }
+        LV(grn) = s2 < kQpZeroRow * kQpZeroRow ? real_t(1.0) : sqrt(s2);
+    }
+}
+
 template <int N, int NB, int WS = 1>
 DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone, int ci0, int ci1, const real_t *P1, int ld1,
                                 int t1, const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1,
                                 const real_t *W2, int ldw2, const real_t *fv, const real_t *base, int tvars, int max_iter,
-                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr, const QpLaneConst *qcp = nullptr,
-                                real_t vtol = kQpTol) {
+                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm, const QpLaneConst *qcp,
+                                real_t vtol, PL_REF(real_t, sfin)) {
     constexpr int M = N - 6;
     DWBC_LANE_DECL;
     QpRows R;
@@ -452,50 +473,47 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
     QpLaneConst qloc;
     if (!qcp) qp_lane_consts<N>(su, ci0, ci1, qloc);  // (callers that solve one QP only)
     const QpLaneConst &qc = qcp ? *qcp : qloc;
+    // One straight-line path for every lane: entry j of a row is  ca * A_j + cb * B_j  with A / B taken from the left block (j < t1) or the
+    // right block, by UNCONDITIONAL loads (clamped addresses, the value masked afterwards) -- 24 independent LDS reads the scheduler can
+    // keep in flight together.  (Rounds 1-2 filled torque and cone lanes in two divergent branches with a load behind every `if (j < t1)`:
+    // each read waited out its own LDS round trip, 3.3 k cycles per QP in the stage table.)
+    //   torque row r (lane < M):  A = [P1 | P2][r, :], ca = 1, cb = 0                         (reference src/dwbc.cpp:1001-1016)
+    //   cone row (lane >= M):     A = [W1 | W2][row2, :], B = [W1 | W2][rowo, :], ca = -c2, cb = -sg  (reference src/dwbc.cpp:1041-1053, wbd.cpp:59-97)
     LANES {
+        const bool tq = lane < M && nlim != 0;
+        const bool cn = lane >= M && lane - M < ncone;
+        const int row2 = LV(qc.row2), rowo = LV(qc.rowo);
+        const real_t *pa1 = tq ? P1 + lane * ld1 : W1 + (cn ? row2 : 0) * ldw1;
+        const real_t *pa2 = tq ? P2 + lane * ld2 : W2 + (cn ? row2 : 0) * ldw2;
+        const real_t *pb1 = W1 + (cn ? rowo : 0) * ldw1;
+        const real_t *pb2 = W2 + (cn ? rowo : 0) * ldw2;
+        const real_t ca = tq ? real_t(1.0) : -LV(qc.c2), cb = tq ? real_t(0.0) : -LV(qc.sg);
+        real_t va[kQpN], vb[kQpN];
 #pragma unroll
-        for (int j = 0; j < kQpN; j++) LV(R.g)[j] = real_t(0.0);
-        LV(R.hi) = DWBC_QP_INF;
-        LV(R.lo) = DWBC_QP_INF;
-        LV(R.id_hi) = -1;
-        LV(R.id_lo) = -1;
-        if (lane < M) {
-            if (nlim) {
-#pragma unroll
-                for (int j = 0; j < kQpN; j++) {
-                    real_t v = real_t(0.0);
-                    if (j < t1) v = P1[lane * ld1 + j];
-                    else if (j < nv) v = P2[lane * ld2 + (j - t1)] * s2;
-                    LV(R.g)[j] = v;
-                }
-                LV(R.hi) = LV(qc.taul) - base[lane];
-                LV(R.lo) = LV(qc.taul) + base[lane];
-                LV(R.id_hi) = lane;
-                LV(R.id_lo) = M + lane;
-            }
-        } else if (lane - M < ncone) {
-            // cone row r10 of contact a acts on the local wrench w as  c2 * w[2] + sg * w[oi]   (reference src/wbd.cpp:59-97)
-            const int rr = lane - M;
-            const real_t c2 = LV(qc.c2), sg = LV(qc.sg);
-            const int row2 = LV(qc.row2), rowo = LV(qc.rowo);
-#pragma unroll
-            for (int j = 0; j < kQpN; j++) {
-                real_t v = real_t(0.0);
-                if (j < t1) v = c2 * W1[row2 * ldw1 + j] + sg * W1[rowo * ldw1 + j];
-                else if (j < nv) v = (c2 * W2[row2 * ldw2 + (j - t1)] + sg * W2[rowo * ldw2 + (j - t1)]) * s2;
-                LV(R.g)[j] = -v;
-            }
-            LV(R.hi) = c2 * fv[row2] + sg * fv[rowo];
-            LV(R.id_hi) = nlim + rr;
+        for (int j = 0; j < kQpN; j++) {
+            const bool f1 = j < t1;
+            const int j2 = j - t1 > 0 ? (j - t1 < (t2 > 0 ? t2 : 1) ? j - t1 : 0) : 0;  // clamped column of the right block
+            const int j1 = f1 ? j : 0;
+            va[j] = f1 ? pa1[j1] : pa2[j2];
+            vb[j] = f1 ? pb1[j1] : pb2[j2];
         }
+#pragma unroll
+        for (int j = 0; j < kQpN; j++) {
+            const real_t v = (ca * va[j] + cb * vb[j]) * (j < t1 ? real_t(1.0) : s2);
+            LV(R.g)[j] = ((tq || cn) && j < nv) ? v : real_t(0.0);
+        }
+        LV(R.hi) = tq ? LV(qc.taul) - base[tq ? lane : 0] : (cn ? -(ca * fv[row2] + cb * fv[rowo]) : DWBC_QP_INF);
+        LV(R.lo) = tq ? LV(qc.taul) + base[tq ? lane : 0] : DWBC_QP_INF;
+        LV(R.id_hi) = tq ? lane : (cn ? nlim + (lane - M) : -1);
+        LV(R.id_lo) = tq ? M + lane : -1;
     }
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
     const long long t_fill1_ = clock64();
 #endif
     // the solver is instantiated for 12, 9 and 6 variables (6 + 6, 3 + 6 and the 6 contact-null variables of the redistribution)
-    if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
-    else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
-    else qp_solve_wave<WS, 12>(R, nv, tvars, max_iter, res, Vlds, warm, vtol);
+    if (nv <= 6) qp_solve_wave<WS, 6>(R, nv, tvars, max_iter, res, Vlds, warm, vtol, sfin);
+    else if (nv <= 9) qp_solve_wave<WS, 9>(R, nv, tvars, max_iter, res, Vlds, warm, vtol, sfin);
+    else qp_solve_wave<WS, 12>(R, nv, tvars, max_iter, res, Vlds, warm, vtol, sfin);
     LANES {
         if (lane < kQpN) xlds[lane] = pick12(res.x, lane);
     }
@@ -503,6 +521,17 @@ DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone,
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
     res.tm[8] = t_fill1_ - t_fill0_;
 #endif
+}
+
+// (callers that do not look at the final slacks: the reduced-dynamics cycle)
+template <int N, int NB, int WS = 1>
+DWBC_DEV void qp_rows_and_solve(const Setup &su, real_t *L, int nlim, int ncone, int ci0, int ci1, const real_t *P1, int ld1,
+                                int t1, const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1,
+                                const real_t *W2, int ldw2, const real_t *fv, const real_t *base, int tvars, int max_iter,
+                                QpResult &res, real_t *Vlds, real_t *xlds, const int *warm = nullptr) {
+    PL(real_t, sfin_unused);
+    qp_rows_and_solve<N, NB, WS>(su, L, nlim, ncone, ci0, ci1, P1, ld1, t1, P2, ld2, t2, s2, W1, ldw1, W2, ldw2, fv, base, tvars, max_iter, res, Vlds,
+                                 xlds, warm, nullptr, kQpTol, sfin_unused);
 }
 
 }  // namespace dwbc

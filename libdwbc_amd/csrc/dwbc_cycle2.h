@@ -112,6 +112,8 @@ struct Lds2 {
     static constexpr int cod_Q = c_s1, cod_v = c_s1 + T * T, cod_G = c_s2 + T * T, cod_T = c_s2 + 2 * T * T;  // scratch of pinv_cod_small
     static constexpr int Pt = 0, c_Gi = 0;                     // (compact map only)
     static constexpr int xl(int lv) { return Xl + lv * M * T; }  // X = J_kt Lambda of level lv < NLV - 1
+    static constexpr int MS = M;                               // row stride of T1r / c_Q (the compact maps pad it to an even number)
+    static constexpr bool batch_reads = true;                  // row products issue their LDS reads in hand-made batches (lds_rows_dot)
 };
 
 // The COMPACT map of the lean, register-capped kernel (`_v2`, EXTRAS = false; batches beyond four instances per CU): the same
@@ -172,9 +174,14 @@ struct Lds3 {
     static constexpr int c_VG = c_Vb;                          // (not stored in this map)
     static constexpr int RG = c_Gi + K * K;
     static constexpr int c_Lt = RG;                            // levels x T x T
-    static constexpr int T1r = c_Lt + NL2 * T * T;             // (levels-1) x (T x M)
-    static constexpr int c_Q = T1r + (NL2 - 1) * T * M;        // T x M
-    static constexpr int RX = c_Q + T * M;                     // phase-local scratch
+    static constexpr int MS = ev(M);                           // row stride of T1r / c_Q: even, so that every row is 16-byte aligned (lds_rows_dot)
+    // the hand-batched LDS reads pin 34 .. 68 VGPRs at once: inside the 256-register cap of this kernel the allocator then sends the
+    // whole W^+ column to scratch around stage 3a (1 076 bytes, 19.4 -> 15.3 M cycles/s at B = 8192, profiles/r03i).  With two waves per
+    // SIMD the other wave covers most of the LDS latency anyway: the compact kernel keeps the compiler-scheduled loops.
+    static constexpr bool batch_reads = false;
+    static constexpr int T1r = c_Lt + NL2 * T * T;             // (levels-1) x (T x MS)
+    static constexpr int c_Q = T1r + (NL2 - 1) * T * MS;       // T x MS
+    static constexpr int RX = c_Q + T * MS;                    // phase-local scratch
     static constexpr int rx_size = max2(max2(C * K, 64) + C * C, 64 + 3 * T * T + 8);
     static constexpr int RXend = RX + ev(rx_size);
     static constexpr int Xl = RXend;                           // X of levels 1 .. NLV-2 (level 0: U)
@@ -388,6 +395,83 @@ __device__ __forceinline__ void lds_col_wait(dwbc_d2v (&c)[NP]) {
         if constexpr (NP > 1) lds_col_pin<1, NP>(c);
     }
 }
+#endif
+
+// out[r] (MODE 0: =, MODE 1: -=)  sum_i A[r][i] x[i]  for NR rows of an LDS-resident matrix A (row stride RS, uniform address) against the
+// lane's own register column x -- the "uniform operand . own column" product of this design.  Left to the compiler, every
+// ds_read_b128 of such a loop is followed by its own s_waitcnt (the disassembly of the J_kt rows: 81 reads, 81 waits, one LDS round
+// trip each: 9.8 k cycles for 198 FMAs); here the reads of CH rows are issued back to back and waited for once, as the W^+ sweep does
+// for its pivot column.  Needs 16-byte-aligned rows (even RS, aligned base); anything else takes the plain loop.
+template <int NR, int NC, int RS, int CH, int MODE, bool ALIGNED = true>
+DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out)[NR]) {
+#if !defined(DWBC_HOST_EMU)
+    if constexpr (sizeof(real_t) == 8 && RS % 2 == 0 && ALIGNED) {
+        constexpr int NP = (NC + 1) / 2;  // reads per row (the last one may fetch one element beyond NC: it stays inside the row's stride
+                                          // when NC < RS, or belongs to the next row and is ignored)
+        const unsigned a0 = (unsigned)(size_t)A;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r0 = 0; r0 < NR; r0 += CH) {
+            dwbc_d2v c[CH][NP];
+#pragma unroll
+            for (int q = 0; q < CH; q++)
+                if (r0 + q < NR) lds_col_issue<0, NP>(c[q], a0 + (unsigned)((r0 + q) * RS * 8));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < CH; q++)
+                if (r0 + q < NR) lds_col_pin<0, NP>(c[q]);
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                if (r0 + q < NR) {
+                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+#pragma unroll
+                    for (int i = 0; i < NC; i++) a4[i & 3] += c[q][i / 2][i & 1] * x[i];
+                    const real_t d = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                    if (MODE == 0) out[r0 + q] = d; else out[r0 + q] -= d;
+                }
+            }
+        }
+        return;
+    }
+#endif
+    for (int r = 0; r < NR; r++) {
+        real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+#pragma unroll
+        for (int i = 0; i < NC; i++) a4[i & 3] += A[r * RS + i] * x[i];
+        const real_t d = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        if (MODE == 0) out[r] = d; else out[r] -= d;
+    }
+}
+
+// acc[p] += sum_{r < NR} A[r][p] * x[r]  for NR consecutive rows (NC entries each, row stride RS) of an LDS-resident matrix: the
+// "own column . uniform operand" product with the rows as the reduction index (Y = J_C A^-1: A = rows of J_C^T, x = the lane's
+// entries of its A^-1 column).  All NR * NC / 2 reads are issued back to back and waited for once (see lds_rows_dot).
+template <int NR, int NC, int RS, bool ALIGNED = true>
+DWBC_WDEV void lds_rows_axpy(const real_t *A, const real_t (&x)[NR], real_t (&acc)[NC]) {
+#if !defined(DWBC_HOST_EMU)
+    if constexpr (sizeof(real_t) == 8 && RS % 2 == 0 && NC % 2 == 0 && ALIGNED) {
+        constexpr int NP = NC / 2;
+        const unsigned a0 = (unsigned)(size_t)A;
+        dwbc_d2v c[NR][NP];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < NR; r++) lds_col_issue<0, NP>(c[r], a0 + (unsigned)(r * RS * 8));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < NR; r++) lds_col_pin<0, NP>(c[r]);
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int p = 0; p < NC; p++) acc[p] += c[r][p / 2][p & 1] * x[r];
+        return;
+    }
+#endif
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int p = 0; p < NC; p++) acc[p] += A[r * RS + p] * x[r];
+}
+
+#if !defined(DWBC_HOST_EMU)
 template <int NN, int K>
 __device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
     constexpr int NP = (NN + 1) / 2;
@@ -850,7 +934,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const int t = kExtras ? su.t_dof[lv] : TTL;
         real_t *Jtt = L + S::c_Jt, *T1 = L + S::c_T1, *Lt = L + S::c_Lt + lv * T * T;  // Jtt: N x T (J_task transposed)
         // compact map: T1 holds the six base columns only (T x 6); the joint columns go straight to T1r of the level / c_Q of the last
-        real_t *T1x = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
+        real_t *T1x = (lv < NLV - 1) ? L + S::T1r + lv * T * S::MS : L + S::c_Q;
         const unsigned long long tm = su.t_dofmask[lv];
         DWBC_SYNC();
         for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = real_t(0.0);
@@ -904,10 +988,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 for (int r = 0; r < TT; r++) {
                     if constexpr (S::compact) {
                         if (lane < 6) T1[r * 6 + lane] = tc_[r];
-                        else if (lane < N) T1x[r * M + (lane - 6)] = tc_[r];
+                        else if (lane < N) T1x[r * S::MS + (lane - 6)] = tc_[r];
                     } else {
                         if (lane < N) T1[r * N + lane] = tc_[r];
-                        if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * M + r * M + (lane - 6)] = tc_[r];
+                        if (lv < NLV - 1 && lane >= 6 && lane < N) L[S::T1r + lv * T * S::MS + r * S::MS + (lane - 6)] = tc_[r];
                     }
                 }
             }
@@ -920,7 +1004,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             real_t acc = real_t(0.0);
 #pragma unroll
             for (int c = 0; c < N; c++)
-                if ((tm >> c) & 1) acc += (S::compact ? (c < 6 ? T1[i * 6 + c] : T1x[i * M + (c < 6 ? 0 : c - 6)]) : T1[i * N + c]) * Jtt[c * T + j];
+                if ((tm >> c) & 1) acc += (S::compact ? (c < 6 ? T1[i * 6 + c] : T1x[i * S::MS + (c < 6 ? 0 : c - 6)]) : T1[i * N + c]) * Jtt[c * T + j];
             L[S::c_s2 + idx] = acc;
         }
         if (lv == 0) DWBC_STAMP(13);  // (diagnostic) level-0 J_t and T1 done
@@ -943,7 +1027,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         if (lv == 0) DWBC_FSTAMP(16);  // level 0: Lambda_task
         // Q = (Lambda J A^-1 N_c)[:,6:] is formed later from T1r; the last level keeps its T1r in the Q slot
         if (!S::compact && lv == NLV - 1)
-            for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + idx] = T1[(idx / M) * N + 6 + idx % M];
+            for (int idx = th.tid; idx < t * M; idx += NT) L[S::c_Q + (idx / M) * S::MS + idx % M] = T1[(idx / M) * N + 6 + idx % M];
         if (dump) {
             for (int idx = th.tid; idx < t * N; idx += NT) dump[dl.J_task + lv * T * N + idx] = Jtt[(idx % N) * T + idx / N];
             for (int idx = th.tid; idx < t * t; idx += NT) dump[dl.Lambda_task + lv * T * T + idx] = Lt[idx];
@@ -989,17 +1073,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
 #pragma unroll
                     for (int a = 0; a < 6; a++) gv[b] += L[S::c_Gi + b * 6 + a] * LV(vbr)[a];
             }
+            // column `lane` of the projector: P = Vb G^-1 Vb^T with gv = G^-1 (row `lane` of Vb) on the compact map, VG Vb^T otherwise
+            if constexpr (S::compact) lds_rows_dot<M, 6, 6, 3, 0, S::batch_reads && S::c_Vb % 2 == 0>(Vb, gv, LV(pc));
+            else lds_rows_dot<M, 6, 6, 3, 0, S::batch_reads && S::c_VG % 2 == 0>(VG, LV(vbr), LV(pc));
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                real_t pij = real_t(0.0);
-                if constexpr (S::compact) {  // P = Vb G^-1 Vb^T with gv = G^-1 (row `lane` of Vb)
-#pragma unroll
-                    for (int a = 0; a < 6; a++) pij += Vb[i * 6 + a] * gv[a];
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
-                }
-                LV(pc)[i] = pij;
+                const real_t pij = LV(pc)[i];
                 LV(w)[i] += alpha * pij;
                 dp = (i == lw) ? pij : dp;
             }
@@ -1027,10 +1106,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];
         }
         // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
-        real_t acc = real_t(0.0);
-#pragma unroll
-        for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
-        if (lane < M) L[S::tg + lane] = acc;
+        real_t tg1[1];
+        lds_rows_dot<1, M, 2 * ((M + 1) / 2), 1, 0, S::batch_reads && S::c_vec % 2 == 0>(L + S::c_vec + 6, LV(w), tg1);
+        if (lane < M) L[S::tg + lane] = tg1[0];
     }
     if (dump) {
         LANES {
@@ -1056,7 +1134,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const int t = kExtras ? su.t_dof[lv] : TTL;
         const real_t *Lt = L + S::c_Lt + lv * T * T;
         const FastDiv fdt(t);
-        const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * M : L + S::c_Q;
+        const real_t *T1rl = (lv < NLV - 1) ? L + S::T1r + lv * T * S::MS : L + S::c_Q;
         real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;  // (Lds2: c_Jt/c_T1 are free again)
         real_t *Ul = L + S::U + lv * M * T;
         real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
@@ -1069,12 +1147,10 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             const bool exact = t == TT;
             LANES {
                 real_t tw[TT];
+                lds_rows_dot<TT, M, S::MS, 1, 0, S::batch_reads && (S::T1r % 2 == 0) && (S::c_Q % 2 == 0)>(T1rl, LV(w), tw);  // (T1r W^+)[r][lane] = J_kt[lane][r]
 #pragma unroll
                 for (int r = 0; r < TT; r++) {
-                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-                    for (int i = 0; i < M; i++) a4[i & 3] += T1rl[r * M + i] * LV(w)[i];
-                    tw[r] = (exact || r < t) ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : real_t(0.0);
+                    tw[r] = (exact || r < t) ? tw[r] : real_t(0.0);
                     if (dump && lane < M && r < t) dump[dl.J_kt + lv * M * T + lane * t + r] = tw[r];
                 }
 #pragma unroll
@@ -1103,7 +1179,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             real_t acc = real_t(0.0);
             if (i < t)
                 _Pragma("unroll 8")
-                for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * M + j];
+                for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * S::MS + j];
             Q[idx] = acc;
         }
         DWBC_SYNC();
@@ -1172,12 +1248,12 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1r[pl]
             const int tp = su.t_dof[pl];
-            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1r + pl * T * M;
+            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1r + pl * T * S::MS;
             for (int idx = th.tid; idx < tp * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
                 real_t acc = real_t(0.0);
                 _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
+                for (int c = 0; c < M; c++) acc += Yp[i * S::MS + c] * Ul[c * T + j];
                 L[S::c_Z + idx] = acc;
             }
             DWBC_SYNC();
@@ -1208,7 +1284,11 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     constexpr int WLD = S::WLD;
     const int colN = 1 + su.fstar_total;  // first column of the contact-null block of the wrench maps
     QpLaneConst qc;
-    if (kExtras ? io.hqp != 0 : true) {
+    PL(real_t, sfin);  // slack of the lane's QP row at the point the last QP returned (qp_solve_wave)
+    PL(real_t, grn);   // norm of the lane's row of the contact redistribution QP
+    bool skip_redis = false;
+    const bool wm_ok = kExtras ? io.hqp != 0 : true;  // the wrench maps exist (hqp = true)
+    if (wm_ok) {
         qp_lane_consts<N>(su, act_c[0], act_c[1], qc);
         wrench_maps<N, NT, S>(th, su, L, JbT, cd, k, WM);
         // wacc = wrench of the torque committed so far (gravity torque to begin with) minus A_rot P_C, contact-local frames
@@ -1225,6 +1305,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         DWBC_FSTAMP(43);  // wrench maps of the cascade
+        redis_row_norms<N, S>(L, nlim, ncone, k, qc, WM + colN, grn);
     }
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
@@ -1234,6 +1315,15 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
             break;
         }
         if (!is_task && k == 0) break;      // nothing to redistribute (dwbc.cpp:1562-1567)
+        if (!is_task && skip_redis) {  // every row of the redistribution QP holds at c = 0 (seen from the last task QP's final slacks): no step
+            if (diag && th.tid == 0) {
+                diag[DG_QP_ITER + kMaxLevels] = 0;
+                diag[DG_QP_NACT + kMaxLevels] = 0;
+                if (EXTRAS)
+                    for (int a = 0; a < kQpLd; a++) diag[DG_QP_ACT + kMaxLevels * kQpLd + a] = -1;
+            }
+            break;
+        }
         const int t = is_task ? su.t_dof[qi] : 0;
         const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
@@ -1252,18 +1342,23 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // torque the level starts from (dwbc.cpp:1001-1016) and its contact wrench minus P_C in the contact frames, both from
         // what is already there: fv = wacc + F_l f*_l (task level) or wacc + F_N contact_qp_ (redistribution)
-        for (int i = th.tid; i < M + C; i += NT) {
-            if (i < M) {
-                real_t acc = L[S::tg + i] + L[S::tt + i];
-                if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
-                else acc += L[S::tc + i];
-                base[i] = acc;
-            } else {
-                const int r = i - M;
-                real_t acc = wacc[r];
-                if (is_task) { for (int j = 0; j < t; j++) acc += WM[r * WLD + colL + j] * fs[j]; }
-                else { for (int j = 0; j < k; j++) acc += WM[r * WLD + colN + j] * clast[j]; }
-                fv[r] = acc;
+        {
+            // straight-line: six unconditional reads per lane, the entries beyond t (or k) masked afterwards -- a loop with a run-time
+            // trip count puts every read behind its own wait
+            real_t f6[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) f6[j] = is_task ? (j < t ? fs[j] : real_t(0.0)) : (j < k ? clast[j] : real_t(0.0));
+            for (int i = th.tid; i < M + C; i += NT) {
+                const bool tq = i < M;
+                const int r = tq ? 0 : i - M;
+                const real_t *row = tq ? Ul + i * T : WM + r * WLD + (is_task ? colL : colN);
+                real_t u6[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) u6[j] = row[j];
+                real_t acc = tq ? L[S::tg + i] + L[S::tt + i] + (is_task ? real_t(0.0) : L[S::tc + i]) : wacc[r];
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc += ((is_task ? j < t : (j < k && !tq)) ? u6[j] * f6[j] : real_t(0.0));
+                if (tq) base[i] = acc; else fv[r] = acc;
             }
         }
         DWBC_SYNC();
@@ -1281,7 +1376,7 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                                      is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
                                      is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x,
                                      (EXTRAS && io.warm && diag) ? diag + DG_QP_ACT + (is_task ? qi : kMaxLevels) * kQpLd : nullptr, &qc,
-                                     is_task ? kQpTol : kQpFeasTol);
+                                     is_task ? kQpTol : kQpFeasTol, sfin);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
@@ -1299,29 +1394,55 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
         const real_t *x = L + S::qp_x;
         if (is_task) {
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }  // cascade aborts (dwbc.cpp:836,1119)
-            for (int i = th.tid; i < M; i += NT) {
-                real_t acc = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
-                L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
-                real_t c = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[t + j];
-                L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+            {
+                real_t fx[6], xc[6];  // f* + f*_qp of the level, contact_qp_ (uniform), entries beyond t / k zero
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    fx[j] = j < t ? fs[j] + x[j] : real_t(0.0);
+                    xc[j] = j < k ? x[t + j] : real_t(0.0);
+                }
+                for (int i = th.tid; i < M + C; i += NT) {
+                    const bool tq = i < M;
+                    const int r = tq ? 0 : i - M;
+                    const real_t *row = tq ? Ul + i * T : WM + r * WLD + colL;
+                    real_t u6[6], n6[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { u6[j] = row[j]; n6[j] = L[S::NwJw + (tq ? i : 0) * 6 + j]; }
+                    real_t acc = real_t(0.0), c = real_t(0.0);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        acc += j < t ? u6[j] * fx[j] : real_t(0.0);
+                        c += j < k ? n6[j] * xc[j] : real_t(0.0);
+                    }
+                    if (tq) {
+                        L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
+                        L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+                    } else {
+                        wacc[r] += acc;       // the wrench of what this level commits
+                        if (r < S::K) clast[r] = r < k ? x[t + r] : real_t(0.0);  // contact_qp_ for the redistribution's start
+                    }
+                }
             }
-            for (int i = th.tid; i < C; i += NT) {  // the wrench of what this level commits; contact_qp_ for the redistribution's start
-                real_t acc = wacc[i];
-                _Pragma("unroll 8")
-                for (int j = 0; j < t; j++) acc += WM[i * WLD + colL + j] * (fs[j] + x[j]);
-                wacc[i] = acc;
-                if (i < S::K) clast[i] = i < k ? x[t + i] : real_t(0.0);
+            if (qi == su.n_levels - 1 && k > 0 && (kExtras ? !io.warm : true)) {
+                // The rows of the redistribution QP (dwbc.cpp:1458-1517) are the rows of this level's QP seen at c = 0 with the total
+                // torque on the right-hand side, so its first look at them -- slack / |row| against the tolerance of canon rule 5 --
+                // can be taken from the slacks this QP ended with.  Nothing violated: the redistribution would return c = 0 after
+                // filling and normalising its 53 rows (6 k cycles in the stage table); it is skipped.
+                LANES {
+                    const bool tq = lane < M && nlim != 0, cn = lane >= M && lane - M < ncone;
+                    LV(grn) = (tq || cn) ? LV(sfin) / LV(grn) : DWBC_QP_INF;  // (grn is not needed again)
+                }
+                int wl_;
+                WAVE_ARGMIN_F32(grn, wl_);
+                skip_redis = !(BCAST(grn, wl_) < -kQpFeasTol);
             }
             if (dump) {
                 for (int j = th.tid; j < t; j += NT) dump[dl.fstar_qp + qi * T + j] = x[j];
                 for (int j = th.tid; j < k; j += NT) dump[dl.contact_qp + qi * (C - 6) + j] = x[t + j];
             }
         } else if (qres.status) {
-            for (int i = th.tid; i < M; i += NT) {
+            for (int i = th.tid; i < M + S::K; i += NT) {
+                if (i >= M) { clast[i - M] += (i - M < k) ? x[i - M] : real_t(0.0); continue; }  // contact_qp_ + redistribution: what torque_contact_ stands for
                 real_t c = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[j];
@@ -1331,7 +1452,9 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
                 for (int j = th.tid; j < k; j += NT) dump[dl.cf_redis + j] = x[j];
         } else {
             st_redis = 0;
-            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);  // dwbc.cpp:1553-1559
+            for (int i = th.tid; i < M + S::K; i += NT) {
+                if (i < M) L[S::tc + i] = real_t(0.0); else clast[i - M] = real_t(0.0);
+            }  // dwbc.cpp:1553-1559
         }
         DWBC_SYNC();
     }
@@ -1345,9 +1468,25 @@ DWBC_DEV void cycle_instance_v2(Thr th, const Setup &su, const BatchIO &io, int 
     io_t *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = too_many ? real_t(0.0) : L[S::tg + i];
     io_t *wr = io.wrench + (size_t)inst * 12;
+    // getContactForce(tau_total) = Jbar[:, 6:] tau - P_C (wbd.cpp:268-271).  In the contact frames that is the running wrench of the
+    // cascade plus the contact-null part (wacc + F_N (contact_qp_ + redistribution): every term a column combination of the wrench
+    // maps); rotated back with blockdiag(R_a, R_a).  (Rounds 1-2 multiplied Jbar with the summed torque again: 33 x 4 LDS reads per lane.)
     for (int i = th.tid; i < 12; i += NT) {
         real_t acc = real_t(0.0);
-        if (i < cd && !too_many) {
+        if (i < cd && !too_many && wm_ok) {
+            const int a = i / 6, h = (i % 6) / 3, y = i % 3;
+            const real_t *R = L + S::Rc + a * 9;
+            real_t loc[3];
+#pragma unroll
+            for (int x_ = 0; x_ < 3; x_++) {
+                const int r = 6 * a + 3 * h + x_;
+                real_t v = wacc[r];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += (j < k) ? WM[r * WLD + colN + j] * clast[j] : real_t(0.0);
+                loc[x_] = v;
+            }
+            acc = R[y * 3] * loc[0] + R[y * 3 + 1] * loc[1] + R[y * 3 + 2] * loc[2];
+        } else if (i < cd && !too_many) {
             acc = -L[S::PC + i];
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);

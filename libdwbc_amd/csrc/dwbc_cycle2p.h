@@ -37,6 +37,7 @@ namespace dwbc {
 template <int N, int NB, int NLV>
 struct Lds4 {
     static constexpr bool compact = true;   // (the code paths shared with Lds3: T1 split into base columns + M-wide home, G^-1 kept, ...)
+    static constexpr bool batch_reads = true;
     static constexpr int M = N - 6;
     static constexpr int C = 6 * kMaxActiveContacts;
     static constexpr int K = C - 6;
@@ -70,8 +71,9 @@ struct Lds4 {
     static constexpr int NwJw = JbT + C * N;
     static constexpr int NL2 = NLV < 2 ? 2 : NLV;              // (the U / T1x regions also host the staged mass matrix)
     static constexpr int U = NwJw + M * K;                     // levels x (M x T)
-    static constexpr int T1x = U + NL2 * M * T;                // levels x (T x M): joint columns of T1 of every level
-    static constexpr int c_T1 = T1x + NL2 * T * M;             // levels x (T x 6): base columns of T1
+    static constexpr int MS = ev(M);                           // row stride of T1x: even, so that every row is 16-byte aligned (lds_rows_dot)
+    static constexpr int T1x = U + NL2 * M * T;                // levels x (T x MS): joint columns of T1 of every level
+    static constexpr int c_T1 = T1x + NL2 * T * MS;            // levels x (T x 6): base columns of T1
     static constexpr int c_Lt = c_T1 + NLV * T * 6;            // levels x T x T
     static constexpr int Jtt = c_Lt + NLV * T * T;             // levels x (N x T): J_task transposed, helper phase 1 -> main phase 3, helper phase 4
     static constexpr int c_Vb = Jtt + NLV * N * T;             // M x K
@@ -132,6 +134,11 @@ struct Lds4 {
     } while (0)
 #else
 #define DWBC_PAIR_BARRIER(i) __syncthreads()
+#endif
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+#define DWBC_PSTAMP(i) do { DWBC_SYNC(); if (diag && th.tid == 0) diag[DG_FTIME + (i)] = (int)(clock64() - t_start_); } while (0)
+#else
+#define DWBC_PSTAMP(i) ((void)0)
 #endif
 
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
@@ -449,19 +456,14 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             real_t yc[C];
 #pragma unroll
             for (int p = 0; p < C; p++) yc[p] = real_t(0.0);
+            // three columns of J_C (rows of its transpose) at a time, both contacts together: the entries of the contact that a dof
+            // does not move are exact zeros, and one batch of 18 reads beats two half-filled ones behind their own waits
+            static_assert(N % 3 == 0, "column blocks of three");
 #pragma unroll
             for (int ib = 0; ib < N; ib += 3) {
-                if ((cm0 >> ib) & 7) {
-#pragma unroll
-                    for (int i = ib; i < ib + 3 && i < N; i++)
-#pragma unroll
-                        for (int p = 0; p < 6; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
-                }
-                if ((cm1 >> ib) & 7) {
-#pragma unroll
-                    for (int i = ib; i < ib + 3 && i < N; i++)
-#pragma unroll
-                        for (int p = 6; p < C; p++) yc[p] += JCt[i * C + p] * LV(s)[i];
+                if (((cm0 | cm1) >> ib) & 7) {
+                    const real_t x3[3] = {LV(s)[ib], LV(s)[ib + 1], LV(s)[ib + 2]};
+                    lds_rows_axpy<3, C, C, S::c_JC % 2 == 0>(JCt + ib * C, x3, yc);
                 }
             }
             if (lane < N) {
@@ -513,13 +515,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             const int col = lane < N ? lane : 0;
 #pragma unroll
             for (int p = 0; p < C; p++) LV(yck)[p] = Yt[col * C + p];
-#pragma unroll
-            for (int p = 0; p < C; p++) {
-                real_t acc = real_t(0.0);
-#pragma unroll
-                for (int p2 = 0; p2 < C; p2++) acc += Lam[p * C + p2] * LV(yck)[p2];
-                LV(jbk)[p] = acc;
-            }
+            lds_rows_dot<C, C, C, 4, 0, S::c_Lam % 2 == 0>(Lam, LV(yck), LV(jbk));  // column `lane` of Jbar^T = Lambda_c Y
         }
         DWBC_SYNC();  // every lane has read what it needs of Y; J_C is dead
         LANES {
@@ -538,26 +534,18 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
 #pragma unroll
             for (int p = 0; p < C; p++) dsub += LV(yck)[p] * LV(jbk)[p];
             LV(dg) -= dsub;
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                real_t a0 = real_t(0.0), a1 = real_t(0.0);
-#pragma unroll
-                for (int p = 0; p < C; p += 2) { a0 += Yt[i * C + p] * LV(jbk)[p]; a1 += Yt[i * C + p + 1] * LV(jbk)[p + 1]; }
-                LV(s)[i] -= a0 + a1;
-            }
+            lds_rows_dot<N, C, C, 4, 1>(Yt, LV(jbk), LV(s));  // s[i] -= Y^T[i, :] . Jbar^T[:, lane]
         }
         DWBC_SYNC();
         LANES {
-            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-            for (int i = 0; i < N; i++) a4[i & 3] += LV(s)[i] * L[S::G + i];
-            const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-            if (lane < N) L[S::c_vec + lane] = acc;
+            real_t gv1[1];
+            lds_rows_dot<1, N, 2 * ((N + 1) / 2), 1, 0>(L + S::G, LV(s), gv1);  // gravity pre-vector (A^-1 N_c G)[lane]
+            if (lane < N) L[S::c_vec + lane] = gv1[0];
         }
         mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
         for (int lv = 0; lv < su.n_levels; lv++) {
             const real_t *Jtt = L + S::Jtt + lv * N * T;
-            real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * M;
+            real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * S::MS;
             const unsigned long long tm = su.t_dofmask[lv];
             auto t1_rows = [&](auto ttc) {
                 constexpr int TT = decltype(ttc)::value;
@@ -577,7 +565,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
 #pragma unroll
                     for (int r = 0; r < TT; r++) {
                         if (lane < 6) T1[r * 6 + lane] = tc_[r];
-                        else if (lane < N) T1x[r * M + (lane - 6)] = tc_[r];
+                        else if (lane < N) T1x[r * S::MS + (lane - 6)] = tc_[r];
                     }
                 }
             };
@@ -638,12 +626,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             if (k > 0) {
                 DWBC_LANE_OPAQUE(lw);
                 real_t dp = real_t(0.0);
+                lds_rows_dot<M, 6, 6, 6, 0>(VG, LV(vbr), LV(pc));  // column `lane` of P = VG Vb^T
 #pragma unroll
                 for (int i = 0; i < M; i++) {
-                    real_t pij = real_t(0.0);
-#pragma unroll
-                    for (int a = 0; a < 6; a++) pij += VG[i * 6 + a] * LV(vbr)[a];
-                    LV(pc)[i] = pij;
+                    const real_t pij = LV(pc)[i];
                     LV(w)[i] += alpha * pij;
                     dp = (i == lw) ? pij : dp;
                 }
@@ -663,10 +649,9 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
 #pragma unroll
                 for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];
             }
-            real_t acc = real_t(0.0);  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
-#pragma unroll
-            for (int i = 0; i < M; i++) acc += LV(w)[i] * L[S::c_vec + 6 + i];
-            if (lane < M) L[S::tg + lane] = acc;
+            real_t tg1[1];  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
+            lds_rows_dot<1, M, 2 * ((M + 1) / 2), 1, 0>(L + S::c_vec + 6, LV(w), tg1);
+            if (lane < M) L[S::tg + lane] = tg1[0];
         }
         DWBC_SYNC();
     }
@@ -676,7 +661,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         for (int lv = 0; lv < su.n_levels; lv++) {
             const int t = su.t_dof[lv];
             const real_t *Jtt = L + S::Jtt + lv * N * T;
-            const real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * M;
+            const real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * S::MS;
             real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs;
             const unsigned long long tm = su.t_dofmask[lv];
             DWBC_SYNC();
@@ -685,7 +670,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 real_t acc = real_t(0.0);
 #pragma unroll
                 for (int c = 0; c < N; c++)
-                    if ((tm >> c) & 1) acc += (c < 6 ? T1[i * 6 + c] : T1x[i * M + (c < 6 ? 0 : c - 6)]) * Jtt[c * T + j];
+                    if ((tm >> c) & 1) acc += (c < 6 ? T1[i * 6 + c] : T1x[i * S::MS + (c < 6 ? 0 : c - 6)]) * Jtt[c * T + j];
                 Li[idx] = acc;
             }
             const int ok_lt = spd_inverse_small(Li, t, t, Lt, t, L + S::hs + 144);
@@ -713,7 +698,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         const int t = TTL;
         const real_t *Lt = L + S::c_Lt + lv * T * T;
         const FastDiv fdt(t);
-        const real_t *T1rl = L + S::T1x + lv * T * M;
+        const real_t *T1rl = L + S::T1x + lv * T * S::MS;
         real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;
         real_t *Ul = L + S::U + lv * M * T;
         real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
@@ -723,13 +708,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (fast) {
             LANES {
                 real_t tw[TTL];
-#pragma unroll
-                for (int r = 0; r < TTL; r++) {
-                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-                    for (int i = 0; i < M; i++) a4[i & 3] += T1rl[r * M + i] * LV(w)[i];
-                    tw[r] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                }
+                lds_rows_dot<TTL, M, S::MS, 1, 0>(T1rl, LV(w), tw);  // (T1r W^+)[r][lane] = J_kt[lane][r]
 #pragma unroll
                 for (int r3 = 0; r3 < TTL; r3++) {
                     real_t acc = real_t(0.0);
@@ -746,7 +725,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             for (int idx = th.tid; idx < t * M; idx += NT) {
                 const int i = idx / M, j = idx - i * M;
                 real_t acc = real_t(0.0);
-                for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * M + j];
+                for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * S::MS + j];
                 Q[idx] = acc;
             }
             DWBC_SYNC();
@@ -792,14 +771,15 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             }
         }
         DWBC_SYNC();
+        DWBC_PSTAMP(16 + 2 * lv);  // rows of J_kt / X of level lv written
         for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1x[pl]
             const int tp = su.t_dof[pl];
-            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1x + pl * T * M;
+            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1x + pl * T * S::MS;
             for (int idx = th.tid; idx < tp * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
                 real_t acc = real_t(0.0);
                 _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) acc += Yp[i * M + c] * Ul[c * T + j];
+                for (int c = 0; c < M; c++) acc += Yp[i * S::MS + c] * Ul[c * T + j];
                 L[S::c_Z + idx] = acc;
             }
             DWBC_SYNC();
@@ -813,6 +793,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             DWBC_SYNC();
         }
         if (!cond) rankbad |= (1 << lv);
+        DWBC_PSTAMP(17 + 2 * lv);  // null-space chain of level lv done
             };
         if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
     }
@@ -828,6 +809,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     constexpr int WLD = S::WLD;
     const int colN = 1 + su.fstar_total;
     QpLaneConst qc;
+    PL(real_t, sfin);  // slack of the lane's QP row at the point the last QP returned (qp_solve_wave)
+    PL(real_t, grn);   // norm of the lane's row of the contact redistribution QP
+    bool skip_redis = false;
+    constexpr bool wm_ok = true;
     qp_lane_consts<N>(su, act_c[0], act_c[1], qc);
     wrench_maps<N, NT, S>(th, su, L, JbT, cd, k, WM);
     for (int i = th.tid; i < C; i += NT) {
@@ -842,32 +827,47 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (i < S::K) clast[i] = real_t(0.0);
     }
     DWBC_SYNC();
+    redis_row_norms<N, S>(L, nlim, ncone, k, qc, WM + colN, grn);
     DWBC_STAMP(6);  // wrench maps done
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;
         if (!is_task && k == 0) break;
+        if (!is_task && skip_redis) {  // every row of the redistribution QP holds at c = 0 (seen from the last task QP's final slacks): no step
+            if (diag && th.tid == 0) {
+                diag[DG_QP_ITER + kMaxLevels] = 0;
+                diag[DG_QP_NACT + kMaxLevels] = 0;
+            }
+            break;
+        }
         const int t = is_task ? su.t_dof[qi] : 0;
         const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
         const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
         const int colL = 1 + (is_task ? su.fstar_off[qi] : 0);
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }
         DWBC_SYNC();
-        for (int i = th.tid; i < M + C; i += NT) {
-            if (i < M) {
-                real_t acc = L[S::tg + i] + L[S::tt + i];
-                if (is_task) { for (int j = 0; j < t; j++) acc += Ul[i * T + j] * fs[j]; }
-                else acc += L[S::tc + i];
-                base[i] = acc;
-            } else {
-                const int r = i - M;
-                real_t acc = wacc[r];
-                if (is_task) { for (int j = 0; j < t; j++) acc += WM[r * WLD + colL + j] * fs[j]; }
-                else { for (int j = 0; j < k; j++) acc += WM[r * WLD + colN + j] * clast[j]; }
-                fv[r] = acc;
+        {
+            // straight-line: six unconditional reads per lane, the entries beyond t (or k) masked afterwards -- a loop with a run-time
+            // trip count puts every read behind its own wait
+            real_t f6[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) f6[j] = is_task ? (j < t ? fs[j] : real_t(0.0)) : (j < k ? clast[j] : real_t(0.0));
+            for (int i = th.tid; i < M + C; i += NT) {
+                const bool tq = i < M;
+                const int r = tq ? 0 : i - M;
+                const real_t *row = tq ? Ul + i * T : WM + r * WLD + (is_task ? colL : colN);
+                real_t u6[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) u6[j] = row[j];
+                real_t acc = tq ? L[S::tg + i] + L[S::tt + i] + (is_task ? real_t(0.0) : L[S::tc + i]) : wacc[r];
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc += ((is_task ? j < t : (j < k && !tq)) ? u6[j] * f6[j] : real_t(0.0));
+                if (tq) base[i] = acc; else fv[r] = acc;
             }
         }
         DWBC_SYNC();
+        if (qi == 0) DWBC_PSTAMP(24);  // level 0: base torque and wrench right-hand side
+        if (!is_task) DWBC_PSTAMP(26);  // redistribution: base torque and wrench right-hand side
         QpResult qres;
         {
             const real_t *P1 = is_task ? Ul : L + S::NwJw;
@@ -877,7 +877,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             qp_rows_and_solve<N, NB, 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
                                         is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
                                         is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x, nullptr, &qc,
-                                        is_task ? kQpTol : kQpFeasTol);
+                                        is_task ? kQpTol : kQpFeasTol, sfin);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
@@ -885,28 +885,58 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             diag[DG_QP_NACT + slot] = qres.nact;
         }
         if (is_task) DWBC_STAMP(7 + qi);  // QP of level qi solved
+#if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
+        if (diag && th.tid == 0 && qi == 0)
+            for (int i_ = 0; i_ < 9; i_++) diag[DG_FTIME + 32 + i_] = (int)qres.tm[i_];
+#endif
         const real_t *x = L + S::qp_x;
         if (is_task) {
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }
-            for (int i = th.tid; i < M; i += NT) {
-                real_t acc = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int j = 0; j < t; j++) acc += Ul[i * T + j] * (fs[j] + x[j]);
-                L[S::tt + i] += acc;
-                real_t c = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[t + j];
-                L[S::tc + i] = c;
+            {
+                real_t fx[6], xc[6];  // f* + f*_qp of the level, contact_qp_ (uniform), entries beyond t / k zero
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    fx[j] = j < t ? fs[j] + x[j] : real_t(0.0);
+                    xc[j] = j < k ? x[t + j] : real_t(0.0);
+                }
+                for (int i = th.tid; i < M + C; i += NT) {
+                    const bool tq = i < M;
+                    const int r = tq ? 0 : i - M;
+                    const real_t *row = tq ? Ul + i * T : WM + r * WLD + colL;
+                    real_t u6[6], n6[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { u6[j] = row[j]; n6[j] = L[S::NwJw + (tq ? i : 0) * 6 + j]; }
+                    real_t acc = real_t(0.0), c = real_t(0.0);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        acc += j < t ? u6[j] * fx[j] : real_t(0.0);
+                        c += j < k ? n6[j] * xc[j] : real_t(0.0);
+                    }
+                    if (tq) {
+                        L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
+                        L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
+                    } else {
+                        wacc[r] += acc;       // the wrench of what this level commits
+                        if (r < S::K) clast[r] = r < k ? x[t + r] : real_t(0.0);  // contact_qp_ for the redistribution's start
+                    }
+                }
             }
-            for (int i = th.tid; i < C; i += NT) {
-                real_t acc = wacc[i];
-                _Pragma("unroll 8")
-                for (int j = 0; j < t; j++) acc += WM[i * WLD + colL + j] * (fs[j] + x[j]);
-                wacc[i] = acc;
-                if (i < S::K) clast[i] = i < k ? x[t + i] : real_t(0.0);
+            if (qi == su.n_levels - 1 && k > 0 && (true)) {
+                // The rows of the redistribution QP (dwbc.cpp:1458-1517) are the rows of this level's QP seen at c = 0 with the total
+                // torque on the right-hand side, so its first look at them -- slack / |row| against the tolerance of canon rule 5 --
+                // can be taken from the slacks this QP ended with.  Nothing violated: the redistribution would return c = 0 after
+                // filling and normalising its 53 rows (6 k cycles in the stage table); it is skipped.
+                LANES {
+                    const bool tq = lane < M && nlim != 0, cn = lane >= M && lane - M < ncone;
+                    LV(grn) = (tq || cn) ? LV(sfin) / LV(grn) : DWBC_QP_INF;  // (grn is not needed again)
+                }
+                int wl_;
+                WAVE_ARGMIN_F32(grn, wl_);
+                skip_redis = !(BCAST(grn, wl_) < -kQpFeasTol);
             }
         } else if (qres.status) {
-            for (int i = th.tid; i < M; i += NT) {
+            for (int i = th.tid; i < M + S::K; i += NT) {
+                if (i >= M) { clast[i - M] += (i - M < k) ? x[i - M] : real_t(0.0); continue; }  // contact_qp_ + redistribution: what torque_contact_ stands for
                 real_t c = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[j];
@@ -914,9 +944,13 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             }
         } else {
             st_redis = 0;
-            for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);
+            for (int i = th.tid; i < M + S::K; i += NT) {
+                if (i < M) L[S::tc + i] = real_t(0.0); else clast[i - M] = real_t(0.0);
+            }
         }
         DWBC_SYNC();
+        if (qi == 0) DWBC_PSTAMP(25);  // level 0: committed (torque_task_, torque_contact_, running wrench)
+        if (!is_task) DWBC_PSTAMP(27);  // redistribution QP done and committed
     }
     if (k == 0) {
         for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);
@@ -924,10 +958,27 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     DWBC_SYNC();
     io_t *tau = io.tau + (size_t)inst * 3 * M;
     for (int i = th.tid; i < 3 * M; i += NT) tau[i] = too_many ? real_t(0.0) : L[S::tg + i];
+    DWBC_PSTAMP(28);  // torques stored
     io_t *wr = io.wrench + (size_t)inst * 12;
+    // getContactForce(tau_total) = Jbar[:, 6:] tau - P_C (wbd.cpp:268-271).  In the contact frames that is the running wrench of the
+    // cascade plus the contact-null part (wacc + F_N (contact_qp_ + redistribution): every term a column combination of the wrench
+    // maps); rotated back with blockdiag(R_a, R_a).  (Rounds 1-2 multiplied Jbar with the summed torque again: 33 x 4 LDS reads per lane.)
     for (int i = th.tid; i < 12; i += NT) {
         real_t acc = real_t(0.0);
-        if (i < cd && !too_many) {
+        if (i < cd && !too_many && wm_ok) {
+            const int a = i / 6, h = (i % 6) / 3, y = i % 3;
+            const real_t *R = L + S::Rc + a * 9;
+            real_t loc[3];
+#pragma unroll
+            for (int x_ = 0; x_ < 3; x_++) {
+                const int r = 6 * a + 3 * h + x_;
+                real_t v = wacc[r];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += (j < k) ? WM[r * WLD + colN + j] * clast[j] : real_t(0.0);
+                loc[x_] = v;
+            }
+            acc = R[y * 3] * loc[0] + R[y * 3 + 1] * loc[1] + R[y * 3 + 2] * loc[2];
+        } else if (i < cd && !too_many) {
             acc = -L[S::PC + i];
             _Pragma("unroll 8")
             for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);

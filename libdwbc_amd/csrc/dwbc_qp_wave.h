@@ -71,13 +71,16 @@ template <int WS, int NV = kQpN>
 // the order of the picks; only the path (and the iteration count, when the cold path adds rows it later drops) does.
 // vtol: violation (slack / |row|) below which a row counts as satisfied during the search: kQpTol for the task QPs, kQpFeasTol for the
 // contact redistribution QP -- it starts from the point the last task QP handed over, which was accepted at kQpFeasTol (canon rule 5)
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, kQpN doubles */, const int *warm = nullptr,
-                             real_t vtol = kQpTol) {
+// sfin (per lane): the UNNORMALISED slack of the lane's row (its tighter side) at the point returned in out.x -- the caller uses it to see
+// whether the contact redistribution QP that follows the last task level has anything to do (dwbc_cycle2.h)
+DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, kQpN doubles */, const int *warm,
+                             real_t vtol, PL_REF(real_t, sfin)) {
     DWBC_LANE_DECL;
     const int k = nv - t;
     PLA(real_t, Mx, NV);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
     PL(real_t, d);          // g . x of the own row (normalised row, scaled variables)
     PL(real_t, fs);         // |g| / |a|: factor from the normalised slack to slack / (norm of the unscaled row)
+    PL(real_t, gnv);        // |g| before the normalisation (1 for a zero row): normalised slack * gnv = slack of the row as given
     PL(real_t, u);          // slot lanes: multiplier
     PL(int, akey);          // slot lanes: (owner lane << 1) | side
     PL(int, actf);          // bit0: hi side in the working set, bit1: lo side
@@ -105,6 +108,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         const real_t gn = zrow ? real_t(1.0) : sqrt(s2);
         const real_t rg = zrow ? real_t(0.0) : real_t(1.0) / gn;
         LV(fs) = zrow ? real_t(1.0) : gn / sqrt(a2);
+        LV(gnv) = gn;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             LV(R.g)[j] *= rg;
@@ -311,12 +315,21 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     }
 #pragma unroll
     for (int i = 0; i < kQpN; i++) out.x[i] = real_t(0.0);
-    if (!status || q == 0) return;  // x = 0: failure (caller zeroes the correction) or no active constraint
+    // slack of every row at the returned point: gx = g . x of the lane's (normalised) row there
+    auto final_slack = [&](int which) {  // 0: x = 0, 1: the GI iterate (d), 2: the lexicographic point (dz holds g . x of it)
+        LANES {
+            const real_t gx = which == 0 ? real_t(0.0) : (which == 1 ? LV(d) : LV(dz));
+            const real_t sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - gx) * LV(gnv);
+            const real_t sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + gx) * LV(gnv);
+            LV(sfin) = sl < sh ? sl : sh;
+        }
+    };
+    if (!status || q == 0) { final_slack(0); return; }  // x = 0: failure (caller zeroes the correction) or no active constraint
     // Tikhonov point on the working set = the GI iterate (the fallback of the canon, and the answer when one of the two
     // variable blocks is empty)
 #pragma unroll
     for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
-    if (!(k > 0 && t > 0)) return;
+    if (!(k > 0 && t > 0)) { final_slack(1); return; }
     // ---- lexicographic least-norm point on the working set (min |delta| first, then min |c|) from the operators the search
     //      already holds.  With N the active normals (scaled variables) the GI iterate is x^ = N^+T b, the minimiser of
     //      1/2 |delta|^2 + 1/2 |c^|^2 on the working set; the minimiser of 1/2 |delta|^2 + 1/2 |c^ - c^_k|^2 on it is
@@ -421,6 +434,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             real_t dd = real_t(0.0);
 #pragma unroll
             for (int j = 0; j < NV; j++) dd += LV(R.g)[j] * xs[j];
+            LV(dz) = dd;  // (dz is free after the search: g . x of the lexicographic point, for final_slack)
             const real_t sh = LV(R.hi) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.hi) - dd) * LV(fs);
             const real_t sl = LV(R.lo) >= DWBC_QP_INF ? DWBC_QP_INF : (LV(R.lo) + dd) * LV(fs);
             LV(val) = sl < sh ? sl : sh;
@@ -433,6 +447,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
             for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
+            final_slack(2);
+        } else {
+            final_slack(1);
         }
     }
 }

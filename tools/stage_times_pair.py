@@ -40,3 +40,14 @@ for i, n in ((5, "stage 3a (J_kt, X, null-space chain)"), (6, "wrench maps (MFMA
     if t[i] > 0:
         print(f"{n:44s} {t[i] - prev:10.0f} {t[i]:12.0f}")
         prev = t[i]
+fine = {16: "level-0 J_kt / X rows written", 17: "level-0 chain done", 18: "level-1 J_kt / X rows written", 19: "level-1 chain done",
+        24: "level-0 QP: base torque + wrench rhs ready", 25: "level-0 QP: committed", 26: "redistribution: base + rhs ready",
+        27: "redistribution QP done, committed", 28: "torques stored"}
+print("fine stamps of the main wave (cumulative):")
+for i in sorted(fine):
+    if f[i] > 0:
+        print(f"  {fine[i]:44s} {f[i]:12.0f}")
+qn = ["post-loop", "slack + arg-min", "publish n, r, z", "step / drop", "commit", "lexicographic point (CG)", "normalise rows, init", "feasibility of the point", "row fill"]
+print("level-0 QP solver sections (cycles, summed over iterations):")
+for i, n in enumerate(qn):
+    print(f"  {n:28s} {f[32 + i]:10.0f}")
