@@ -602,7 +602,7 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
         float *dump;
         const float *body;
         const int *topo;
-        int hqp, pair_swap_bit, warm;
+        int hqp, pair_swap_bit, warm, wrench_ld;
     } io{};
     static_assert(sizeof(IoF32) == sizeof(BatchIO), "BatchIO layouts of the two builds must match");
     io.B = b->B;

@@ -24,23 +24,28 @@ namespace dwbc {
 
 constexpr int kQpN = 12;  // max variables (6 task + 6 contact-null)
 
-struct QpRows {
-    PLA(real_t, g, kQpN);  // row coefficients, contact columns already scaled by kQpScaleGI, zero padded
+// QN: capacity in variables -- kQpN for the product kernels (6 task + 6 contact-null), 18 for the three-contact kernel (dwbc_cycle_gc.h)
+template <int QN>
+struct QpRowsT {
+    PLA(real_t, g, QN);    // row coefficients, contact columns already scaled by kQpScaleGI, zero padded
     PL(real_t, hi);        // g.x <= hi
     PL(real_t, lo);        // -g.x <= lo   (lo = +inf: one-sided row)
     PL(int, id_hi);        // reference row index of the hi side (for diagnostics)
     PL(int, id_lo);
 };
+using QpRows = QpRowsT<kQpN>;
 
-struct QpResult {
+template <int QN>
+struct QpResultT {
     int status, iters, nact;
     real_t viol;
-    real_t x[kQpN];   // uniform, unscaled [delta (t); c (k)]
-    int act[kQpN];    // reference row indices of the working set
+    real_t x[QN];     // uniform, unscaled [delta (t); c (k)]
+    int act[QN];      // reference row indices of the working set
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
     long long tm[10];  // diagnostic build: cycles per solver section; [8] row fill, [9] (free)
 #endif
 };
+using QpResult = QpResultT<kQpN>;
 
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
 #define DWBC_QPT_INIT() long long qpt_last_ = clock64(); for (int i_ = 0; i_ < 10; i_++) out.tm[i_] = 0
@@ -54,17 +59,10 @@ struct QpResult {
 
 
 
-// scaled-variable iterate -> position order of the final solve: contact variables first (the heavy rows of the
-// row-sorted weighted QR), then the task variables
-#define DWBC_QP_PERM_CASE(TT, KK)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NV; i++)                                                        \
-        LV(c)[i] = (i < (KK)) ? sgw * wsc * LV(R.g)[((TT) + i) < kQpN ? (TT) + i : 0]                     \
-                              : ((i < (KK) + (TT)) ? sgw * LV(R.g)[(i - (KK)) >= 0 ? i - (KK) : 0] : real_t(0.0));
-
 // WS != 0: report the working set (reference row indices) in out.act -- diagnostics the lean kernel build leaves out.
 // NV >= nv: compile-time bound of the variable count (12, 9 or 6); every dot product, rank-one update and QR step runs over NV
 // entries instead of the maximum 12 (the padded entries are exact zeros, so the result does not depend on NV).
-template <int WS, int NV = kQpN>
+template <int WS, int NV = kQpN, int QN = kQpN>
 // warm: reference row indices of the previous solve's working set (kQpN entries, -1 = empty) or nullptr.  Hot start in the sense of
 // SolveQPoases(init = false): the search visits those rows first -- each is added as soon as it is violated -- before it falls
 // back to the most-violated rule.  The Tikhonov problem is strictly convex, so the point the search ends at does not depend on
@@ -73,9 +71,11 @@ template <int WS, int NV = kQpN>
 // contact redistribution QP -- it starts from the point the last task QP handed over, which was accepted at kQpFeasTol (canon rule 5)
 // sfin (per lane): the UNNORMALISED slack of the lane's row (its tighter side) at the point returned in out.x -- the caller uses it to see
 // whether the contact redistribution QP that follows the last task level has anything to do (dwbc_cycle2.h)
-DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &out, real_t *V /* LDS, kQpN doubles */, const int *warm,
+DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResultT<QN> &out, real_t *V /* LDS, QN doubles */, const int *warm,
                              real_t vtol, PL_REF(real_t, sfin)) {
     DWBC_LANE_DECL;
+    static_assert(NV <= QN && NV <= 24, "variable count");
+    constexpr int SB = NV > 16 ? 32 : 16;  // first working-set slot lane (the H rows take lanes 0..NV-1)
     const int k = nv - t;
     PLA(real_t, Mx, NV);  // lanes 0..11: row of H;  lanes 16..27: row of N^+ for working-set slot lane-16
     PL(real_t, d);          // g . x of the own row (normalised row, scaled variables)
@@ -120,7 +120,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         LV(u) = real_t(0.0);
         LV(akey) = 0;
         LV(actf) = 0;
-        LV(slotbit) = (lane >= 16 && lane < 16 + NV) ? (1 << (lane - 16)) : 0;
+        LV(slotbit) = (lane >= SB && lane < SB + NV) ? (1 << (lane - SB)) : 0;
         LV(m) = real_t(0.0);
         LV(dz) = real_t(0.0);
     }
@@ -129,19 +129,19 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     int used = 0, q = 0, it = 0, status = 1, p = 0, side = 0, kmin = 0;
     bool pick = true;
     real_t up = real_t(0.0), worst = real_t(0.0);
-    int wid[kQpN], wpos = kQpN;
+    int wid[QN], wpos = QN;
     if (WS && warm) {
 #pragma unroll
-        for (int a = 0; a < kQpN; a++) wid[a] = warm[a];
+        for (int a = 0; a < QN; a++) wid[a] = warm[a];
         wpos = 0;
     }
     for (;;) {
         bool got = false;
         if (WS && pick) {
-            while (wpos < kQpN && !got) {  // rows of the previous working set first
+            while (wpos < QN && !got) {  // rows of the previous working set first
                 int id = -1;
 #pragma unroll
-                for (int a = 0; a < kQpN; a++) id = (a == wpos) ? wid[a] : id;
+                for (int a = 0; a < QN; a++) id = (a == wpos) ? wid[a] : id;
                 wpos++;
                 if (id < 0) continue;
                 LANES {
@@ -236,7 +236,11 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         }
         real_t t1;
         int l;
-        WAVE_ARGMIN_ROW1(val, key, t1, l);
+        if constexpr (SB == 16) {
+            WAVE_ARGMIN_ROW1(val, key, t1, l);  // (the slot lanes are DPP row 1)
+        } else {
+            WAVE_ARGMIN(val, key, t1, l);       // every other lane holds +inf
+        }
         const real_t t2 = zok ? -sp * fast_rcp(zg) : DWBC_QP_INF;
         const real_t tstep = t1 < t2 ? t1 : t2;
         if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
@@ -257,7 +261,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
             const real_t inv_ = fast_rcp(zg);
             LANES {
                 real_t coef = LV(m) * inv_;
-                if (lane == 16 + slot) { coef = -inv_; LV(u) = up; LV(akey) = kmin; }
+                if (lane == SB + slot) { coef = -inv_; LV(u) = up; LV(akey) = kmin; }
 #pragma unroll
                 for (int j = 0; j < NV; j++) LV(Mx)[j] -= coef * zu[j];
                 if (lane == p) LV(actf) |= (side ? 2 : 1);
@@ -292,7 +296,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                 if (lane == (kl >> 1)) LV(actf) &= ~((kl & 1) ? 2 : 1);
             }
             WSYNC();
-            used &= ~(1 << (l - 16));
+            used &= ~(1 << (l - SB));
             q--;
         }
         DWBC_QPT(4);
@@ -303,9 +307,9 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     out.status = status;
     out.viol = worst >= DWBC_QP_INF ? real_t(0.0) : worst;
 #pragma unroll
-    for (int a = 0; a < kQpN; a++) {
+    for (int a = 0; a < QN; a++) {
         if (WS) {
-            const int ka = BCASTI(akey, 16 + a);
+            const int ka = BCASTI(akey, SB + a);
             const int ow = ka >> 1;
             const int idh = BCASTI(R.id_hi, ow), idl = BCASTI(R.id_lo, ow);
             out.act[a] = ((used >> a) & 1) ? ((ka & 1) ? idl : idh) : -1;
@@ -314,7 +318,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         }
     }
 #pragma unroll
-    for (int i = 0; i < kQpN; i++) out.x[i] = real_t(0.0);
+    for (int i = 0; i < QN; i++) out.x[i] = real_t(0.0);
     // slack of every row at the returned point: gx = g . x of the lane's (normalised) row there
     auto final_slack = [&](int which) {  // 0: x = 0, 1: the GI iterate (d), 2: the lexicographic point (dz holds g . x of it)
         LANES {
@@ -328,7 +332,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     // Tikhonov point on the working set = the GI iterate (the fallback of the canon, and the answer when one of the two
     // variable blocks is empty)
 #pragma unroll
-    for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xu[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
+    for (int j = 0; j < QN; j++) out.x[j] = (j < nv) ? xu[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
     if (!(k > 0 && t > 0)) { final_slack(1); return; }
     // ---- lexicographic least-norm point on the working set (min |delta| first, then min |c|) from the operators the search
     //      already holds.  With N the active normals (scaled variables) the GI iterate is x^ = N^+T b, the minimiser of
@@ -344,7 +348,8 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
     //      (Replaces the column-pivoted Householder QR of the weighted normals of rounds 1-2, ~13 k cycles per QP.)
     {
         real_t xs[NV];
-        constexpr int KC = 6;  // contact-null variables: k <= 6 (one or two 6D contacts)
+        constexpr int KC = QN > 12 ? QN - 6 : 6;  // contact-null variables: k <= 6 (one or two 6D contacts); 12 in the three-contact build
+        constexpr int kCgMax = KC > kQpRefine ? KC + 2 : kQpRefine;
         static_assert(NV >= KC, "variable blocks");
         bool settled = false;
         // STD: the layout every lean launch has when it gets here (t = NV - 6 task variables, then 6 contact-null ones): the
@@ -400,7 +405,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
                 bn += cb[i] * cb[i];
             }
             const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
-            for (int r = 0; r < kQpRefine && rs > rtol2; r++) {
+            for (int r = 0; r < kCgMax && rs > rtol2; r++) {
                 hmul(cp);
                 real_t ap[KC], pap = real_t(0.0);
 #pragma unroll
@@ -446,7 +451,7 @@ DWBC_WDEV void qp_solve_wave(QpRows &R, int nv, int t, int max_iter, QpResult &o
         if (settled && !(wv < -kQpFeasTol)) {
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
-            for (int j = 0; j < kQpN; j++) out.x[j] = (j < nv) ? xs[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
+            for (int j = 0; j < QN; j++) out.x[j] = (j < nv) ? xs[j < NV ? j : 0] * ((j >= t) ? kQpScaleGI : real_t(1.0)) : real_t(0.0);
             final_slack(2);
         } else {
             final_slack(1);

@@ -165,6 +165,8 @@ struct BatchIO {  // device pointers.  Inputs and outputs are io_t (double) in b
                                  // waves (-1: never)
     int warm;                    // 1: init = false (reference src/dwbc.cpp:1064-1074, src/qp_wrapper.cpp:249-296): every QP first tries
                                  // the rows of its previous working set (diag[DG_QP_ACT..], written by the previous launch)
+    int wrench_ld;               // general-contact kernel (dwbc_cycle_gc.h): doubles per instance in `wrench` (18 for three contacts); the
+                                 // product kernels write 12 per instance and do not read it
 };
 
 }  // namespace dwbc

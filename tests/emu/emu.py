@@ -109,6 +109,22 @@ class Emu:
         assert ok == 1, self.L.emu_error(self.h)
         return dict(tau=tau, wrench=wr, status=st, diag=diag, dump=dmp)
 
+    def run_gc(self, q, flags, fstar):
+        """the general-contact kernel (dwbc_cycle_gc.h, up to three simultaneously active contacts); wrench is (B, 18)"""
+        B = q.shape[0]
+        q = np.ascontiguousarray(q, np.float64)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        fstar = np.ascontiguousarray(fstar, np.float64)
+        assert flags.shape == (B, self.ncon) and fstar.shape == (B, self.F)
+        tau = np.zeros((B, 3, self.m))
+        wr = np.zeros((B, 18))
+        st = np.zeros(B, np.int32)
+        diag = np.zeros((B, 90), np.int32)
+        self.L.emu_run_gc.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        ok = self.L.emu_run_gc(self.h, B, q.ctypes.data, flags.ctypes.data, fstar.ctypes.data, tau.ctypes.data, wr.ctypes.data, st.ctypes.data, diag.ctypes.data)
+        assert ok == 1, self.L.emu_error(self.h)
+        return dict(tau=tau, wrench=wr, status=st, diag=diag)
+
     def dump_field(self, dmp, name, shape):
         off = self.L.emu_dump_offset(self.h, name.encode())
         assert off >= 0

@@ -13,6 +13,7 @@
 
 #include "../../libdwbc_amd/csrc/dwbc_reduced.h"
 #include "../../libdwbc_amd/csrc/dwbc_cycle2p.h"
+#include "../../libdwbc_amd/csrc/dwbc_cycle_gc.h"
 #include "../../libdwbc_amd/csrc/dwbc_hqp.h"
 #include "../../libdwbc_amd/csrc/dwbc_model.h"
 #include "../../libdwbc_amd/csrc/dwbc_setup.h"
@@ -227,6 +228,32 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
         else cycle_instance_v2<39, 34, 4, 1, true, TopoTocabi>(th, c->su, io, b, lds.data(), ilds.data());
     }
     from_real(rdump, dump);
+    return 1;
+}
+
+// the general-contact kernel of dwbc_cycle_gc.h (up to three active contacts; wrench: B x 18), LDS poisoned per instance
+int emu_run_gc(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
+               int *status, int *diag) {
+    if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
+    auto rb = to_real(c->body.data(), c->body.size());
+    BatchIO io{};
+    io.B = B;
+    io.q = q;
+    io.flags = flags;
+    io.fstar = fstar;
+    io.tau = tau;
+    io.wrench = wrench;
+    io.wrench_ld = 18;
+    io.status = status;
+    io.diag = diag;
+    io.body = rb.data();
+    io.topo = c->topo.data();
+    io.hqp = 1;
+    std::vector<real_t> lds(LdsG<39, 34, 3>::total + 64);
+    for (int b = 0; b < B; b++) {
+        std::fill(lds.begin(), lds.end(), std::numeric_limits<real_t>::quiet_NaN());
+        cycle_instance_gc<39, 34, 3, 1>(Thr{0}, c->su, io, b, lds.data());
+    }
     return 1;
 }
 
