@@ -56,7 +56,7 @@ enum dwbc_field {
     DWBC_IN_FSTAR = 2,    /* (sum task dof)  f64  -- SetTaskSpace(level, f*) concatenated */
     /* outputs (bindable) */
     DWBC_TAU = 10,        /* (3, m) f64: torque_grav_, torque_task_, torque_contact_  (include/dwbc.h:115-117) */
-    DWBC_WRENCH = 11,     /* (12)   f64: getContactForce(tau_total), zero padded       (src/dwbc.cpp:891-896) */
+    DWBC_WRENCH = 11,     /* (12; 18 after dwbc_batch_set_max_active_contacts(b, 3)) f64: getContactForce(tau_total), zero padded (src/dwbc.cpp:891-896) */
     DWBC_STATUS = 12,     /* (1)    i32: 1 ok / 0 failed                               */
     DWBC_DIAG = 13,       /* (90)   i32: stage status, QP iterations, working sets, stage stamps */
     /* derived getters (host only) */
@@ -174,6 +174,12 @@ int dwbc_batch_task_dof(const dwbc_batch *b, int level);
 int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, const double *qddot);
 /* SetContact(bool...) include/dwbc.h:291 : flags is B x n_contacts */
 int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags);
+/* SetContact with a third flag raised: the reference stacks every flagged contact (src/dwbc.cpp:445-453; its tests register both
+ * hands next to the feet, tests/dwbc_test.cpp:68-69).  The product kernels stack two; n = 3 routes every solve of this batch through
+ * the general-contact kernel (up to three simultaneously active 6D contacts per instance, hqp = true, link tasks with f* from
+ * SetTaskSpace) and widens DWBC_WRENCH to 6 n doubles per instance.  Call before binding a wrench buffer.  n = 2 restores the default. */
+int dwbc_batch_set_max_active_contacts(dwbc_batch *b, int n);
+int dwbc_batch_max_active_contacts(const dwbc_batch *b);
 /* SetTaskSpace(level, f*) include/dwbc.h:333 : fstar is B x task_dof(level) */
 int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar);
 

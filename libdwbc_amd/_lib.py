@@ -45,6 +45,8 @@ SYMBOLS = [
     ("dwbc_batch_task_dof", _i, [_vp, _i]),
     ("dwbc_batch_set_state", _i, [_vp, _vp, _vp, _vp]),
     ("dwbc_batch_set_contact", _i, [_vp, _vp]),
+    ("dwbc_batch_set_max_active_contacts", _i, [_vp, _i]),
+    ("dwbc_batch_max_active_contacts", _i, [_vp]),
     ("dwbc_batch_set_fstar", _i, [_vp, _i, _vp]),
     ("dwbc_batch_copy_kinematics", _i, [_vp, _vp]),
     ("dwbc_batch_bind_device", _i, [_vp, _i, _vp]),

@@ -246,6 +246,16 @@ class Batch:
         _check(self._L.dwbc_batch_copy_kinematics(target._h, self._h))
         target.n_contacts = self.n_contacts
 
+    def set_max_active_contacts(self, n):
+        """Contacts that may be active at once in one instance: 2 (default, the product kernels) or 3 -- every solve of the batch then
+        runs the general-contact kernel (feet + one hand, ...; hqp = true, link tasks) and ``get("wrench")`` is (B, 6 n).  The
+        reference stacks any number of flagged contacts (src/dwbc.cpp:445-453)."""
+        _check(self._L.dwbc_batch_set_max_active_contacts(self._h, int(n)))
+
+    @property
+    def max_active_contacts(self):
+        return int(self._L.dwbc_batch_max_active_contacts(self._h))
+
     def set_contact(self, flags):
         f = np.ascontiguousarray(flags, np.uint8)
         assert f.shape == (self.B, self.n_contacts), f.shape
@@ -322,7 +332,7 @@ class Batch:
         return self._L.dwbc_batch_kernel_name(self._h).decode()
 
     _SHAPES = dict(
-        tau=lambda s: (3, s.m), wrench=lambda s: (12,), status=lambda s: (), diag=lambda s: (90,),
+        tau=lambda s: (3, s.m), wrench=lambda s: (6 * s.max_active_contacts,), status=lambda s: (), diag=lambda s: (90,),
         tau_grav=lambda s: (s.m,), tau_task=lambda s: (s.m,), tau_contact=lambda s: (s.m,), tau_total=lambda s: (s.m,),
         A=lambda s: (s.n, s.n), A_inv=lambda s: (s.n, s.n), A_inv_N_C=lambda s: (s.n, s.n), J_C=lambda s: (12, s.n),
         J_C_INV_T=lambda s: (12, s.n), Lambda_c=lambda s: (144,), W_inv=lambda s: (s.m, s.m), NwJw=lambda s: (s.m, 6),

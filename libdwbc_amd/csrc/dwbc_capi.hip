@@ -441,19 +441,41 @@ int dwbc_batch_set_state(dwbc_batch *b, const double *q, const double *qdot, con
 int dwbc_batch_set_contact(dwbc_batch *b, const uint8_t *flags) {
     if (b->su.n_contacts == 0) return fail("Contact Constraint size mismatch");  // include/dwbc.h:438-441
     if (b->d_flags && !b->own_flags) return fail("contact flags are bound to a device buffer");
-    // the kernels stack at most kMaxActiveContacts simultaneous 6D contacts (the reference: any number, src/dwbc.cpp:445-453);
-    // an instance with more is refused here instead of failing on the device (status 0, zero torques)
+    // the product kernels stack two simultaneous 6D contacts, the general-contact kernel three (the reference: any number,
+    // src/dwbc.cpp:445-453); an instance with more than the batch is set up for is refused here instead of failing on the device
     const int ncn = b->su.n_contacts;
     for (int i = 0; i < b->B; i++) {
         int on = 0;
         for (int c = 0; c < ncn; c++) on += flags[(size_t)i * ncn + c] ? 1 : 0;
-        if (on > kMaxActiveContacts) return fail("more than 2 simultaneously active contacts in one instance: not supported by the device path");
+        if (on > b->max_active)
+            return fail(b->max_active > 2 ? "more than 3 simultaneously active contacts in one instance: not supported by the device path"
+                                          : "more than 2 simultaneously active contacts in one instance: call dwbc_batch_set_max_active_contacts(b, 3) first (3 is the most the device path stacks)");
     }
     wait_uploads(b);
     if (flags != b->h_flags.data()) memcpy(b->h_flags.data(), flags, b->h_flags.size());
     b->dirty_flags = true;
     return 1;
 }
+
+// SetContact with more than two flags raised (reference src/dwbc.cpp:445-453 stacks every flagged contact): n = 3 routes the
+// batch's solves through the general-contact kernel (dwbc_cycle_gc.h) and widens the wrench output to 6 n doubles per instance
+int dwbc_batch_set_max_active_contacts(dwbc_batch *b, int n) {
+    if (n != 2 && n != kGcContacts) return fail("max active contacts: 2 (default) or 3");
+    if (n == b->max_active) return 1;
+    if (n > 2) {
+        if (b->dtype == DWBC_F32) return fail("three active contacts: fp64 batches only");
+        if (!lookup_gc(b->n, b->su.nb)) return fail("no general-contact kernel for this model size");
+    }
+    if (!b->own_wrench) return fail("wrench is bound to a device buffer: set the contact capacity before binding");
+    HIP_OK(hipStreamSynchronize(b->stream));
+    HIP_OK(hipFree(b->d_wrench));
+    b->d_wrench = nullptr;
+    HIP_OK(hipMalloc(&b->d_wrench, (size_t)b->B * 6 * n * sizeof(double)));
+    HIP_OK(hipMemset(b->d_wrench, 0, (size_t)b->B * 6 * n * sizeof(double)));
+    b->max_active = n;
+    return 1;
+}
+int dwbc_batch_max_active_contacts(const dwbc_batch *b) { return b->max_active; }
 
 int dwbc_batch_set_fstar(dwbc_batch *b, int level, const double *fstar) {
     if (level < 0 || level >= b->su.n_levels) return fail("ERROR : task space size overflow");  // src/dwbc.cpp:668-671
@@ -630,7 +652,37 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     return 1;
 }
 
+// three active contacts: every instance of the batch goes through the general-contact kernel (lean scope)
+static int launch_gc(dwbc_batch *b) {
+    const GcEntry *g = lookup_gc(b->n, b->su.nb);
+    if (!g) return fail("no general-contact kernel for this model size");
+    if (!b->hqp) return fail("three active contacts: hqp = true only (the reference's closed-form redistribution is written for two contacts, src/dwbc.cpp:1570-1619)");
+    if (b->su.n_traj > 0 || b->su.has_com_task || b->su.n_custom > 0 || b->dump_on)
+        return fail("three active contacts: link tasks with f* from SetTaskSpace only (no trajectories, COM or custom levels, no dump record)");
+    if (!b->gc_attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(g->fn), hipFuncAttributeMaxDynamicSharedMemorySize, g->lds_bytes));
+        b->gc_attr_set = true;
+    }
+    BatchIO io{};
+    io.B = b->B;
+    io.q = b->d_q;
+    io.flags = b->d_flags;
+    io.fstar = b->d_fstar;
+    io.tau = b->d_tau;
+    io.wrench = b->d_wrench;
+    io.wrench_ld = 6 * b->max_active;
+    io.status = b->d_status;
+    io.diag = b->d_diag;
+    io.body = b->d_body;
+    io.topo = b->d_topo;
+    io.hqp = 1;
+    b->ws_valid = false;  // cold-started QPs, no working sets kept
+    hipLaunchKernelGGL(g->fn, dim3(b->B), dim3(kNT), g->lds_bytes, b->stream, b->su, io);
+    return hipGetLastError() == hipSuccess ? 1 : fail("general-contact kernel launch failed");
+}
+
 static int launch(dwbc_batch *b, bool reduced = false) {
+    if (b->max_active > 2) return reduced ? fail("three active contacts: not built on the reduced dynamics path") : launch_gc(b);
     if (b->dtype == DWBC_F32) return launch_f32(b, reduced);
     const KernelEntry *ke = pick_kernel(b, reduced);
     if (!ke) return fail("no kernel for this model / number of task levels");
@@ -785,7 +837,7 @@ size_t dwbc_batch_field_bytes(const dwbc_batch *b, int field) {
         case DWBC_IN_CONTACT: return B * b->su.n_contacts;
         case DWBC_IN_FSTAR: return B * b->su.fstar_total * 8;
         case DWBC_TAU: return B * 3 * m * 8;
-        case DWBC_WRENCH: return B * 12 * 8;
+        case DWBC_WRENCH: return B * 6 * b->max_active * 8;
         case DWBC_STATUS: return B * 4;
         case DWBC_DIAG: return B * DG_COUNT * 4;
         case DWBC_TAU_GRAV: case DWBC_TAU_TASK: case DWBC_TAU_CONTACT: case DWBC_TAU_TOTAL: return B * m * 8;
@@ -902,6 +954,10 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 
 const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     static thread_local std::string name;
+    if (b->max_active > 2) {
+        name = "dwbc::dwbc_cycle_kernel_gc<" + std::to_string(b->n) + ", " + std::to_string(b->su.nb) + ", 64>";
+        return name.c_str();
+    }
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     const std::string pre = b->dtype == DWBC_F32 ? "dwbc_f32::" : "dwbc::";  // as rocprofv3 prints the instantiations
     if (!ke) return "";
@@ -927,6 +983,12 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
+    if (b->max_active > 2) {
+        const GcEntry *g = lookup_gc(b->n, b->su.nb);
+        if (threads) *threads = kNT;
+        if (lds) *lds = g ? g->lds_bytes : 0;
+        return 1;
+    }
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
     if (threads) *threads = kNT;
     int n_cu = b->n_cu;

@@ -74,6 +74,8 @@ struct dwbc_batch {
     bool dump_on = false;
     int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
     float *f_body = nullptr;
+    int max_active = 2;           // simultaneously active contacts per instance the batch solves (2: product kernels; 3: dwbc_cycle_gc.h)
+    bool gc_attr_set = false;
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
     int f32_lds = 0, f32_lds_wide = 0, f32_key = -1, f32_topo = 0;
     int hqp = 1;

@@ -3,7 +3,7 @@
 //
 // The product kernels (dwbc_cycle2.h, dwbc_cycle2p.h) are built around two contacts: 12 contact rows fit the register / LDS budget
 // that gives them their speed, and their small blocks are unrolled for k in {0, 6}.  This kernel is the general statement of the same
-// cycle, one wavefront per instance, every matrix resident in LDS (~100 KB: one workgroup per CU) and every loop over run-time
+// cycle, one wavefront per instance, every matrix resident in LDS (80 KB: two workgroups per CU) and every loop over run-time
 // dimensions cd = 6 nc, k = cd - 6, t -- correctness first; a batch opts into it with dwbc_batch_set_max_active_contacts(b, 3).
 // NCC = 3: 18 contact rows, 12 contact-null variables, QPs of up to 18 variables and 33 + 30 = 63 rows -- still one row per lane of
 // the wave-level active-set solver (dwbc_qp_wave.h, instantiated for 18 variables).  Four contacts would need 73 lanes: not built.
@@ -53,14 +53,17 @@ struct LdsG {
     static constexpr int k_S = k_Ic + NB * 10;
     static constexpr int k_F = k_S + N * 6;
     static constexpr int k_end = k_F + N * 6;
-    // --- scratch, contact phase
+    // --- scratch, contact phase.  Y = J_C A^-1 is dead once A^-1 N_c exists, before the projector P is formed: P takes its place
+    //     (and reaches past it, so Vb and the small scratch sit behind P's end).  W + alpha P is built and inverted in bufA (A^-1 is
+    //     dead by then).  78 KB instead of 93: two workgroups per CU.
+    static constexpr int c_P = tmp;                   // M x M projector on null(W)
     static constexpr int c_Y = tmp;                   // J_C A^-1 (C x N)
-    static constexpr int c_Vb = c_Y + C * N;          // M x k
+    static_assert(C * N <= M * M, "Y fits under P");
+    static constexpr int c_Vb = c_P + M * M;          // M x k
     static constexpr int c_s1 = c_Vb + M * K;         // C x 2C Gauss-Jordan scratch
     static constexpr int c_s2 = c_s1 + C * 2 * C;     // C x C
-    static constexpr int c_P = c_s2 + C * C;          // M x M projector on null(W)
-    static constexpr int c_W1 = c_P + M * M;          // M x M
-    static constexpr int c_vec = c_W1 + M * M;        // N
+    static constexpr int c_VG = c_s2 + C * C;         // M x k: Vb G^-1
+    static constexpr int c_vec = c_VG + M * K;        // N
     static constexpr int c_end = c_vec + N;
     // --- scratch, task / QP phase
     static constexpr int t_Jt = tmp;                  // T x N
@@ -388,7 +391,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         // ---- W^+ and NwJw.  null(W) is known in closed form: W = S A^-1 N_c S^T vanishes exactly on
         //      { J_C[:,6:]^T lam : J_C[:,:6]^T lam = 0 } (internal wrenches), so V2's span needs no pivoted QR (wbd.cpp:5-53, 120-128)
         real_t *Winv = L + S::bufA;  // A_inv is dead from here on
-        real_t *W1 = L + S::c_W1, *P = L + S::c_P, *Vb = L + S::c_Vb;
+        real_t *W1 = L + S::bufA, *P = L + S::c_P, *Vb = L + S::c_Vb;  // (W + alpha P and its inverse live where A^-1 was)
         if (k > 0) {
             // basis of internal wrenches: (f_i, m_i) = e_a on contact i >= 1, balanced on contact 0
             const real_t *Pc = L + S::Pc;
@@ -425,9 +428,9 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             // projector on null(W):  P = Vb (Vb^T Vb)^-1 Vb^T
             mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
             gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
-            mm_nn<NT>(th, W1, k, Vb, k, L + S::c_s2, k, M, k, k);  // (M x k) = Vb G^-1, in the first M k entries of W1
+            mm_nn<NT>(th, L + S::c_VG, k, Vb, k, L + S::c_s2, k, M, k, k);  // (M x k) = Vb G^-1
             DWBC_SYNC();
-            mm_nt<NT>(th, P, M, W1, k, Vb, k, M, k, M);
+            mm_nt<NT>(th, P, M, L + S::c_VG, k, Vb, k, M, k, M);
             DWBC_SYNC();
         }
         // alpha = trace(W) / M;  W + alpha P is SPD;  W^+ = (W + alpha P)^-1 - P / alpha
@@ -444,7 +447,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         {
             if (!spd_inverse_reg<M>(W1, M, W1, M)) st_contact = 0;
             const real_t ia = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
-            for (int idx = th.tid; idx < M * M; idx += NT) Winv[idx] = W1[idx] - (k > 0 ? P[idx] * ia : real_t(0.0));
+            for (int idx = th.tid; idx < M * M; idx += NT) Winv[idx] = W1[idx] - (k > 0 ? P[idx] * ia : real_t(0.0));  // (in place: Winv is W1)
             DWBC_SYNC();
         }
         // FNl = A_rot (Jbar[:,6:] NwJw)   (cd x k), contact-local frames

@@ -6,6 +6,7 @@
 
 #include "dwbc_reduced.h"
 #include "dwbc_cycle2p.h"
+#include "dwbc_cycle_gc.h"
 
 namespace dwbc {
 
@@ -53,6 +54,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void d
     cycle_instance_v2p<N, NB, NLV, 64, Topo>(wave, th, su, io, inst, lds);
 }
 
+// up to three simultaneously active contacts (dwbc_cycle_gc.h): the general statement of the cycle, matrices in LDS (80 KB: two
+// workgroups per CU), any number of task levels -- for batches that opt in with dwbc_batch_set_max_active_contacts(b, 3)
+constexpr int kGcContacts = 3;
+template <int N, int NB, int NT>
+__global__ __launch_bounds__(NT) void dwbc_cycle_kernel_gc(const Setup su, const BatchIO io) {
+    static_assert(NT == 64, "one wavefront per instance");
+    extern __shared__ __attribute__((aligned(16))) real_t lds[];
+    const int inst = blockIdx.x;
+    if (inst >= io.B) return;
+    Thr th{(int)threadIdx.x};
+    cycle_instance_gc<N, NB, kGcContacts, NT>(th, su, io, inst, lds);
+}
+
 // reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
 template <int N, int NB, int NLV, int NT, class Topo>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_reduced(const Setup su, const BatchIO io) {
@@ -85,9 +99,25 @@ struct KernelEntry {
     void (*fn_pair)(const Setup, const BatchIO);  // two waves per instance (128 threads), lean, batches of at most 4 instances per CU; or nullptr
     int lds_bytes_pair;
 };
+// the general-contact kernel of a model size (any tree, any number of levels): one per (n, nb)
+struct GcEntry {
+    int n, nb;
+    void (*fn)(const Setup, const BatchIO);
+    int lds_bytes;
+};
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
 // flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).  Other model sizes come
 // from kernel packs (dwbc_pack.hip: this header instantiated for one (N, NB), loaded by the C-ABI at model-load time).
+#if !defined(DWBC_PACK_N) && !defined(DWBC_NO_PAIR_KERNEL)
+const GcEntry kKernelsGc[] = {
+    {39, 34, dwbc_cycle_kernel_gc<39, 34, kNT>, LdsG<39, 34, kGcContacts>::total_bytes},
+};
+inline const GcEntry *lookup_gc(int n, int nb) {
+    for (const GcEntry &e : kKernelsGc)
+        if (e.n == n && e.nb == nb) return &e;
+    return nullptr;
+}
+#endif
 #ifdef DWBC_PACK_N
 #elif defined(DWBC_EXPERIMENT)
 // A/B build (make experiment VARIANT=.. XFLAGS=..): only the BASELINE config[1] instantiation, seconds to compile
