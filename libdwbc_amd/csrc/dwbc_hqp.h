@@ -18,6 +18,8 @@
 // the solver state (H^-1, T, M, the vectors).  Code is NT-generic (strided loops, every hand-over between threads behind a
 // workgroup barrier) so that tests/emu runs it with one host thread and the device with several wavefronts.
 #pragma once
+#include <cstdlib>
+
 #include "dwbc_cycle.h"
 
 // this path keeps matrices in HBM that lanes of the wave hand to each other: a full workgroup barrier (waits for outstanding
@@ -46,9 +48,11 @@ struct HqpDesc {
     int oy[kHqpMaxLevels], ov[kHqpMaxLevels], ow[kHqpMaxLevels];
     int rec;       // doubles per instance record
     int max_rows;  // most inequality rows (own + earlier) any level sees
-    int scratch;   // doubles per instance of HBM scratch: Z (nv x nv) | HZ (nv x nv) | CZ (max_rows x nv)
+    int scratch;   // doubles per instance of scratch: Z (nv x nv) | HZ (nv x nv) | CZ (max_rows x nv)
     int lds;       // doubles of LDS
+    int scratch_in_lds;  // bits: 1 = Z, 2 = H Z, 4 = C Z sit behind the solver state in LDS (as far as the 160 KB of a CU reach); else HBM (io.scratch)
 };
+constexpr int kHqpLdsBudget = 160 * 1024 / 8 - 64;  // doubles of LDS one workgroup may take
 enum HqpStat { HQS_STATUS = 0, HQS_ITER = kHqpMaxLevels, HQS_NULL = 2 * kHqpMaxLevels, HQS_COUNT = 3 * kHqpMaxLevels };
 struct HqpIO {
     int B;
@@ -114,6 +118,17 @@ inline void hqp_layout(HqpDesc &d, bool share_cost) {
     d.max_rows = max_rows > 0 ? max_rows : 1;
     d.scratch = 2 * nv * nv + d.max_rows * nv;
     d.lds = HqpLds::make(nv, d.max_rows).total;
+    // Z, H Z and C Z are read and re-read inside a level -- C Z by every active-set step, Z by every product that forms the level,
+    // H Z once.  VERDICT r2's "obvious first move" -- keep them in LDS -- was built and measured (DWBC_HQP_SCRATCH_LDS=1: they go to LDS
+    // in that order of preference as far as the CU's 160 KB reach behind the solver state; the TOCABI LQP, 51 variables and 152 rows:
+    // C Z 62 KB + Z 21 KB next to 72 KB of state, H Z stays in HBM) and does NOT pay: the map then allows one workgroup per CU instead
+    // of two, and the cascade goes from 4.4 to 5.4 ms per 1024 instances (profiles/r03_lqp_summary.txt).  The default stays HBM.
+    d.scratch_in_lds = 0;
+    if (getenv("DWBC_HQP_SCRATCH_LDS")) {
+        const int sz[3] = {d.max_rows * nv, nv * nv, nv * nv}, bit[3] = {4, 1, 2};
+        for (int i = 0; i < 3; i++)
+            if (d.lds + sz[i] <= kHqpLdsBudget) { d.lds += sz[i]; d.scratch_in_lds |= bit[i]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -227,6 +242,12 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
     const HqpLds l = HqpLds::make(nv, d.max_rows);
     double *rec = io.rec + (size_t)inst * d.rec;
     double *Z = io.scratch + (size_t)inst * d.scratch, *HZ = Z + nv * nv, *CZ = HZ + nv * nv;
+    {
+        int o = l.total;  // LDS placement in the order hqp_layout() granted it: C Z, Z, H Z
+        if (d.scratch_in_lds & 4) { CZ = L + o; o += d.max_rows * nv; }
+        if (d.scratch_in_lds & 1) { Z = L + o; o += nv * nv; }
+        if (d.scratch_in_lds & 2) { HZ = L + o; o += nv * nv; }
+    }
     int *stat = io.stat + (size_t)inst * HQS_COUNT;
     for (int idx = th.tid; idx < nv * nv; idx += NT) Z[idx] = (idx / nv == idx % nv) ? 1.0 : 0.0;
     for (int i = th.tid; i < HQS_COUNT; i += NT) stat[i] = i < kHqpMaxLevels ? 1 : 0;
