@@ -349,7 +349,7 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
     {
         real_t xs[NV];
         constexpr int KC = QN > 12 ? QN - 6 : 6;  // contact-null variables: k <= 6 (one or two 6D contacts); 12 in the three-contact build
-        constexpr int kCgMax = KC > kQpRefine ? KC + 2 : kQpRefine;
+        constexpr int kCgMax = KC > kQpRefine ? 4 * KC : kQpRefine;
         static_assert(NV >= KC, "variable blocks");
         bool settled = false;
         // STD: the layout every lean launch has when it gets here (t = NV - 6 task variables, then 6 contact-null ones): the
@@ -405,7 +405,11 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                 bn += cb[i] * cb[i];
             }
             const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
+            bool nulldir = false;
             for (int r = 0; r < kCgMax && rs > rtol2; r++) {
+#ifdef DWBC_QP_TRACE
+                printf("  cg %d rs %.3e\n", r, (double)rs);
+#endif
                 hmul(cp);
                 real_t ap[KC], pap = real_t(0.0);
 #pragma unroll
@@ -414,6 +418,17 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     pap += cp[i] * ap[i];
                 }
                 if (!(pap > real_t(0.0))) break;
+                if constexpr (KC > 6) {
+                    // A search direction on which I - H_cc has (numerically) no curvature is a direction of c the working set does not
+                    // constrain -- twelve active rows whose contact block has rank 11, seen with two feet and a hand: a step along
+                    // it would divide round-off by round-off (c of 1e7).  The lexicographic point has no component there (stage 2
+                    // is the least-norm c; the restatement truncates the same direction by rank, oracle _lex_eqp), and neither has
+                    // the start: stop here.
+                    real_t pp = real_t(0.0);
+#pragma unroll
+                    for (int i = 0; i < KC; i++) pp += cp[i] * cp[i];
+                    if (pap < kQpNullDir * pp) { nulldir = true; break; }
+                }
                 const real_t al = rs * fast_rcp(pap);
                 real_t rs2 = real_t(0.0);
 #pragma unroll
@@ -427,8 +442,18 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                 for (int i = 0; i < KC; i++) cp[i] = cr[i] + be * cp[i];
                 rs = rs2;
             }
-            settled = !(rs > rtol2);
+            settled = !(rs > rtol2) || (nulldir && !(rs > kQpNullRes * kQpNullRes * bn));
+#ifdef DWBC_QP_TRACE
+            printf("lex: NV %d KC %d t %d k %d q %d rs %.3e rtol2 %.3e bn %.3e settled %d\n", NV, KC, t, k, q, (double)rs, (double)rtol2, (double)bn, (int)settled);
+#endif
             hmul(cx);  // x = x^ + H [0; c^]  (its contact block reproduces c^ when the residual is zero)
+#ifdef DWBC_QP_TRACE
+            {
+                double tr_ = 0.0;
+                for (int i = 0; i < KC; i++) { const double r_ = (double)(cb[i] - (cx[i] - hcc(i))); tr_ += r_ * r_; }
+                printf("  true residual^2 %.3e (recursive %.3e)\n", tr_, (double)rs);
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < NV; i++) xs[i] = xu[i] + BCAST(m, i);
         };
@@ -448,6 +473,15 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
         WAVE_ARGMIN_F32(val, wi);
         const real_t wv = BCAST(val, wi);
         DWBC_QPT(7);
+#ifdef DWBC_QP_TRACE
+        printf("  lex worst slack %.3e at lane %d -> %s;  xs:", (double)wv, wi, (settled && !(wv < -kQpFeasTol)) ? "lex" : "tikhonov");
+        for (int j = 0; j < NV; j++) printf(" %.6e", (double)(xs[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
+        printf("\n  xu:");
+        for (int j = 0; j < NV; j++) printf(" %.6e", (double)(xu[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
+        printf("\n  working set (owner lane, side):");
+        for (int a = 0; a < NV; a++) if ((used >> a) & 1) { const int ka = BCASTI(akey, SB + a); printf(" (%d,%d)", ka >> 1, ka & 1); }
+        printf("\n");
+#endif
         if (settled && !(wv < -kQpFeasTol)) {
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
 #pragma unroll
