@@ -97,7 +97,7 @@ constexpr real_t kQpReorth = real_t(1.0e-2);  // |H n|^2 below which the new dir
 #endif
 constexpr int kQpRefine = DWBC_QP_REFINE;   // most iterated-Tikhonov steps towards the lexicographic point (dwbc_qp_wave.h)
 constexpr real_t kQpNullDir = kF32 ? real_t(1.0e-6) : real_t(1.0e-12);   // curvature / |p|^2 below which a CG direction of the lexicographic solve is a null direction (18-variable QPs)
-constexpr real_t kQpNullRes = kF32 ? real_t(1.0e-4) : real_t(1.0e-8);    // relative residual accepted when the solve stopped at such a direction
+constexpr real_t kQpNullRes = kF32 ? real_t(1.0e-4) : real_t(1.0e-9);    // relative residual accepted when the solve stopped at such a direction
 constexpr real_t kQpRefineTol = kF32 ? real_t(1.0e-5) : real_t(1.0e-12);  // a step's change / |x| below which the sequence has settled
 }  // namespace dwbc
 #include "dwbc_qp_wave.h"

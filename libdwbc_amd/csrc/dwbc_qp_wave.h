@@ -55,6 +55,13 @@ using QpResult = QpResultT<kQpN>;
 #define DWBC_QPT(i) ((void)0)
 #endif
 
+#ifdef DWBC_QP_TRACE
+#ifdef DWBC_HOST_EMU
+#define QP_TRACE(...) printf(__VA_ARGS__)
+#else
+#define QP_TRACE(...) do { if (threadIdx.x == 0) printf(__VA_ARGS__); } while (0)
+#endif
+#endif
 #define DWBC_QP_INF (dwbc::kF32 ? dwbc::real_t(1.0e30) : dwbc::real_t(1.0e300))
 
 
@@ -406,9 +413,16 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
             }
             const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
             bool nulldir = false;
+            // 18-variable solves keep the best iterate: a step along a direction of small but not negligible curvature (1e-8 seen on a
+            // foot + a hand) can throw away ten digits of an iterate that was already good enough
+            real_t cbest[KC > 6 ? KC : 1], rbest = rs;
+            if constexpr (KC > 6) {
+#pragma unroll
+                for (int i = 0; i < KC; i++) cbest[i] = cx[i];
+            }
             for (int r = 0; r < kCgMax && rs > rtol2; r++) {
 #ifdef DWBC_QP_TRACE
-                printf("  cg %d rs %.3e\n", r, (double)rs);
+                QP_TRACE("  cg %d rs %.3e\n", r, (double)rs);
 #endif
                 hmul(cp);
                 real_t ap[KC], pap = real_t(0.0);
@@ -417,7 +431,7 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     ap[i] = cp[i] - hcc(i);
                     pap += cp[i] * ap[i];
                 }
-                if (!(pap > real_t(0.0))) break;
+                if (!(pap > real_t(0.0))) break;  // (round-off on a direction without curvature: same case as below)
                 if constexpr (KC > 6) {
                     // A search direction on which I - H_cc has (numerically) no curvature is a direction of c the working set does not
                     // constrain -- twelve active rows whose contact block has rank 11, seen with two feet and a hand: a step along
@@ -427,6 +441,9 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     real_t pp = real_t(0.0);
 #pragma unroll
                     for (int i = 0; i < KC; i++) pp += cp[i] * cp[i];
+#ifdef DWBC_QP_TRACE
+                    QP_TRACE("  cg %d pap/pp %.3e\n", r, (double)(pap / pp));
+#endif
                     if (pap < kQpNullDir * pp) { nulldir = true; break; }
                 }
                 const real_t al = rs * fast_rcp(pap);
@@ -437,21 +454,39 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     cr[i] -= al * ap[i];
                     rs2 += cr[i] * cr[i];
                 }
+                if constexpr (KC > 6) {
+                    if (rs2 < rbest) {
+                        rbest = rs2;
+#pragma unroll
+                        for (int i = 0; i < KC; i++) cbest[i] = cx[i];
+                    }
+                }
                 const real_t be = rs2 * fast_rcp(rs);
 #pragma unroll
                 for (int i = 0; i < KC; i++) cp[i] = cr[i] + be * cp[i];
                 rs = rs2;
             }
-            settled = !(rs > rtol2) || (nulldir && !(rs > kQpNullRes * kQpNullRes * bn));
+            // 18-variable solves: a solve that stopped at such a direction (or ran out of steps around it) has reached what the
+            // arithmetic allows; it stands if its residual is below kQpNullRes (relative) -- seen: 2e-10 on a foot + a hand
+            if constexpr (KC > 6) {
+                if (rbest < rs) {
+                    rs = rbest;
+#pragma unroll
+                    for (int i = 0; i < KC; i++) cx[i] = cbest[i];
+                }
+            }
+            settled = !(rs > rtol2) || (KC > 6 && !(rs > kQpNullRes * kQpNullRes * bn));
+            (void)nulldir;
+            (void)cbest;
 #ifdef DWBC_QP_TRACE
-            printf("lex: NV %d KC %d t %d k %d q %d rs %.3e rtol2 %.3e bn %.3e settled %d\n", NV, KC, t, k, q, (double)rs, (double)rtol2, (double)bn, (int)settled);
+            QP_TRACE("lex: NV %d KC %d t %d k %d q %d rs %.3e rtol2 %.3e bn %.3e settled %d\n", NV, KC, t, k, q, (double)rs, (double)rtol2, (double)bn, (int)settled);
 #endif
             hmul(cx);  // x = x^ + H [0; c^]  (its contact block reproduces c^ when the residual is zero)
 #ifdef DWBC_QP_TRACE
             {
                 double tr_ = 0.0;
                 for (int i = 0; i < KC; i++) { const double r_ = (double)(cb[i] - (cx[i] - hcc(i))); tr_ += r_ * r_; }
-                printf("  true residual^2 %.3e (recursive %.3e)\n", tr_, (double)rs);
+                QP_TRACE("  true residual^2 %.3e (recursive %.3e)\n", tr_, (double)rs);
             }
 #endif
 #pragma unroll
@@ -474,13 +509,13 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
         const real_t wv = BCAST(val, wi);
         DWBC_QPT(7);
 #ifdef DWBC_QP_TRACE
-        printf("  lex worst slack %.3e at lane %d -> %s;  xs:", (double)wv, wi, (settled && !(wv < -kQpFeasTol)) ? "lex" : "tikhonov");
-        for (int j = 0; j < NV; j++) printf(" %.6e", (double)(xs[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
-        printf("\n  xu:");
-        for (int j = 0; j < NV; j++) printf(" %.6e", (double)(xu[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
-        printf("\n  working set (owner lane, side):");
-        for (int a = 0; a < NV; a++) if ((used >> a) & 1) { const int ka = BCASTI(akey, SB + a); printf(" (%d,%d)", ka >> 1, ka & 1); }
-        printf("\n");
+        QP_TRACE("  lex worst slack %.3e at lane %d -> %s;  xs:", (double)wv, wi, (settled && !(wv < -kQpFeasTol)) ? "lex" : "tikhonov");
+        for (int j = 0; j < NV; j++) QP_TRACE(" %.6e", (double)(xs[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
+        QP_TRACE("\n  xu:");
+        for (int j = 0; j < NV; j++) QP_TRACE(" %.6e", (double)(xu[j] * ((j >= t) ? kQpScaleGI : real_t(1.0))));
+        QP_TRACE("\n  working set (owner lane, side):");
+        for (int a = 0; a < NV; a++) if ((used >> a) & 1) { const int ka = BCASTI(akey, SB + a); QP_TRACE(" (%d,%d)", ka >> 1, ka & 1); }
+        QP_TRACE("\n");
 #endif
         if (settled && !(wv < -kQpFeasTol)) {
             out.viol = wv >= DWBC_QP_INF ? real_t(0.0) : wv;
