@@ -591,13 +591,28 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     (void)colbuf;
     DWBC_SYNC();
     if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo, pivratio);
+    // Jacobi scaling: the sweep runs on D^-1 A D^-1, D = sqrt(diag A), and the inverse is scaled back.  The unpivoted sweep's error goes
+    // with the condition number it sees, and J A^-1 J^T of a foot and a HAND mixes rows of 1e-1 with rows of 1e3 (light links): unscaled,
+    // A^-1 N_c came out 4e-11 (relative) off and W^+ -- which amplifies it by 1 / lambda_min(W)^2 -- 2.5e-7, the torques 1e-5 Nm
+    // against the restatement on every foot + hand pair (feet only: 1e-10).  The scaled matrix has a unit diagonal.
     PLA(real_t, s, 12);
     PL(real_t, dg);
+    PL(real_t, dsc);
+    real_t rd[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const real_t a = i < n ? Ain[i * lda + i] : real_t(1.0);
+        rd[i] = a > real_t(0.0) ? real_t(1.0) / sqrt(a) : real_t(1.0);
+    }
     LANES {
         const int col = lane < n ? lane : 0;
+        real_t dc = real_t(1.0);
 #pragma unroll
-        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] : real_t(0.0);
-        LV(dg) = (lane < n) ? Ain[col * lda + col] : real_t(1.0);
+        for (int i = 0; i < 12; i++) dc = (col == i) ? rd[i] : dc;
+        LV(dsc) = dc;
+#pragma unroll
+        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] * rd[i] * dc : real_t(0.0);
+        LV(dg) = (lane < n) ? Ain[col * lda + col] * dc * dc : real_t(1.0);
     }
     const int ok = sweep_inverse_rl<12>(s, dg, n);
     DWBC_SYNC();
@@ -605,7 +620,7 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
         if (lane < n) {
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                if (i < n) Out[i * ldo + lane] = LV(s)[i];
+                if (i < n) Out[i * ldo + lane] = LV(s)[i] * rd[i] * LV(dsc);
         }
     }
     DWBC_SYNC();

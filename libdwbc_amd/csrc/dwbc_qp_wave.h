@@ -413,13 +413,11 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
             }
             const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
             bool nulldir = false;
-            // 18-variable solves keep the best iterate: a step along a direction of small but not negligible curvature (1e-8 seen on a
+            // The best iterate is kept: a step along a direction of small but not negligible curvature (1e-8 seen on a
             // foot + a hand) can throw away ten digits of an iterate that was already good enough
-            real_t cbest[KC > 6 ? KC : 1], rbest = rs;
-            if constexpr (KC > 6) {
+            real_t cbest[KC], rbest = rs;
 #pragma unroll
-                for (int i = 0; i < KC; i++) cbest[i] = cx[i];
-            }
+            for (int i = 0; i < KC; i++) cbest[i] = cx[i];
             for (int r = 0; r < kCgMax && rs > rtol2; r++) {
 #ifdef DWBC_QP_TRACE
                 QP_TRACE("  cg %d rs %.3e\n", r, (double)rs);
@@ -432,7 +430,7 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     pap += cp[i] * ap[i];
                 }
                 if (!(pap > real_t(0.0))) break;  // (round-off on a direction without curvature: same case as below)
-                if constexpr (KC > 6) {
+                {
                     // A search direction on which I - H_cc has (numerically) no curvature is a direction of c the working set does not
                     // constrain -- twelve active rows whose contact block has rank 11, seen with two feet and a hand: a step along
                     // it would divide round-off by round-off (c of 1e7).  The lexicographic point has no component there (stage 2
@@ -454,7 +452,7 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                     cr[i] -= al * ap[i];
                     rs2 += cr[i] * cr[i];
                 }
-                if constexpr (KC > 6) {
+                {
                     if (rs2 < rbest) {
                         rbest = rs2;
 #pragma unroll
@@ -466,16 +464,16 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
                 for (int i = 0; i < KC; i++) cp[i] = cr[i] + be * cp[i];
                 rs = rs2;
             }
-            // 18-variable solves: a solve that stopped at such a direction (or ran out of steps around it) has reached what the
+            // A solve that stopped at such a direction (or ran out of steps around it) has reached what the
             // arithmetic allows; it stands if its residual is below kQpNullRes (relative) -- seen: 2e-10 on a foot + a hand
-            if constexpr (KC > 6) {
+            {
                 if (rbest < rs) {
                     rs = rbest;
 #pragma unroll
                     for (int i = 0; i < KC; i++) cx[i] = cbest[i];
                 }
             }
-            settled = !(rs > rtol2) || (KC > 6 && !(rs > kQpNullRes * kQpNullRes * bn));
+            settled = !(rs > rtol2) || !(rs > kQpNullRes * kQpNullRes * bn);
             (void)nulldir;
             (void)cbest;
 #ifdef DWBC_QP_TRACE

@@ -175,3 +175,44 @@ def test_gpu_three_contacts_three_levels_and_scope():
     tau_r2, _, st_r2, _ = _oracle(q, two, fs, tasks=cases.TASKS_3LEVEL_SWING_R)
     ok = st_r2 == 1
     assert np.abs(wbc.get("tau")[ok] - tau_r2[ok]).max() < TOL_TAU
+
+
+# ---- the two-contact product kernels on pairs that include a hand.  Found while pinning the three-contact kernel: a foot and a hand give
+#      J A^-1 J^T rows of 1e-1 next to rows of 1e3 (the unscaled 12 x 12 sweep left the torques 1e-5 Nm off on every such pair) and working
+#      sets whose contact block loses rank (the lexicographic solve blew up and fell back: 8e-3 Nm on one instance in 500)
+PAIRS = [[1, 0, 1, 0], [0, 1, 0, 1], [0, 0, 1, 1], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 0, 0]]
+
+
+@pytest.mark.parametrize("compact", [False, True, "pair"])
+def test_emulated_product_kernels_on_foot_and_hand_pairs(compact):
+    B = 192
+    q, _, fs = cases.synth_batch(B, seed=9100, yaw=True)
+    rng = np.random.default_rng(0)
+    fl = np.array([PAIRS[i] for i in rng.integers(0, len(PAIRS), B)], np.uint8)
+    # instances of the 9100.. sweep that were 4e-3 .. 8e-3 Nm off before the rank rule of the lexicographic solve (QP canon 3)
+    q2, _, fs2 = cases.synth_batch(1024, seed=9101, yaw=True)
+    q, fs, fl = np.vstack([q, q2[[67, 901]]]), np.vstack([fs, fs2[[67, 901]]]), np.vstack([fl, [[0, 1, 1, 0], [1, 0, 1, 0]]]).astype(np.uint8)
+    e = Emu(cases.URDF, cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, compact=compact)
+    tau_r, wr_r, st_r, _ = _oracle(q, fl, fs)
+    ok = st_r == 1
+    assert (r["status"] == st_r).all() and ok.mean() > 0.95
+    assert np.abs(r["tau"][ok] - tau_r[ok]).max() < TOL_TAU
+    assert np.abs(r["wrench"][ok] - wr_r[ok][:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]]).max() < TOL_WR
+
+
+@pytest.mark.gpu
+def test_gpu_product_kernels_on_foot_and_hand_pairs():
+    for B in (1024, 4096):  # the two-wave kernel, the compact one-wave kernel
+        q, _, fs = cases.synth_batch(B, seed=9101, yaw=True)
+        rng = np.random.default_rng(1)
+        fl = np.array([PAIRS[i] for i in rng.integers(0, len(PAIRS), B)], np.uint8)
+        fl[67], fl[901] = [0, 1, 1, 0], [1, 0, 1, 0]
+        wbc = _make_gpu(B)
+        wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
+        wbc.solve()
+        assert "kernel_gc" not in wbc.kernel_name()
+        tau_r, wr_r, st_r, _ = _oracle(q, fl, fs)
+        ok = st_r == 1
+        assert (wbc.get("status") == st_r).all() and ok.mean() > 0.95
+        assert np.abs(wbc.get("tau")[ok] - tau_r[ok]).max() < TOL_TAU

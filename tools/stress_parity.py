@@ -28,6 +28,28 @@ for name, (tasks, kw) in cfgs.items():
         worst = max(worst, float(np.abs(tau[ok] - tr[ok]).max()))
     print(f"{name:7s} instances {tot}  status mismatches {mism}  ok {okc}  max|tau - oracle| {worst:.3e}", flush=True)
 
+# the product (two-contact) kernels on contact pairs that include a hand: four registered contacts, two active per instance
+PAIRS = [[1, 0, 1, 0], [0, 1, 0, 1], [0, 0, 1, 1], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 0, 0]]
+B = 4096
+w = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
+for c in cases.CONTACTS_4: w.add_contact(c["link"], c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+for lv, links in enumerate(cases.TASKS_2LEVEL):
+    for mode, link, pt in links: w.add_task(lv, mode, link, pt)
+w.set_torque_limit(np.array(cases.TAU_LIM))
+S = orc.make_setup(cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
+worst = 0.0; mism = 0; tot = 0; okc = 0
+for seed in range(5):
+    q, _, fs = cases.synth_batch(B, seed=9100 + seed, yaw=True)
+    rng = np.random.default_rng(seed)
+    fl = np.array([PAIRS[i] for i in rng.integers(0, len(PAIRS), B)], np.uint8)
+    w.set_state(q); w.set_contact(fl); w.set_fstar_all(fs); w.solve()
+    tau, st = w.get("tau"), w.get("status")
+    tr, wr, sr, _ = orc.cycle_batch(M, S, q, fl, fs, 16)
+    mism += int((st != sr).sum()); tot += B
+    ok = (st == 1) & (sr == 1); okc += int(ok.sum())
+    worst = max(worst, float(np.abs(tau[ok] - tr[ok]).max()))
+print(f"hand_pairs ({w.kernel_name()[:40]}) instances {tot}  status mismatches {mism}  ok {okc}  max|tau - oracle| {worst:.3e}", flush=True)
+
 # three simultaneously active contacts through the general-contact kernel (dwbc_cycle_gc.h): random contact sets per instance
 def make_gc(B, tasks):
     w = D.Batch(D.Model.from_urdf(cases.URDF), B, device=0)
