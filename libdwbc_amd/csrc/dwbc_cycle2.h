@@ -588,7 +588,6 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
 
 DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *colbuf, real_t *pivratio = nullptr) {
     DWBC_LANE_DECL;
-    (void)colbuf;
     DWBC_SYNC();
     if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo, pivratio);
     // Jacobi scaling: the sweep runs on D^-1 A D^-1, D = sqrt(diag A), and the inverse is scaled back.  The unpivoted sweep's error goes
@@ -598,20 +597,19 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     PLA(real_t, s, 12);
     PL(real_t, dg);
     PL(real_t, dsc);
-    real_t rd[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const real_t a = i < n ? Ain[i * lda + i] : real_t(1.0);
-        rd[i] = a > real_t(0.0) ? real_t(1.0) / sqrt(a) : real_t(1.0);
-    }
+    // (the scale factors go through colbuf: twelve uniform doubles held in registers across the sweep cost the 256-register kernels spills)
     LANES {
         const int col = lane < n ? lane : 0;
-        real_t dc = real_t(1.0);
+        const real_t a = Ain[col * lda + col];
+        LV(dsc) = (lane < n && a > real_t(0.0)) ? real_t(1.0) / sqrt(a) : real_t(1.0);
+        if (lane < 12) colbuf[lane] = LV(dsc);
+    }
+    DWBC_SYNC();
+    LANES {
+        const int col = lane < n ? lane : 0;
+        const real_t dc = LV(dsc);
 #pragma unroll
-        for (int i = 0; i < 12; i++) dc = (col == i) ? rd[i] : dc;
-        LV(dsc) = dc;
-#pragma unroll
-        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] * rd[i] * dc : real_t(0.0);
+        for (int i = 0; i < 12; i++) LV(s)[i] = (lane < n && i < n) ? Ain[i * lda + col] * colbuf[i] * dc : real_t(0.0);
         LV(dg) = (lane < n) ? Ain[col * lda + col] * dc * dc : real_t(1.0);
     }
     const int ok = sweep_inverse_rl<12>(s, dg, n);
@@ -620,7 +618,7 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
         if (lane < n) {
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                if (i < n) Out[i * ldo + lane] = LV(s)[i] * rd[i] * LV(dsc);
+                if (i < n) Out[i * ldo + lane] = LV(s)[i] * colbuf[i] * LV(dsc);
         }
     }
     DWBC_SYNC();

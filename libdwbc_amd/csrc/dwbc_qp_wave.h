@@ -413,69 +413,50 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
             }
             const real_t rtol2 = kQpRefineTol * kQpRefineTol * bn;
             bool nulldir = false;
-            // The best iterate is kept: a step along a direction of small but not negligible curvature (1e-8 seen on a
-            // foot + a hand) can throw away ten digits of an iterate that was already good enough
-            real_t cbest[KC], rbest = rs;
-#pragma unroll
-            for (int i = 0; i < KC; i++) cbest[i] = cx[i];
+            const real_t atol2 = kQpNullRes * kQpNullRes * bn;  // residual (squared) at which a solve that cannot go on stands
             for (int r = 0; r < kCgMax && rs > rtol2; r++) {
 #ifdef DWBC_QP_TRACE
                 QP_TRACE("  cg %d rs %.3e\n", r, (double)rs);
 #endif
                 hmul(cp);
-                real_t ap[KC], pap = real_t(0.0);
+                real_t ap[KC], pap = real_t(0.0), pp = real_t(0.0);
 #pragma unroll
                 for (int i = 0; i < KC; i++) {
                     ap[i] = cp[i] - hcc(i);
                     pap += cp[i] * ap[i];
+                    pp += cp[i] * cp[i];
                 }
-                if (!(pap > real_t(0.0))) break;  // (round-off on a direction without curvature: same case as below)
-                {
-                    // A search direction on which I - H_cc has (numerically) no curvature is a direction of c the working set does not
-                    // constrain -- twelve active rows whose contact block has rank 11, seen with two feet and a hand: a step along
-                    // it would divide round-off by round-off (c of 1e7).  The lexicographic point has no component there (stage 2
-                    // is the least-norm c; the restatement truncates the same direction by rank, oracle _lex_eqp), and neither has
-                    // the start: stop here.
-                    real_t pp = real_t(0.0);
-#pragma unroll
-                    for (int i = 0; i < KC; i++) pp += cp[i] * cp[i];
-#ifdef DWBC_QP_TRACE
-                    QP_TRACE("  cg %d pap/pp %.3e\n", r, (double)(pap / pp));
-#endif
-                    if (pap < kQpNullDir * pp) { nulldir = true; break; }
-                }
+                // A search direction on which I - H_cc has (numerically) no curvature is a direction of c the working set does not
+                // constrain -- a working set whose contact block has lost rank, seen as soon as a HAND is in contact (twelve active rows
+                // of rank 11 on two feet and a hand, six of rank 5 on a foot and a hand): a step along it would divide round-off by
+                // round-off (c of 1e7).  The lexicographic point has no component there (stage 2 is the least-norm c; the restatement
+                // truncates the same direction by rank, oracle _lex_eqp), and neither has the start: stop here.  (pap <= 0: the same
+                // case seen through round-off.)
+                if (!(pap > kQpNullDir * pp)) { nulldir = true; break; }
                 const real_t al = rs * fast_rcp(pap);
+                // a step along a direction of small but not negligible curvature (1e-8 seen) can throw away ten digits of an iterate
+                // that is already good enough: such a step is not taken
                 real_t rs2 = real_t(0.0);
+#pragma unroll
+                for (int i = 0; i < KC; i++) {
+                    const real_t rn = cr[i] - al * ap[i];
+                    rs2 += rn * rn;
+                }
+                if (rs2 > rs && !(rs > atol2)) { nulldir = true; break; }
 #pragma unroll
                 for (int i = 0; i < KC; i++) {
                     cx[i] += al * cp[i];
                     cr[i] -= al * ap[i];
-                    rs2 += cr[i] * cr[i];
-                }
-                {
-                    if (rs2 < rbest) {
-                        rbest = rs2;
-#pragma unroll
-                        for (int i = 0; i < KC; i++) cbest[i] = cx[i];
-                    }
                 }
                 const real_t be = rs2 * fast_rcp(rs);
 #pragma unroll
                 for (int i = 0; i < KC; i++) cp[i] = cr[i] + be * cp[i];
                 rs = rs2;
             }
-            // A solve that stopped at such a direction (or ran out of steps around it) has reached what the
-            // arithmetic allows; it stands if its residual is below kQpNullRes (relative) -- seen: 2e-10 on a foot + a hand
-            {
-                if (rbest < rs) {
-                    rs = rbest;
-#pragma unroll
-                    for (int i = 0; i < KC; i++) cx[i] = cbest[i];
-                }
-            }
-            settled = !(rs > rtol2) || !(rs > kQpNullRes * kQpNullRes * bn);
+            // a solve that stopped at such a direction (or ran out of steps around it) has reached what the arithmetic allows; it stands
+            // if its relative residual is below kQpNullRes (seen: 2e-10 on a foot + a hand)
+            settled = !(rs > rtol2) || !(rs > atol2);
             (void)nulldir;
-            (void)cbest;
 #ifdef DWBC_QP_TRACE
             QP_TRACE("lex: NV %d KC %d t %d k %d q %d rs %.3e rtol2 %.3e bn %.3e settled %d\n", NV, KC, t, k, q, (double)rs, (double)rtol2, (double)bn, (int)settled);
 #endif
