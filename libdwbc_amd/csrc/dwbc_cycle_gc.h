@@ -113,6 +113,43 @@ DWBC_DEVN int spd_inverse_reg(const real_t *Sin, int ld, real_t *Out, int ldo) {
     return ok;
 }
 
+// SPD inverse of the leading n x n block (n <= NN <= 24) by the same register sweep on the Jacobi-scaled matrix D^-1 A D^-1, D = sqrt(diag A)
+// (see spd_inverse_small, dwbc_cycle2.h: a hand next to a foot mixes rows of 1e-1 with rows of 1e3).  Sin (ld) -> Out (ldo), in place allowed;
+// colbuf: NN doubles of LDS.  Used for the Gram matrix of the internal-wrench basis (well conditioned).
+template <int NN>
+DWBC_DEVN int spd_inverse_scaled(const real_t *Sin, int ld, int n, real_t *Out, int ldo, real_t *colbuf) {
+    DWBC_LANE_DECL;
+    PLA(real_t, s, NN);
+    PL(real_t, dg);
+    PL(real_t, dsc);
+    DWBC_SYNC();
+    LANES {
+        const int col = lane < n ? lane : 0;
+        const real_t a = Sin[col * ld + col];
+        LV(dsc) = (lane < n && a > real_t(0.0)) ? real_t(1.0) / sqrt(a) : real_t(1.0);
+        if (lane < NN) colbuf[lane] = LV(dsc);
+    }
+    DWBC_SYNC();
+    LANES {
+        const int col = lane < n ? lane : 0;
+        const real_t dc = LV(dsc);
+#pragma unroll
+        for (int i = 0; i < NN; i++) LV(s)[i] = (lane < n && i < n) ? Sin[i * ld + col] * colbuf[i] * dc : real_t(0.0);
+        LV(dg) = (lane < n) ? Sin[col * ld + col] * dc * dc : real_t(1.0);
+    }
+    const int ok = sweep_inverse_rl<NN>(s, dg, n);
+    DWBC_SYNC();
+    LANES {
+        if (lane < n) {
+#pragma unroll
+            for (int i = 0; i < NN; i++)
+                if (i < n) Out[i * ldo + lane] = LV(s)[i] * colbuf[i] * LV(dsc);
+        }
+    }
+    DWBC_SYNC();
+    return ok;
+}
+
 // QP rows into lanes + solve, for up to NCC contacts (same rows as qp_rows_and_solve of dwbc_cycle.h):
 //   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053, src/wbd.cpp:59-97)
@@ -193,6 +230,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
     const int *topo = io.topo;  // parent[nb] depth[nb] subtree[nb]
     const io_t *qin = io.q + (size_t)inst * (N + 1);
     int *diag = io.diag ? io.diag + (size_t)inst * DG_COUNT : nullptr;
+    DWBC_STAMP_INIT();
 
     // ================= stage 0: kinematics, A, A_inv, G  (src/dwbc.cpp:279-371) =================
     for (int i = th.tid; i < N + 1; i += NT) L[S::q + i] = (real_t)qin[i];
@@ -333,9 +371,11 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         for (int j = th.tid; j < N; j += NT) L[S::G + j] = kGrav * A[2 * N + j];  // G_ = -J_com_lin^T m g (dwbc.cpp:358)
     }
+    DWBC_STAMP(0);  // kinematics + CRBA
     int st_contact = 1;
     // A_inv = llt(A).solve(I)  (dwbc.cpp:307), in place (the columns live in registers meanwhile)
     if (!spd_inverse_reg<N>(L + S::bufA, N, L + S::bufA, N)) st_contact = 0;
+    DWBC_STAMP(1);  // A^-1
 
     // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
     const unsigned char *fl = io.flags + (size_t)inst * su.n_contacts;
@@ -374,11 +414,14 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);      // J A^-1 J^T
         if (cd > 0) {
-            const real_t cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);  // Lambda_c (wbd.cpp:115)
+            // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan in LDS, as the reference's .inverse() -- 45 k cycles for 18 x 18, and worth them: the
+            // scaled register sweep (spd_inverse_scaled) left two three-contact instances in 6000 at 3e-6 .. 5e-6 Nm
+            const real_t cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
             if (!(cond > real_t(1e-14))) st_contact = 0;
         }
         mm_nn<NT>(th, JbT, N, Lam, cd, Y, N, cd, cd, N);             // Jbar^T = Lambda J A^-1 (wbd.cpp:116)
         DWBC_SYNC();
+        DWBC_STAMP(2);  // J_C, Y, Lambda_c, Jbar
         // A^-1 N_c = A^-1 - Y^T Jbar^T   (wbd.cpp:117-118 without materialising N_c)
         for (int idx = th.tid; idx < N * N; idx += NT) {
             const int i = idx / N, j = idx - i * N;
@@ -388,6 +431,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             AiNc[idx] = s;
         }
         DWBC_SYNC();
+        DWBC_STAMP(3);  // A^-1 N_c
         // ---- W^+ and NwJw.  null(W) is known in closed form: W = S A^-1 N_c S^T vanishes exactly on
         //      { J_C[:,6:]^T lam : J_C[:,:6]^T lam = 0 } (internal wrenches), so V2's span needs no pivoted QR (wbd.cpp:5-53, 120-128)
         real_t *Winv = L + S::bufA;  // A_inv is dead from here on
@@ -413,26 +457,30 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 Vb[idx] = s;
             }
             DWBC_SYNC();
-            // NwJw = Vb (Jbar[0:k,6:] Vb)^-1   (wbd.cpp:128; invariant to the choice of basis of span(V2^T))
+            // G = Vb^T Vb, G^-1, VG = Vb G^-1;  projector on null(W):  P = VG Vb^T
+            real_t *Gm = L + S::c_s2, *cb = L + S::c_s1;
+            mm_tn<NT>(th, Gm, k, Vb, k, Vb, k, k, M, k);
+            spd_inverse_scaled<S::K>(Gm, k, k, Gm, k, cb);
+            mm_nn<NT>(th, L + S::c_VG, k, Vb, k, Gm, k, M, k, k);
+            DWBC_SYNC();
+            mm_nt<NT>(th, P, M, L + S::c_VG, k, Vb, k, M, k, M);
+            DWBC_SYNC();
+            // NwJw = Vb (Jbar[0:k,6:] Vb)^-1   (wbd.cpp:128; invariant to the choice of basis of span(V2^T)).  Jbar1 Vb is a general k x k
+            // matrix: pivoted Gauss-Jordan, as the reference's .inverse().  (The SPD-only form of the product kernels, VG JV^T (JV G^-1 JV^T)^-1,
+            // squares its condition number: measured 5e-6 Nm on one three-contact instance in 6000, 1e-8 with the direct inverse.)
             for (int idx = th.tid; idx < k * k; idx += NT) {
                 const int i = idx / k, j = idx - i * k;
                 real_t s = real_t(0.0);
                 _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * Vb[c * k + j];
-                L[S::c_s2 + idx] = s;
+                for (int c2 = 0; c2 < M; c2++) s += JbT[i * N + 6 + c2] * Vb[c2 * k + j];
+                Gm[idx] = s;
             }
-            const real_t cond = gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
+            const real_t cond = gj_inverse<NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
             if (!(cond > real_t(1e-13))) st_contact = 0;
-            mm_nn<NT>(th, L + S::NwJw, k, Vb, k, L + S::c_s2, k, M, k, k);
-            DWBC_SYNC();
-            // projector on null(W):  P = Vb (Vb^T Vb)^-1 Vb^T
-            mm_tn<NT>(th, L + S::c_s2, k, Vb, k, Vb, k, k, M, k);
-            gj_inverse<NT>(th, L + S::c_s2, k, k, L + S::c_s2, k, L + S::c_s1);
-            mm_nn<NT>(th, L + S::c_VG, k, Vb, k, L + S::c_s2, k, M, k, k);  // (M x k) = Vb G^-1
-            DWBC_SYNC();
-            mm_nt<NT>(th, P, M, L + S::c_VG, k, Vb, k, M, k, M);
+            mm_nn<NT>(th, L + S::NwJw, k, Vb, k, Gm, k, M, k, k);
             DWBC_SYNC();
         }
+        DWBC_STAMP(4);  // Vb, NwJw, projector
         // alpha = trace(W) / M;  W + alpha P is SPD;  W^+ = (W + alpha P)^-1 - P / alpha
         real_t alpha = real_t(0.0);
         for (int i = 0; i < M; i++) alpha += AiNc[(6 + i) * N + 6 + i];
@@ -450,6 +498,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             for (int idx = th.tid; idx < M * M; idx += NT) Winv[idx] = W1[idx] - (k > 0 ? P[idx] * ia : real_t(0.0));  // (in place: Winv is W1)
             DWBC_SYNC();
         }
+        DWBC_STAMP(5);  // W^+
         // FNl = A_rot (Jbar[:,6:] NwJw)   (cd x k), contact-local frames
         if (k > 0) {
             for (int idx = th.tid; idx < cd * k; idx += NT) {
@@ -476,6 +525,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
         DWBC_SYNC();
     }
+    DWBC_STAMP(6);  // FNl, gravity torque, P_C
 
     // ================= stage 3: task cascade (dwbc.cpp:685-873, 941-1127; wbd.cpp:207-261) =================
     const int nlim = su.has_tau_lim ? 2 * M : 0;
@@ -573,6 +623,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             // --- QP rows (dwbc.cpp:988-1053)
+            if (lv < 2) DWBC_STAMP(7 + 3 * lv);  // level lv: task Jacobian, J_kt, null-space chain
             const io_t *fs = fs_in + su.fstar_off[lv];
             real_t *base = L + S::t_base, *F = L + S::t_F, *fv = L + S::t_fv;
             for (int i = th.tid; i < M; i += NT) {
@@ -599,9 +650,11 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 if (j < t) F[i * T + j] = v; else fv[i] = v;
             }
             DWBC_SYNC();
+            if (lv < 2) DWBC_STAMP(8 + 3 * lv);  // level lv: QP inputs
             QpResultT<QN> qres;
             qp_rows_and_solve_gc<N, NCC>(su, nlim, ncone, act_c, U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, T, L + S::FNl, k, fv, base, t,
                                          su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x, kQpTol);
+            if (lv < 2) DWBC_STAMP(9 + 3 * lv);  // level lv: QP solved
             if (diag && th.tid == 0) {
                 diag[DG_QP_ITER + lv] = qres.iters;
                 diag[DG_QP_NACT + lv] = qres.nact;
@@ -667,6 +720,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);  // dwbc.cpp:1562-1567
     }
     DWBC_SYNC();
+    DWBC_STAMP(13);  // redistribution QP
 
     // ================= outputs =================
     io_t *tau = io.tau + (size_t)inst * 3 * M;
