@@ -13,7 +13,10 @@ for c in cases.CONTACTS_4: w.add_contact(c["link"], c["point"], c["lx"], c["ly"]
 for lv, links in enumerate(cases.TASKS_2LEVEL):
     for mode, link, pt in links: w.add_task(lv, mode, link, pt)
 w.set_torque_limit(np.array(cases.TAU_LIM)); w.set_max_active_contacts(3)
-for seed in range(3):
+import sys as _s
+NS = int(_s.argv[1]) if len(_s.argv) > 1 else 3
+if len(_s.argv) > 2: sets = [[int(a) for a in _s.argv[2]]]
+for seed in range(NS):
     q, _, fs = cases.synth_batch(B, seed=9100 + seed, yaw=True)
     rng = np.random.default_rng(seed)
     fl = np.array([sets[i] for i in rng.integers(0, len(sets), B)], np.uint8)

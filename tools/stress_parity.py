@@ -12,13 +12,14 @@ def make(B, tasks):
     for lv, links in enumerate(tasks):
         for mode, link, pt in links: w.add_task(lv, mode, link, pt)
     w.set_torque_limit(np.array(cases.TAU_LIM)); return w
+NS = int(os.environ.get("STRESS_SEEDS", "5"))  # seeds per configuration (STRESS_SEEDS=20 for a long soak)
 B = 4096
 cfgs = {"ds": (cases.TASKS_2LEVEL, {}), "ds_yaw": (cases.TASKS_2LEVEL, dict(yaw=True)), "mixed": (cases.TASKS_2LEVEL, dict(contact_mode="mixed")),
         "ss_L": (cases.TASKS_3LEVEL_SWING_R, dict(contact_mode="L", levels=3)), "ss_R": (cases.TASKS_3LEVEL_SWING_L, dict(contact_mode="R", levels=3))}
 for name, (tasks, kw) in cfgs.items():
     w = make(B, tasks); S = orc.make_setup(cases.CONTACTS_2, tasks, cases.TAU_LIM)
     worst = 0.0; mism = 0; tot = 0; okc = 0
-    for seed in range(5):
+    for seed in range(NS):
         q, fl, fs = cases.synth_batch(B, seed=9000 + seed, **kw)
         w.set_state(q); w.set_contact(fl); w.set_fstar_all(fs); w.solve()
         tau, st = w.get("tau"), w.get("status")
@@ -38,7 +39,7 @@ for lv, links in enumerate(cases.TASKS_2LEVEL):
 w.set_torque_limit(np.array(cases.TAU_LIM))
 S = orc.make_setup(cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
 worst = 0.0; mism = 0; tot = 0; okc = 0
-for seed in range(5):
+for seed in range(NS):
     q, _, fs = cases.synth_batch(B, seed=9100 + seed, yaw=True)
     rng = np.random.default_rng(seed)
     fl = np.array([PAIRS[i] for i in rng.integers(0, len(PAIRS), B)], np.uint8)
@@ -63,7 +64,7 @@ B = 2048
 for name, sets in SETS.items():
     w = make_gc(B, cases.TASKS_2LEVEL); S = orc.make_setup(cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
     worst = 0.0; worstw = 0.0; mism = 0; tot = 0; okc = 0
-    for seed in range(3):
+    for seed in range(max(3, NS * 3 // 5)):
         q, _, fs = cases.synth_batch(B, seed=9100 + seed, yaw=True)
         rng = np.random.default_rng(seed)
         fl = np.array([sets[i] for i in rng.integers(0, len(sets), B)], np.uint8)
