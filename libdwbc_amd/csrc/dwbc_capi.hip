@@ -112,7 +112,7 @@ int dwbc_model_get_arrays(const dwbc_model *mm, int32_t *parent, double *R_T, do
 //      generic (any tree of its size) or built for one parent table (TopoPack: the tree-sparse sweep); the latter is preferred
 //      when its table equals the model's
 namespace {
-struct KernelPack { void *dl; const KernelEntry *tab; int count; std::vector<int> parents; };  // parents empty: generic
+struct KernelPack { void *dl; const KernelEntry *tab; int count; std::vector<int> parents; GcEntry gc; };  // parents empty: generic; gc.fn: the size's general-contact kernel or nullptr
 std::vector<KernelPack> g_packs;
 std::mutex g_pack_mutex;
 bool builtin_has(int n, int nb) {
@@ -140,6 +140,14 @@ const KernelEntry *pack_lookup(int n, int nb, int nlv, const std::vector<int> &p
             if (p.tab[i].n == n && p.tab[i].nb == nb && (nlv < 0 || p.tab[i].nlv == nlv)) return &p.tab[i];
     }
     return nullptr;
+}
+// the general-contact kernel of a model size: built in (TOCABI) or from a loaded pack of that size
+GcEntry find_gc(int n, int nb) {  // fn == nullptr: none
+    if (const GcEntry *g = lookup_gc(n, nb)) return *g;
+    std::lock_guard<std::mutex> lk(g_pack_mutex);
+    for (const auto &p : g_packs)
+        if (p.gc.fn && p.gc.n == n && p.gc.nb == nb) return p.gc;
+    return GcEntry{0, 0, nullptr, 0};
 }
 const KernelEntry *pack_pick(int n, int nb, int nlv, const std::vector<int> &parents) {
     if (const KernelEntry *ke = pack_lookup(n, nb, nlv, parents, false)) return ke;
@@ -170,7 +178,13 @@ int try_load_pack(const std::string &path, const std::vector<int> &parents, bool
         err = path + " was built from another version of the kernels: rebuild it (make -C libdwbc_amd/csrc pack ...)";
         return -1;
     }
-    KernelPack kp{dl, tab, count, {}};
+    KernelPack kp{dl, tab, count, {}, GcEntry{0, 0, nullptr, 0}};
+    typedef const void *(*gc_fn)(int *);
+    if (gc_fn gf = (gc_fn)dlsym(dl, "dwbc_pack_gc")) {
+        int lds = 0;
+        const void *fn = gf(&lds);
+        if (fn && count > 0) kp.gc = GcEntry{tab[0].n, tab[0].nb, reinterpret_cast<void (*)(const Setup, const BatchIO)>(const_cast<void *>(fn)), lds};
+    }
     if (pf) {
         int pnb = 0;
         const int *pp = pf(&pnb);
@@ -464,7 +478,7 @@ int dwbc_batch_set_max_active_contacts(dwbc_batch *b, int n) {
     if (n == b->max_active) return 1;
     if (n > 2) {
         if (b->dtype == DWBC_F32) return fail("three active contacts: fp64 batches only");
-        if (!lookup_gc(b->n, b->su.nb)) return fail("no general-contact kernel for this model size");
+        if (!find_gc(b->n, b->su.nb).fn) return fail("no general-contact kernel for this model size (built in for TOCABI; kernel packs carry one for models of at most 40 dof)");
     }
     if (!b->own_wrench) return fail("wrench is bound to a device buffer: set the contact capacity before binding");
     HIP_OK(hipStreamSynchronize(b->stream));
@@ -654,8 +668,8 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
 
 // three active contacts: every instance of the batch goes through the general-contact kernel (lean scope)
 static int launch_gc(dwbc_batch *b) {
-    const GcEntry *g = lookup_gc(b->n, b->su.nb);
-    if (!g) return fail("no general-contact kernel for this model size");
+    const GcEntry gc_ = find_gc(b->n, b->su.nb), *g = &gc_;
+    if (!g->fn) return fail("no general-contact kernel for this model size (built in for TOCABI; kernel packs carry one for models of at most 40 dof)");
     if (!b->hqp) return fail("three active contacts: hqp = true only (the reference's closed-form redistribution is written for two contacts, src/dwbc.cpp:1570-1619)");
     if (b->su.n_traj > 0 || b->su.has_com_task || b->su.n_custom > 0 || b->dump_on)
         return fail("three active contacts: link tasks with f* from SetTaskSpace only (no trajectories, COM or custom levels, no dump record)");
@@ -984,9 +998,9 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
     if (b->max_active > 2) {
-        const GcEntry *g = lookup_gc(b->n, b->su.nb);
+        const GcEntry g = find_gc(b->n, b->su.nb);
         if (threads) *threads = kNT;
-        if (lds) *lds = g ? g->lds_bytes : 0;
+        if (lds) *lds = g.fn ? g.lds_bytes : 0;
         return 1;
     }
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);

@@ -58,8 +58,7 @@ struct LdsG {
     //     dead by then).  78 KB instead of 93: two workgroups per CU.
     static constexpr int c_P = tmp;                   // M x M projector on null(W)
     static constexpr int c_Y = tmp;                   // J_C A^-1 (C x N)
-    static_assert(C * N <= M * M, "Y fits under P");
-    static constexpr int c_Vb = c_P + M * M;          // M x k
+    static constexpr int c_Vb = c_P + max2(M * M, C * N);  // M x k (behind P and behind Y, whichever reaches further: small models)
     static constexpr int c_s1 = c_Vb + M * K;         // C x 2C Gauss-Jordan scratch
     static constexpr int c_s2 = c_s1 + C * 2 * C;     // C x C
     static constexpr int c_VG = c_s2 + C * C;         // M x k: Vb G^-1

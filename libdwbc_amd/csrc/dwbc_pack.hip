@@ -43,6 +43,14 @@ extern "C" const int *dwbc_pack_parents(int *nb) {
     return TopoPack::parent;
 }
 #endif
+// the general-contact kernel (dwbc_cycle_gc.h: up to three simultaneously active contacts) of this model size, when its QP rows fit one
+// per lane ((N - 6) torque rows + 30 cone rows <= 64)
+#if (DWBC_PACK_N - 6 + 10 * 3) <= 64
+extern "C" const void *dwbc_pack_gc(int *lds_bytes) {
+    *lds_bytes = LdsG<DWBC_PACK_N, DWBC_PACK_NB, kGcContacts>::total_bytes;
+    return reinterpret_cast<const void *>(dwbc_cycle_kernel_gc<DWBC_PACK_N, DWBC_PACK_NB, kNT>);
+}
+#endif
 extern "C" const KernelEntry *dwbc_pack_table(int *count, unsigned *abi_tag) {
     *count = (int)(sizeof(kPack) / sizeof(kPack[0]));
     *abi_tag = kernel_abi_tag();

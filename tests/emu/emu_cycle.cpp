@@ -234,7 +234,8 @@ int emu_run(EmuCtx *c, int B, const double *q, const unsigned char *flags, const
 // the general-contact kernel of dwbc_cycle_gc.h (up to three active contacts; wrench: B x 18), LDS poisoned per instance
 int emu_run_gc(EmuCtx *c, int B, const double *q, const unsigned char *flags, const double *fstar, double *tau, double *wrench,
                int *status, int *diag) {
-    if (c->model.ndof != 39 || c->model.nb != 34) { c->err = "emu is instantiated for TOCABI (39 dof) only"; return 0; }
+    const int n_ = c->model.ndof, nb_ = c->model.nb;
+    if (!((n_ == 39 && nb_ == 34) || (n_ == 37 && nb_ == 32) || (n_ == 23 && nb_ == 18))) { c->err = "emu_run_gc: instantiated for (39, 34), (37, 32) and (23, 18)"; return 0; }
     auto rb = to_real(c->body.data(), c->body.size());
     BatchIO io{};
     io.B = B;
@@ -250,9 +251,12 @@ int emu_run_gc(EmuCtx *c, int B, const double *q, const unsigned char *flags, co
     io.topo = c->topo.data();
     io.hqp = 1;
     std::vector<real_t> lds(LdsG<39, 34, 3>::total + 64);
+    static_assert(LdsG<37, 32, 3>::total <= LdsG<39, 34, 3>::total && LdsG<23, 18, 3>::total <= LdsG<39, 34, 3>::total, "one buffer");
     for (int b = 0; b < B; b++) {
         std::fill(lds.begin(), lds.end(), std::numeric_limits<real_t>::quiet_NaN());
-        cycle_instance_gc<39, 34, 3, 1>(Thr{0}, c->su, io, b, lds.data());
+        if (n_ == 39) cycle_instance_gc<39, 34, 3, 1>(Thr{0}, c->su, io, b, lds.data());
+        else if (n_ == 37) cycle_instance_gc<37, 32, 3, 1>(Thr{0}, c->su, io, b, lds.data());
+        else cycle_instance_gc<23, 18, 3, 1>(Thr{0}, c->su, io, b, lds.data());
     }
     return 1;
 }

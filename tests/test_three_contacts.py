@@ -216,3 +216,69 @@ def test_gpu_product_kernels_on_foot_and_hand_pairs():
         ok = st_r == 1
         assert (wbc.get("status") == st_r).all() and ok.mean() > 0.95
         assert np.abs(wbc.get("tau")[ok] - tau_r[ok]).max() < TOL_TAU
+
+
+# ---- three contacts on a model of another size (kernel packs carry the general-contact kernel for models of at most 40 dof)
+def _variant37(tmp_path):
+    from oracle import urdf_model
+
+    path = cases.variant_urdf(tmp_path / "fixed_head.urdf", cases.HEAD_JOINTS)
+    mo = urdf_model.load_urdf(path)
+    names = list(mo["names"])
+    links = [names.index(n) for n in ("L_AnkleRoll_Link", "R_AnkleRoll_Link", "L_Wrist2_Link", "Upperbody_Link")]
+    return path, mo, links
+
+
+def _oracle37(mo, links, q, fl, fs, lim):
+    M = orc.make_model(mo)
+    contacts = [dict(c, link=l) for c, l in zip(cases.CONTACTS_4[:3], links[:3])]
+    S = orc.make_setup(contacts, [[(0, 0, (0, 0, 0))], [(6, links[3], (0, 0, 0))]], lim)
+    return contacts, orc.cycle_batch(M, S, q, fl, fs, 0)
+
+
+def test_emulated_general_contact_kernel_on_a_37_dof_model(tmp_path):
+    from tests.test_model_packs import variant_states
+
+    path, mo, links = _variant37(tmp_path)
+    B = 8
+    q, fs = variant_states(mo, B, seed=13)
+    fl = np.tile(np.array([1, 1, 1], np.uint8), (B, 1))
+    fl[1], fl[2] = [1, 0, 1], [1, 1, 0]
+    lim = np.full(31, 300.0)
+    contacts, (tau_r, wr_r, st_r, _) = _oracle37(mo, links, q, fl, fs, lim)
+    e = Emu(path, contacts, [[(0, 0, (0, 0, 0))], [(6, links[3], (0, 0, 0))]], lim)
+    r = e.run_gc(q, fl, fs)
+    ok = st_r == 1
+    assert (r["status"] == st_r).all() and ok.all()
+    assert np.abs(r["tau"] - tau_r).max() < TOL_TAU
+    assert np.abs(r["wrench"] - wr_r[:, :18]).max() < TOL_WR
+
+
+@pytest.mark.gpu
+def test_gpu_three_contacts_on_a_37_dof_model_through_its_kernel_pack(tmp_path):
+    import libdwbc_amd as D
+    from tests.test_model_packs import variant_states
+
+    path, mo, links = _variant37(tmp_path)
+    md = D.Model.from_urdf(path)
+    cases.ensure_pack(md)
+    B = 96
+    q, fs = variant_states(mo, B, seed=17)
+    fl = np.tile(np.array([1, 1, 1], np.uint8), (B, 1))
+    fl[::5] = [1, 0, 1]
+    lim = np.full(31, 300.0)
+    contacts, (tau_r, wr_r, st_r, _) = _oracle37(mo, links, q, fl, fs, lim)
+    wbc = D.Batch(md, B, device=0)
+    for c in contacts:
+        wbc.add_contact(md.link_id(mo["names"][c["link"]]), c["point"], c["lx"], c["ly"], c["mu"], c["muz"])
+    wbc.add_task(0, D.TASK_LINK_6D, 0)
+    wbc.add_task(1, D.TASK_LINK_ROTATION, md.link_id("Upperbody_Link"))
+    wbc.set_torque_limit(lim)
+    wbc.set_max_active_contacts(3)
+    wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
+    wbc.solve()
+    assert "dwbc_cycle_kernel_gc<37, 32, 64>" in wbc.kernel_name()
+    ok = st_r == 1
+    assert (wbc.get("status") == st_r).all() and ok.mean() > 0.9
+    assert np.abs(wbc.get("tau")[ok] - tau_r[ok]).max() < TOL_TAU
+    assert np.abs(wbc.get("wrench")[ok] - wr_r[ok][:, :18]).max() < TOL_WR
