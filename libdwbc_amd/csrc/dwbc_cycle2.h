@@ -590,10 +590,10 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     DWBC_LANE_DECL;
     DWBC_SYNC();
     if (n <= 6) return spd_inverse_chol6(Ain, lda, n, Out, ldo, pivratio);
-    // Jacobi scaling: the sweep runs on D^-1 A D^-1, D = sqrt(diag A), and the inverse is scaled back.  The unpivoted sweep's error goes
+    // Jacobi scaling: the sweep runs on D^-1 A D^-1, D ~ sqrt(diag A) rounded to a power of two, and the inverse is scaled back.  The unpivoted sweep's error goes
     // with the condition number it sees, and J A^-1 J^T of a foot and a HAND mixes rows of 1e-1 with rows of 1e3 (light links): unscaled,
     // A^-1 N_c came out 4e-11 (relative) off and W^+ -- which amplifies it by 1 / lambda_min(W)^2 -- 2.5e-7, the torques 1e-5 Nm
-    // against the restatement on every foot + hand pair (feet only: 1e-10).  The scaled matrix has a unit diagonal.
+    // against the restatement on every foot + hand pair (feet only: 1e-10).  The scaled matrix has its diagonal in [0.5, 2).
     PLA(real_t, s, 12);
     PL(real_t, dg);
     PL(real_t, dsc);
@@ -601,7 +601,10 @@ DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, 
     LANES {
         const int col = lane < n ? lane : 0;
         const real_t a = Ain[col * lda + col];
-        LV(dsc) = (lane < n && a > real_t(0.0)) ? real_t(1.0) / sqrt(a) : real_t(1.0);
+        // a power of two next to 1 / sqrt(a): the scaling is then exact (no rounding of its own) and costs two instructions
+        int e2 = 0;
+        (void)frexp(a > real_t(0.0) ? a : real_t(1.0), &e2);
+        LV(dsc) = (lane < n && a > real_t(0.0)) ? ldexp(real_t(1.0), -(e2 >> 1)) : real_t(1.0);
         if (lane < 12) colbuf[lane] = LV(dsc);
     }
     DWBC_SYNC();

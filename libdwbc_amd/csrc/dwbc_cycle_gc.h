@@ -125,7 +125,10 @@ DWBC_DEVN int spd_inverse_scaled(const real_t *Sin, int ld, int n, real_t *Out, 
     LANES {
         const int col = lane < n ? lane : 0;
         const real_t a = Sin[col * ld + col];
-        LV(dsc) = (lane < n && a > real_t(0.0)) ? real_t(1.0) / sqrt(a) : real_t(1.0);
+        // a power of two next to 1 / sqrt(a): the scaling is then exact (no rounding of its own) and costs two instructions
+        int e2 = 0;
+        (void)frexp(a > real_t(0.0) ? a : real_t(1.0), &e2);
+        LV(dsc) = (lane < n && a > real_t(0.0)) ? ldexp(real_t(1.0), -(e2 >> 1)) : real_t(1.0);
         if (lane < NN) colbuf[lane] = LV(dsc);
     }
     DWBC_SYNC();
