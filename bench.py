@@ -315,6 +315,7 @@ def make_line(args, world, dt, kern_ms, status_ok, info, backend):
             "lds_bytes_per_instance": info["lds"],
             "status_ok_fraction": status_ok,
             "collective_backend": {None: "none (one rank)", "nccl": "rccl"}.get(backend, backend),
+            "untimed_ramp_launches": (lambda r: (400 if args.batch <= 4096 else 40) if r < 0 else r)(getattr(args, "ramp", 0)),
         },
         "roofline": {
             "bound": ROOF_BOUND,
