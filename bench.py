@@ -13,6 +13,9 @@ processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFO
 GPU and exits with their status.  Under torchrun (WORLD_SIZE set) it is a rank.  DWBC_BENCH_BACKEND=gloo rehearses the
 multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the gather goes through host tensors).
 
+Timing: an untimed ramp (--ramp, default 400 launches; a fresh context runs its first ~100 launches 3-5 % slow), W untimed
+warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
