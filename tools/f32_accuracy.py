@@ -19,7 +19,7 @@ B = args.batch
 M = orc.make_model(cases.tocabi_model())
 CFG = [("double support, flat feet", {}, cases.TASKS_2LEVEL), ("double support, random yaw + 0.1 rad tilt", dict(yaw=True), cases.TASKS_2LEVEL),
        ("left single support + swing foot", dict(contact_mode="L", levels=3), cases.TASKS_3LEVEL_SWING_R), ("mixed contact modes", dict(contact_mode="mixed"), cases.TASKS_2LEVEL)]
-for name, kw, tasks in CFG:
+for name, kw, tasks in [c_ for c_ in CFG if not (os.environ.get("F32_TWO_LEVEL_ONLY") and c_[1].get("levels") == 3)]:
     q, fl, fs = cases.synth_batch(B, seed=1234, **kw)
     S = orc.make_setup(cases.CONTACTS_2, tasks, cases.TAU_LIM)
     tau, wr, st, _ = orc.cycle_batch(M, S, q, fl, fs, len(os.sched_getaffinity(0)))
