@@ -152,6 +152,62 @@ DWBC_DEVN int spd_inverse_scaled(const real_t *Sin, int ld, int n, real_t *Out, 
     return ok;
 }
 
+// Gauss-Jordan inverse with partial pivoting (gj_inverse of dwbc_cycle.h; stands in for Eigen's .inverse(), reference src/wbd.cpp:115,128)
+// for one wavefront and n <= 64: the pivot search is one LDS read per lane and a wave arg-max instead of n dependent reads by every lane
+// (18 x 70 cycles per pivot).  W: n x 2n scratch.  Returns min |pivot| / max |pivot|.
+template <int NT>
+DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t *Ai, int ldi, real_t *W) {
+    DWBC_LANE_DECL;
+    const int w = 2 * n;
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < n * w; idx += NT) {
+        int i = idx / w, j = idx - i * w;
+        W[idx] = j < n ? A[i * lda + j] : (j - n == i ? real_t(1.0) : real_t(0.0));
+    }
+    real_t pmin = kF32 ? real_t(1e30) : real_t(1e300), pmax = real_t(0.0);
+    PL(real_t, pv);
+    PL(int, pk);
+    for (int c = 0; c < n; c++) {
+        DWBC_SYNC();
+        LANES {
+            const bool in = lane >= c && lane < n;
+            LV(pv) = in ? -fabs(W[(in ? lane : c) * w + c]) : DWBC_QP_INF;
+            LV(pk) = lane;
+        }
+        real_t bneg;
+        int p;
+        WAVE_ARGMIN(pv, pk, bneg, p);
+        const real_t best = -bneg;
+        pmin = best < pmin ? best : pmin;
+        pmax = best > pmax ? best : pmax;
+        DWBC_SYNC();
+        if (p != c)
+            for (int j = th.tid; j < w; j += NT) { real_t t = W[c * w + j]; W[c * w + j] = W[p * w + j]; W[p * w + j] = t; }
+        DWBC_SYNC();
+        const real_t piv = W[c * w + c];
+        const real_t inv = piv != real_t(0.0) ? real_t(1.0) / piv : real_t(0.0);
+        DWBC_SYNC();
+        for (int j = th.tid; j < w; j += NT) W[c * w + j] *= inv;
+        DWBC_SYNC();
+        // eliminate: element (i, j) -= W[i][c] * W[c][j]; column c itself is read before it is overwritten
+        for (int idx = th.tid; idx < n * w; idx += NT) {
+            int i = idx / w, j = idx - i * w;
+            if (i == c || j == c) continue;
+            W[idx] -= W[i * w + c] * W[c * w + j];
+        }
+        DWBC_SYNC();
+        for (int i = th.tid; i < n; i += NT)
+            if (i != c) W[i * w + c] = real_t(0.0);
+    }
+    DWBC_SYNC();
+    for (int idx = th.tid; idx < n * n; idx += NT) {
+        int i = idx / n, j = idx - i * n;
+        Ai[i * ldi + j] = W[i * w + n + j];
+    }
+    DWBC_SYNC();
+    return pmax > real_t(0.0) ? pmin / pmax : real_t(0.0);
+}
+
 // QP rows into lanes + solve, for up to NCC contacts (same rows as qp_rows_and_solve of dwbc_cycle.h):
 //   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053, src/wbd.cpp:59-97)
@@ -159,13 +215,19 @@ template <int N, int NCC>
 DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const int *act_c, const real_t *P1, int ld1, int t1,
                                    const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1, const real_t *W2, int ldw2,
                                    const real_t *fv, const real_t *base, int tvars, int max_iter, QpResultT<kMaxTaskDof + 6 * NCC - 6> &res,
-                                   real_t *Vlds, real_t *xlds, real_t vtol) {
+                                   real_t *Vlds, real_t *xlds, real_t vtol, bool fixed_layout = false) {
     constexpr int M = N - 6, QN = kMaxTaskDof + 6 * NCC - 6;
     static_assert(M + 10 * NCC <= 64, "one QP row per lane");
     DWBC_LANE_DECL;
     QpRowsT<QN> R;
     PL(real_t, sfin);
-    const int nv = t1 + t2;
+    // fixed_layout (the task QPs): the task variables take positions 0 .. 5 and the contact-null variables positions 6 .. 17 whatever t and k
+    // are, the unused positions are zero columns (variables no row touches stay zero).  The solver then always sees (t, k) = (6, 12), the layout
+    // whose lexicographic solve has compile-time positions; with the packed layout a three-dof level (t = 3) or two contacts (k = 6) went
+    // through per-entry selects (216 per product with H).  x comes back in the same positions.
+    const int off2 = fixed_layout ? kMaxTaskDof : t1;
+    const int nv = fixed_layout ? QN : t1 + t2;
+    if (fixed_layout) tvars = kMaxTaskDof;
     LANES {
 #pragma unroll
         for (int j = 0; j < QN; j++) LV(R.g)[j] = real_t(0.0);
@@ -179,7 +241,7 @@ DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const i
                 for (int j = 0; j < QN; j++) {
                     real_t v = real_t(0.0);
                     if (j < t1) v = P1[lane * ld1 + j];
-                    else if (j < nv) v = P2[lane * ld2 + (j - t1)] * s2;
+                    else if (j >= off2 && j < off2 + t2) v = P2[lane * ld2 + (j - off2)] * s2;
                     LV(R.g)[j] = v;
                 }
                 LV(R.hi) = (real_t)su.tau_lim[lane] - base[lane];
@@ -200,7 +262,7 @@ DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const i
             for (int j = 0; j < QN; j++) {
                 real_t v = real_t(0.0);
                 if (j < t1) v = c2 * W1[row2 * ldw1 + j] + sg * W1[rowo * ldw1 + j];
-                else if (j < nv) v = (c2 * W2[row2 * ldw2 + (j - t1)] + sg * W2[rowo * ldw2 + (j - t1)]) * s2;
+                else if (j >= off2 && j < off2 + t2) v = (c2 * W2[row2 * ldw2 + (j - off2)] + sg * W2[rowo * ldw2 + (j - off2)]) * s2;
                 LV(R.g)[j] = -v;
             }
             LV(R.hi) = c2 * fv[row2] + sg * fv[rowo];
@@ -418,7 +480,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         if (cd > 0) {
             // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan in LDS, as the reference's .inverse() -- 45 k cycles for 18 x 18, and worth them: the
             // scaled register sweep (spd_inverse_scaled) left two three-contact instances in 6000 at 3e-6 .. 5e-6 Nm
-            const real_t cond = gj_inverse<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
+            const real_t cond = gj_inverse_wave<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
             if (!(cond > real_t(1e-14))) st_contact = 0;
         }
         mm_nn<NT>(th, JbT, N, Lam, cd, Y, N, cd, cd, N);             // Jbar^T = Lambda J A^-1 (wbd.cpp:116)
@@ -477,7 +539,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 for (int c2 = 0; c2 < M; c2++) s += JbT[i * N + 6 + c2] * Vb[c2 * k + j];
                 Gm[idx] = s;
             }
-            const real_t cond = gj_inverse<NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
+            const real_t cond = gj_inverse_wave<NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
             if (!(cond > real_t(1e-13))) st_contact = 0;
             mm_nn<NT>(th, L + S::NwJw, k, Vb, k, Gm, k, M, k, k);
             DWBC_SYNC();
@@ -561,7 +623,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             mm_nn<NT>(th, T1, N, Jt, N, AiNc, N, t, N, N);           // J_t A^-1 N_c
             DWBC_SYNC();
             mm_nt<NT>(th, L + S::t_s2, t, T1, N, Jt, N, t, N, t);
-            gj_inverse<NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task (plain inverse, wbd.cpp:210)
+            gj_inverse_wave<NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task (plain inverse, wbd.cpp:210)
             for (int idx = th.tid; idx < t * M; idx += NT) {             // Q = (Lambda J A^-1 N_c)[:,6:]
                 const int i = idx / M, j = idx - i * M;
                 real_t s = real_t(0.0);
@@ -575,7 +637,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             // PinvCODWB (wbd.cpp:5-30, 212): the inverse when the block has full rank, the rank-revealing pseudo-inverse otherwise
             // (threshold 1e-6 on the pivots of a column-pivoted QR, as in the product kernels)
-            const real_t piv = gj_inverse<NT>(th, L + S::t_s2, t, t, L + S::t_s3, t, L + S::t_s1);
+            const real_t piv = gj_inverse_wave<NT>(th, L + S::t_s2, t, t, L + S::t_s3, t, L + S::t_s1);
             if (!(piv > kCodCheck)) {
                 real_t *cod = L + S::t_cod;
                 pinv_cod_small<NT>(th, L + S::t_s2, t, kCodThreshold, L + S::t_s3, cod, cod + T * T, cod + 2 * T * T, cod + 3 * T * T);
@@ -655,7 +717,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             if (lv < 2) DWBC_STAMP(8 + 3 * lv);  // level lv: QP inputs
             QpResultT<QN> qres;
             qp_rows_and_solve_gc<N, NCC>(su, nlim, ncone, act_c, U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, T, L + S::FNl, k, fv, base, t,
-                                         su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x, kQpTol);
+                                         su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x, kQpTol, true);
             if (lv < 2) DWBC_STAMP(9 + 3 * lv);  // level lv: QP solved
             if (diag && th.tid == 0) {
                 diag[DG_QP_ITER + lv] = qres.iters;
@@ -670,7 +732,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 for (int j = 0; j < t; j++) s += U[i * T + j] * ((real_t)fs[j] + x[j]);
                 L[S::tt + i] += s;
                 real_t c = real_t(0.0);
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[t + j];
+                for (int j = 0; j < k; j++) c += L[S::NwJw + i * k + j] * x[T + j];  // (fixed layout: contact-null variables from position 6 on)
                 L[S::tc + i] = c;
             }
             DWBC_SYNC();
