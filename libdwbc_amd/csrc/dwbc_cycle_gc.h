@@ -159,9 +159,10 @@ template <int NT>
 DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t *Ai, int ldi, real_t *W) {
     DWBC_LANE_DECL;
     const int w = 2 * n;
+    const FastDiv fdw(w), fdn(n);  // (a run-time integer division costs ~40 VALU instructions: 11 of them per pivot in the elimination loop)
     DWBC_SYNC();
     for (int idx = th.tid; idx < n * w; idx += NT) {
-        int i = idx / w, j = idx - i * w;
+        int i = fdw.div(idx), j = idx - i * w;
         W[idx] = j < n ? A[i * lda + j] : (j - n == i ? real_t(1.0) : real_t(0.0));
     }
     real_t pmin = kF32 ? real_t(1e30) : real_t(1e300), pmax = real_t(0.0);
@@ -191,7 +192,7 @@ DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t
         DWBC_SYNC();
         // eliminate: element (i, j) -= W[i][c] * W[c][j]; column c itself is read before it is overwritten
         for (int idx = th.tid; idx < n * w; idx += NT) {
-            int i = idx / w, j = idx - i * w;
+            int i = fdw.div(idx), j = idx - i * w;
             if (i == c || j == c) continue;
             W[idx] -= W[i * w + c] * W[c * w + j];
         }
@@ -201,7 +202,7 @@ DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t
     }
     DWBC_SYNC();
     for (int idx = th.tid; idx < n * n; idx += NT) {
-        int i = idx / n, j = idx - i * n;
+        int i = fdn.div(idx), j = idx - i * n;
         Ai[i * ldi + j] = W[i * w + n + j];
     }
     DWBC_SYNC();
@@ -454,6 +455,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
     const bool too_many = nflag > NCC;
     if (too_many) st_contact = 0;
     const int cd = 6 * nc, k = cd > 6 ? cd - 6 : 0;
+    const FastDiv fdk(k);  // idx / k by one multiply (idx < 2048)
     DWBC_SYNC();
     for (int a = 0; a < nc; a++) {
         const int ci = act_c[a], link = su.c_link[ci];
@@ -504,7 +506,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             // basis of internal wrenches: (f_i, m_i) = e_a on contact i >= 1, balanced on contact 0
             const real_t *Pc = L + S::Pc;
             for (int idx = th.tid; idx < M * k; idx += NT) {
-                const int r = idx / k, a = idx - r * k;
+                const int r = fdk.div(idx), a = idx - r * k;
                 const int ci = 1 + a / 6, e = a % 6;
                 real_t f2[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
                 if (e < 3) f2[e] = real_t(1.0); else m2[e - 3] = real_t(1.0);
@@ -533,7 +535,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             // matrix: pivoted Gauss-Jordan, as the reference's .inverse().  (The SPD-only form of the product kernels, VG JV^T (JV G^-1 JV^T)^-1,
             // squares its condition number: measured 5e-6 Nm on one three-contact instance in 6000, 1e-8 with the direct inverse.)
             for (int idx = th.tid; idx < k * k; idx += NT) {
-                const int i = idx / k, j = idx - i * k;
+                const int i = fdk.div(idx), j = idx - i * k;
                 real_t s = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int c2 = 0; c2 < M; c2++) s += JbT[i * N + 6 + c2] * Vb[c2 * k + j];
@@ -566,7 +568,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         // FNl = A_rot (Jbar[:,6:] NwJw)   (cd x k), contact-local frames
         if (k > 0) {
             for (int idx = th.tid; idx < cd * k; idx += NT) {
-                const int i = idx / k, j = idx - i * k;
+                const int i = fdk.div(idx), j = idx - i * k;
                 real_t s = real_t(0.0);
                 _Pragma("unroll 8")
                 for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * L[S::NwJw + c * k + j];
@@ -574,7 +576,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             for (int idx = th.tid; idx < cd * k; idx += NT) {
-                const int i = idx / k, j = idx - i * k;
+                const int i = fdk.div(idx), j = idx - i * k;
                 const int a = i / 6, h = (i % 6) / 3, x = i % 3;
                 const real_t *R = L + S::Rc + a * 9;
                 const real_t *src = L + S::c_s1 + (6 * a + 3 * h) * k + j;
@@ -600,6 +602,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         real_t *Winv = L + S::bufA, *AiNc = L + S::bufN, *JbT = L + S::JbT;
         for (int lv = 0; lv < su.n_levels && st_task; lv++) {
             const int t = su.t_dof[lv];
+            const FastDiv fdt(t), fdt1(t + 1);
             real_t *Jt = L + S::t_Jt, *T1 = L + S::t_T1, *Lt = L + S::t_Lt, *Q = L + S::t_Q, *QW = L + S::t_QW, *Jkt = L + S::t_Jkt, *U = L + S::t_U;
             // --- J_task rows by link mode (dwbc.cpp:709-788)
             DWBC_SYNC();
@@ -644,7 +647,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 DWBC_SYNC();
             }
             for (int idx = th.tid; idx < M * t; idx += NT) {             // J_kt = W^+ Q^T pinv(.)
-                const int i = idx / t, j = idx - i * t;
+                const int i = fdt.div(idx), j = idx - i * t;
                 real_t s = real_t(0.0);
                 for (int p = 0; p < t; p++) s += QW[p * M + i] * L[S::t_s3 + p * t + j];
                 Jkt[idx] = s;
@@ -653,7 +656,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             // X = J_kt Lambda ;  Y = (J_t A^-1 N_c)[:,6:]   => Null_i = Null_{i-1} (I - X Y)   (wbd.cpp:257-261)
             real_t *X = (lv < kMaxLevels - 1) ? L + S::Xl + lv * M * T : L + S::t_QW;
             for (int idx = th.tid; idx < M * t; idx += NT) {
-                const int i = idx / t, j = idx - i * t;
+                const int i = fdt.div(idx), j = idx - i * t;
                 real_t s = real_t(0.0);
                 for (int p = 0; p < t; p++) s += Jkt[i * t + p] * Lt[p * t + j];
                 X[i * T + j] = s;
@@ -671,7 +674,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 const real_t *Xp = L + S::Xl + pl * M * T, *Yp = L + S::Yl + pl * T * M;
                 DWBC_SYNC();
                 for (int idx = th.tid; idx < tp * t; idx += NT) {       // Z = Yp U  (tp x t)
-                    const int i = idx / t, j = idx - i * t;
+                    const int i = fdt.div(idx), j = idx - i * t;
                     real_t s = real_t(0.0);
                     _Pragma("unroll 8")
                     for (int c = 0; c < M; c++) s += Yp[i * M + c] * U[c * T + j];
@@ -679,7 +682,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 }
                 DWBC_SYNC();
                 for (int idx = th.tid; idx < M * t; idx += NT) {
-                    const int i = idx / t, j = idx - i * t;
+                    const int i = fdt.div(idx), j = idx - i * t;
                     real_t s = U[i * T + j];
                     for (int p = 0; p < tp; p++) s -= Xp[i * T + p] * L[S::t_s2 + p * t + j];
                     U[i * T + j] = s;
@@ -698,7 +701,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             // contact wrench map in the contact-local frames: F (cd x t) = A_rot Jbar[:,6:] U ; fv = A_rot (Jbar[:,6:] base - P_C)
             for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-                const int i = idx / (t + 1), j = idx - i * (t + 1);
+                const int i = fdt1.div(idx), j = idx - i * (t + 1);
                 real_t s = real_t(0.0);
                 if (j < t) { for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * U[c * T + j]; }
                 else { for (int c = 0; c < M; c++) s += JbT[i * N + 6 + c] * base[c]; s -= L[S::PC + i]; }
@@ -706,7 +709,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             for (int idx = th.tid; idx < cd * (t + 1); idx += NT) {
-                const int i = idx / (t + 1), j = idx - i * (t + 1);
+                const int i = fdt1.div(idx), j = idx - i * (t + 1);
                 const int a = i / 6, h = (i % 6) / 3, x = i % 3;
                 const real_t *R = L + S::Rc + a * 9;
                 const real_t *src = L + S::t_s1 + (6 * a + 3 * h) * (T + 1) + j;
