@@ -200,10 +200,18 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
     from libdwbc_amd import shard
 
     dist = None
-    if world > 1:
+    # DWBC_BENCH_FORCE_COLLECTIVE=1: a one-rank job still creates its process group and runs the final all_gather (world = 1), so
+    # that the RCCL branch of this function executes on a one-GPU box (tests/test_gpu_parity.py::test_gpu_bench_one_rank_rccl_gather)
+    collective = world > 1 or os.environ.get("DWBC_BENCH_FORCE_COLLECTIVE") == "1"
+    if collective:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)  # every backend: the engine's stream, events and synchronisation are this device's
@@ -223,7 +231,7 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
     cdev = eng.dev if backend in (None, "nccl") else torch.device("cpu")  # where collective buffers live
 
     def gather_final():
-        if world == 1:  # one rank: the outputs already sit where the caller reads them, there is nothing to exchange
+        if not collective:  # one rank: the outputs already sit where the caller reads them, there is nothing to exchange
             return None
         pack = shard.pack_outputs_torch(eng.tau, eng.wrench, eng.status)
         return shard.gather_packed(pack.to(cdev), dist, world, sizes)
@@ -241,7 +249,7 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
         eng.solve()
     gather_final()
     eng.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
@@ -249,21 +257,26 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
         eng.solve()
     gathered = gather_final()
     eng.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     eng.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if world == 1:
+    forced_check = None
+    if not collective:
         gathered = shard.pack_outputs_torch(eng.tau, eng.wrench, eng.status)  # (after the timed region: what a gather would have returned)
+    elif world == 1:  # forced one-rank collective: what came back through the backend must be this rank's own rows
+        forced_check = bool(torch.equal(gathered.cpu(), shard.pack_outputs_torch(eng.tau, eng.wrench, eng.status).cpu()))
     status_ok = float(eng.status.float().mean().item())
     kern_ms = eng.kernel_ms(args.steps)
     line = None
     if rank == 0:
         line = make_line(args, world, dt, kern_ms, status_ok, eng.info(), backend)
+        if forced_check is not None:
+            line["config"]["forced_one_rank_gather_matches_local"] = forced_check
         if args.workload == "reduced" and engine_factory is HipEngine:
             # configs[4] names a "reduced centroidal-dynamics fast path": on this kernel it is NOT one (the 39-wide sweeps are shared,
             # the reduced blocks come on top) -- the full-model kernel at the same batch and dtype is timed beside it so that nobody
@@ -280,7 +293,7 @@ def rank_main(args, rank, local_rank, world, backend, engine_factory=HipEngine):
                 "cycles_per_s": args.batch / (fms * 1e-3), "kernel_ms": fms, "kernel": full.info()["kernel"],
                 "note": "the reduced (centroidal) path is a coverage row, not a fast path, on this design: reduced / full = "
                         + f"{(args.batch / (kern_ms * 1e-3)) / (args.batch / (fms * 1e-3)):.2f}"}
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     return line, gathered
@@ -381,7 +394,7 @@ def main(argv=None):
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}", file=sys.stderr)
         return 2
     backend = None
-    if world > 1:
+    if world > 1 or os.environ.get("DWBC_BENCH_FORCE_COLLECTIVE") == "1":
         # DWBC_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks.  The driver's runs use
         # the default, RCCL with one GPU per rank.
         backend = os.environ.get("DWBC_BENCH_BACKEND", "nccl")

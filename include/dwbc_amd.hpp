@@ -142,6 +142,17 @@ class HQP {
     }
     void updateCostMatrix(int level, const Mat &H, const Vec &g) { check(dwbc_hqp_update_cost_matrix(h_, level, H.d.data(), g.data())); }
     void normalizeConstraintMatrix(int level) { check(dwbc_hqp_normalize_constraint_matrix(h_, level)); }
+    // hqp_hs_[level].updateInequalityCostWeight / updateEqualityCostWeight / updateConstraintWeight (dwbc_hqp.cpp:503-553): full matrices,
+    // or vectors taken as diagonals (the VectorXd overloads); read by solvefirst only, as in the reference (:245-254)
+    void updateConstraintWeight(int level, const Mat &V, const Mat &W) {
+        check(dwbc_hqp_update_constraint_weight(h_, level, V.d.empty() ? nullptr : V.d.data(), W.d.empty() ? nullptr : W.d.data()));
+        if ((int)wV_.size() <= level) { wV_.resize(level + 1); wW_.resize(level + 1); }
+        wV_[level] = V; wW_[level] = W;
+    }
+    void updateInequalityCostWeight(int level, const Mat &V) { updateConstraintWeight(level, V, kept(wW_, level)); }
+    void updateEqualityCostWeight(int level, const Mat &W) { updateConstraintWeight(level, kept(wV_, level), W); }
+    void updateInequalityCostWeight(int level, const Vec &V) { updateInequalityCostWeight(level, diag(V)); }
+    void updateEqualityCostWeight(int level, const Vec &W) { updateEqualityCostWeight(level, diag(W)); }
     void prepare(bool = false) { check(dwbc_hqp_prepare(h_)); }  // dwbc_hqp.cpp:23-85
     void solvefirst(bool init = true) { if (check(dwbc_hqp_solve_first(h_, init))) fetch(); }       // dwbc_hqp.cpp:222-289
     void solveSequential(bool init = true, bool = false) { if (check(dwbc_hqp_solve_sequential(h_, init))) fetch(); }  // :397-403
@@ -166,6 +177,9 @@ class HQP {
 
   private:
     dwbc_hqp *h_ = nullptr;
+    std::vector<Mat> wV_, wW_;  // the weights handed over so far (one of the two setters keeps the other's matrix)
+    static Mat kept(const std::vector<Mat> &v, int level) { return level < (int)v.size() ? v[level] : Mat(); }
+    static Mat diag(const Vec &v) { Mat m((int)v.size(), (int)v.size()); for (int i = 0; i < (int)v.size(); i++) m(i, i) = v[i]; return m; }
     bool check(int ok) { if (!ok) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl; return ok != 0; }
 };
 

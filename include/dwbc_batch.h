@@ -237,6 +237,10 @@ int dwbc_hqp_clear(dwbc_hqp *h);                                                
 int dwbc_hqp_update_constraint_matrix(dwbc_hqp *h, int level, const double *A, const double *a, const double *Bm, const double *b);
 int dwbc_hqp_update_cost_matrix(dwbc_hqp *h, int level, const double *H, const double *g);  /* updateCostMatrix :483-493 (g is stored, never read: as in the reference) */
 int dwbc_hqp_normalize_constraint_matrix(dwbc_hqp *h, int level);                   /* normalizeConstraintMatrix :555-581 */
+/* HQP_Hierarch::updateInequalityCostWeight / updateEqualityCostWeight / updateConstraintWeight :503-553.  V: B x ineq x ineq, W: B x eq x eq
+ * (row major per instance; NULL = identity).  As in the reference they enter dwbc_hqp_solve_first only (level 0 posed on V A, V a, W B,
+ * W b, :245-254); solveSequential reads the unweighted matrices, and the weights of later levels are stored and never read. */
+int dwbc_hqp_update_constraint_weight(dwbc_hqp *h, int level, const double *V, const double *W);
 /* seed hqp_hs_[level].y_ans_ / v_ans_ directly, as ConfigureLQP does for level 0 (src/dwbc.cpp:4378-4381) */
 int dwbc_hqp_set_answer(dwbc_hqp *h, int level, const double *y_ans, const double *v_ans);
 int dwbc_hqp_prepare(dwbc_hqp *h);                    /* HQP::prepare :23-85 (the null-space chain itself is evaluated with the solve) */

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("dwbc_hqp_update_constraint_matrix", _i, [_vp, _i, _vp, _vp, _vp, _vp]),
     ("dwbc_hqp_update_cost_matrix", _i, [_vp, _i, _vp, _vp]),
     ("dwbc_hqp_normalize_constraint_matrix", _i, [_vp, _i]),
+    ("dwbc_hqp_update_constraint_weight", _i, [_vp, _i, _vp, _vp]),
     ("dwbc_hqp_set_answer", _i, [_vp, _i, _vp, _vp]),
     ("dwbc_hqp_prepare", _i, [_vp]),
     ("dwbc_hqp_solve_first", _i, [_vp, _i]),

@@ -481,11 +481,25 @@ int dwbc_batch_set_max_active_contacts(dwbc_batch *b, int n) {
         if (!find_gc(b->n, b->su.nb).fn) return fail("no general-contact kernel for this model size (built in for TOCABI; kernel packs carry one for models of at most 40 dof)");
     }
     if (!b->own_wrench) return fail("wrench is bound to a device buffer: set the contact capacity before binding");
+    if (n < b->max_active) {  // lowering the capacity: the flags already set must fit it (they were validated against the old one)
+        const int ncn = b->su.n_contacts;
+        for (int i = 0; i < b->B && ncn > 0 && !b->h_flags.empty(); i++) {
+            int on = 0;
+            for (int c = 0; c < ncn; c++) on += b->h_flags[(size_t)i * ncn + c] ? 1 : 0;
+            if (on > n) return fail("max active contacts: the contact flags of this batch hold an instance with more active contacts than the new capacity");
+        }
+    }
+    HIP_OK(hipSetDevice(b->device));  // (the new buffer must live on the batch's device whatever device is current in the caller's thread)
     HIP_OK(hipStreamSynchronize(b->stream));
-    HIP_OK(hipFree(b->d_wrench));
-    b->d_wrench = nullptr;
-    HIP_OK(hipMalloc(&b->d_wrench, (size_t)b->B * 6 * n * sizeof(double)));
-    HIP_OK(hipMemset(b->d_wrench, 0, (size_t)b->B * 6 * n * sizeof(double)));
+    // the new buffer first, the swap only on success: a failed allocation leaves the batch as it was
+    double *nw = nullptr;
+    HIP_OK(hipMalloc(&nw, (size_t)b->B * 6 * n * sizeof(double)));
+    if (hipMemset(nw, 0, (size_t)b->B * 6 * n * sizeof(double)) != hipSuccess) {
+        (void)hipFree(nw);
+        return fail("max active contacts: hipMemset of the new wrench buffer failed");
+    }
+    (void)hipFree(b->d_wrench);
+    b->d_wrench = nw;
     b->max_active = n;
     return 1;
 }
@@ -812,6 +826,9 @@ int dwbc_batch_copy_kinematics(dwbc_batch *dst, const dwbc_batch *src) {
         dst->h_flags.assign((size_t)src->B * src->su.n_contacts, 0);
         HIP_OK(hipMemcpy(dst->h_flags.data(), src->d_flags, dst->h_flags.size(), hipMemcpyDeviceToHost));
     }
+    // the contact capacity travels with the flags (a three-contact source would otherwise hand the two-contact product kernels rows
+    // with three flags raised: status 0 on every such instance); after the flags, so that lowering is checked against the copied ones
+    if (dst->max_active != src->max_active && !dwbc_batch_set_max_active_contacts(dst, src->max_active)) return 0;
     dst->h_qdot = src->h_qdot; dst->dirty_qdot = !src->h_qdot.empty();
     dst->h_ctime = src->h_ctime; dst->dirty_ctime = !src->h_ctime.empty();
     dst->h_traj = src->h_traj; dst->dirty_traj = !src->h_traj.empty();

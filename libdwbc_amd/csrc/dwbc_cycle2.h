@@ -310,11 +310,12 @@ DWBC_WDEV int sweep_inverse_rl(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int n
 // sparsity).  Rows outside the relatives would receive c_i * h with c_i == 0.0 exactly, so leaving them out changes no bit
 // of the result of this pivot order.  The pattern is a compile-time constant (Topo, dwbc_topo.h): the pivots are unrolled by
 // template recursion and each keeps only its relatives' rows -- for TOCABI 753 of the 1521 FMA + broadcast pairs.
-template <class Topo, int NN, int K>
+// LO: the matrix columns sit in lanes LO .. LO + NN - 1 (column c in lane LO + c); the other lanes may carry right-hand sides
+template <class Topo, int NN, int K, int LO = 0>
 DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
     DWBC_LANE_DECL;
     constexpr unsigned long long rel = Topo::relatives(K);
-    real_t d = BCAST(dg, K);
+    real_t d = BCAST(dg, K + LO);
     int pos = d > real_t(0.0) ? 1 : 0;
     DWBC_FLAG_VGPR(pos);
     ok &= pos;
@@ -322,11 +323,11 @@ DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
     const real_t rp = fast_rcp(d);
 #ifdef DWBC_HOST_EMU
     real_t snap_[NN];
-    for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[K][i_];
+    for (int i_ = 0; i_ < NN; i_++) snap_[i_] = s[K + LO][i_];
 #endif
     LANES {
         DWBC_LANE_OPAQUE(lk);
-        const bool piv = lk == K;
+        const bool piv = lk == K + LO;
         const real_t cj = LV(s)[K];
         const real_t h = piv ? (real_t(1.0) - rp) : cj * rp;
 #pragma unroll
@@ -335,17 +336,17 @@ DWBC_WDEV void tree_pivot(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), int &ok) {
 #ifdef DWBC_HOST_EMU
                 const real_t ci = snap_[i];
 #else
-                const real_t ci = readlane_f64(LV(s)[i], K);
+                const real_t ci = readlane_f64(LV(s)[i], K + LO);
 #endif
                 LV(s)[i] -= ci * h;
             }
         }
         LV(dg) = piv ? -rp : LV(dg) - cj * h;
     }
-    if constexpr (K > 0) tree_pivot<Topo, NN, K - 1>(s, dg, ok);
+    if constexpr (K > 0) tree_pivot<Topo, NN, K - 1, LO>(s, dg, ok);
 }
 
-template <class Topo, int NN>
+template <class Topo, int NN, int LO = 0>
 DWBC_WDEV int sweep_inverse_tree(PLA_REF(real_t, s, NN), PL_REF(real_t, dg)) {
     DWBC_LANE_DECL;
     static_assert(NN == Topo::ndof, "topology / kernel size mismatch");
@@ -353,14 +354,14 @@ DWBC_WDEV int sweep_inverse_tree(PLA_REF(real_t, s, NN), PL_REF(real_t, dg)) {
     LANES {
         DWBC_LANE_OPAQUE(lp);
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lp) ? LV(dg) - real_t(1.0) : LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == lp - LO) ? LV(dg) - real_t(1.0) : LV(s)[i];
     }
-    tree_pivot<Topo, NN, NN - 1>(s, dg, ok);
+    tree_pivot<Topo, NN, NN - 1, LO>(s, dg, ok);
     ok = DWBC_FLAG_UNIFORM(ok);
     LANES {
         DWBC_LANE_OPAQUE(le);  // own compares: the prologue's masks are not kept alive (spilled) across the sweep
 #pragma unroll
-        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le) ? -LV(dg) : -LV(s)[i];
+        for (int i = 0; i < NN; i++) LV(s)[i] = (i == le - LO) ? -LV(dg) : -LV(s)[i];
         LV(dg) = -LV(dg);
     }
     return ok;
@@ -402,8 +403,11 @@ __device__ __forceinline__ void lds_col_wait(dwbc_d2v (&c)[NP]) {
 // ds_read_b128 of such a loop is followed by its own s_waitcnt (the disassembly of the J_kt rows: 81 reads, 81 waits, one LDS round
 // trip each: 9.8 k cycles for 198 FMAs); here the reads of CH rows are issued back to back and waited for once, as the W^+ sweep does
 // for its pivot column.  Needs 16-byte-aligned rows (even RS, aligned base); anything else takes the plain loop.
-template <int NR, int NC, int RS, int CH, int MODE, bool ALIGNED = true>
-DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out)[NR]) {
+// OFF / NO: the results go to out[OFF .. OFF + NR - 1] of an array of NO entries (a slice of a register column, addressed statically --
+// a reference to `&column[OFF]` would make the whole column addressable and send it to scratch)
+template <int NR, int NC, int RS, int CH, int MODE, bool ALIGNED = true, int OFF = 0, int NO = NR>
+DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out)[NO]) {
+    static_assert(OFF + NR <= NO, "output slice");
 #if !defined(DWBC_HOST_EMU)
     if constexpr (sizeof(real_t) == 8 && RS % 2 == 0 && ALIGNED) {
         constexpr int NP = (NC + 1) / 2;  // reads per row (the last one may fetch one element beyond NC: it stays inside the row's stride
@@ -427,19 +431,20 @@ DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out
 #pragma unroll
                     for (int i = 0; i < NC; i++) a4[i & 3] += c[q][i / 2][i & 1] * x[i];
                     const real_t d = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                    if (MODE == 0) out[r0 + q] = d; else out[r0 + q] -= d;
+                    if (MODE == 0) out[OFF + r0 + q] = d; else out[OFF + r0 + q] -= d;
                 }
             }
         }
         return;
     }
 #endif
+#pragma unroll
     for (int r = 0; r < NR; r++) {
         real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
         for (int i = 0; i < NC; i++) a4[i & 3] += A[r * RS + i] * x[i];
         const real_t d = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        if (MODE == 0) out[r] = d; else out[r] -= d;
+        if (MODE == 0) out[OFF + r] = d; else out[OFF + r] -= d;
     }
 }
 
@@ -472,13 +477,13 @@ DWBC_WDEV void lds_rows_axpy(const real_t *A, const real_t (&x)[NR], real_t (&ac
 }
 
 #if !defined(DWBC_HOST_EMU)
-template <int NN, int K>
+template <int NN, int K, int LO = 0>
 __device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
     constexpr int NP = (NN + 1) / 2;
     dwbc_d2v col[NP];
-    asm volatile("ds_write_b64 %0, %1" ::"v"(cb + 8 * lane), "v"(s[K]) : "memory");
+    asm volatile("ds_write_b64 %0, %1" ::"v"(cb + 8 * ((lane - LO) & 63)), "v"(s[K]) : "memory");  // (64 doubles: every lane has a slot)
     lds_col_issue<0, NP>(col, cb);
-    double d = readlane_f64(dg2, K) + 2.0;
+    double d = readlane_f64(dg2, K + LO) + 2.0;
     int pos = d > 0.0 ? 1 : 0;
     DWBC_FLAG_VGPR(pos);
     ok &= pos;
@@ -490,33 +495,34 @@ __device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok,
 #pragma unroll
     for (int i = 0; i < NN; i++) s[i] -= col[i / 2][i & 1] * h;
     dg2 -= cj * h;              // pivot lane: (d - 2) - (d - 2 + 1/d) = -1/d
-    if constexpr (K > 0) lds_pivot<NN, K - 1>(s, dg2, ok, cb, lane);
+    if constexpr (K > 0) lds_pivot<NN, K - 1, LO>(s, dg2, ok, cb, lane);
 }
 #endif
 
-template <int NN>
+// LO: lane of matrix column 0 (the columns sit in lanes LO .. LO + NN - 1; colbuf: 64 doubles)
+template <int NN, int LO = 0>
 DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
 #if defined(DWBC_HOST_EMU)
     (void)colbuf;
-    return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
+    return sweep_inverse_tree<TopoDense<NN>, NN, LO>(s, dg);
 #else
     if constexpr (sizeof(real_t) != 8 || NN < 16) {  // fp32 build; small matrices: the register sweep
-        return sweep_inverse_tree<TopoDense<NN>, NN>(s, dg);
+        return sweep_inverse_tree<TopoDense<NN>, NN, LO>(s, dg);
     } else {
         const int lane = (int)(threadIdx.x & 63u);
         int ok = 1;
         {
             DWBC_LANE_OPAQUE(lp);
 #pragma unroll
-            for (int i = 0; i < NN; i++) s[i] = (i == lp) ? dg - 1.0 : s[i];
+            for (int i = 0; i < NN; i++) s[i] = (i == lp - LO) ? dg - 1.0 : s[i];
         }
         double dg2 = dg - 2.0;
-        lds_pivot<NN, NN - 1>(s, dg2, ok, (unsigned)(size_t)colbuf, lane);
+        lds_pivot<NN, NN - 1, LO>(s, dg2, ok, (unsigned)(size_t)colbuf, lane);
         ok = DWBC_FLAG_UNIFORM(ok);
         {
             DWBC_LANE_OPAQUE(le);
 #pragma unroll
-            for (int i = 0; i < NN; i++) s[i] = (i == le) ? -dg2 : -s[i];
+            for (int i = 0; i < NN; i++) s[i] = (i == le - LO) ? -dg2 : -s[i];
             dg = -dg2;
         }
         return ok;

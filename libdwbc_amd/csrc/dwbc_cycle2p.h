@@ -65,6 +65,13 @@ struct Lds4 {
     static constexpr int aw = pw + NB * 3;
     static constexpr int Rw0 = Rw;
     static constexpr int fend = aw + NB * 3;
+    // phase 4 -> 5: (W + alpha P)^-1 T1r^T of every level, one row per task dof (the right-hand sides that ride through the W^+
+    // sweep in its idle lanes), over the link frames, which are dead after B1
+    // phase 1b -> 3: what rode through the A^-1 sweep next to Y: rows of J_t A^-1 (one per task dof, <= 12) and A^-1 G (row 12), stride N
+    static constexpr int ajt = Rw;
+    static_assert(13 * N <= fend - Rw, "J_t A^-1 and A^-1 G borrow the link frames");
+    static constexpr int jk = Rw;
+    static_assert(Rw % 2 == 0, "16-byte aligned rows");
     // ---- long-lived
     static constexpr int JbT = fend;                           // C x N; J_C (N x C) until Jbar^T is written over it
     static constexpr int c_JC = JbT;
@@ -98,7 +105,8 @@ struct Lds4 {
     static constexpr int k_A = U;                              // packed lower triangle over U / T1x (written from phase 3 / stage 3a on)
     static_assert(N * (N + 1) / 2 <= (c_T1 - U), "the staged mass matrix borrows the U / T1x region");
     static constexpr int c_Y = kin;                            // N x C (phase 2-3)
-    static_assert(C * N <= kin_end - kin, "Y borrows the stage-0 scratch");
+    static constexpr int c_D = kin + C * N;                    // helper, phase 2-3: D = J_t A^-1 J_C^T (<= 12 x C), then Y G (C)
+    static_assert(C * N + 13 * C <= kin_end - kin && (kin + C * N) % 2 == 0, "Y and D borrow the stage-0 scratch");
     // stage 3a scratch of the main wave (phase 5) and the QP scratch, over the dead stage-0 scratch
     static constexpr int c_QW = kin;                           // Q (slow route)
     static constexpr int c_QWp = c_QW + T * M;                 // Q W^+ (slow route)
@@ -116,6 +124,7 @@ struct Lds4 {
     static constexpr int qp_V = t_cl + K;
     static constexpr int qp_x = qp_V + kQpLd;
     static constexpr int p5_end = qp_x + kQpLd;
+    static_assert(NLV * T * MS <= fend - Rw, "the J_kt staging block borrows the link frames");
     static constexpr int total = max2(kin_end, p5_end);
     static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
     // names of the other maps that shared helpers mention but this kernel does not use
@@ -135,10 +144,22 @@ struct Lds4 {
 #else
 #define DWBC_PAIR_BARRIER(i) __syncthreads()
 #endif
+#if defined(DWBC_HOST_EMU)
+#define DWBC_PAIR_BARRIER_X() ((void)0)
+#else
+#define DWBC_PAIR_BARRIER_X() __syncthreads()
+#endif
 #if defined(DWBC_STAGE_TIMERS) && !defined(DWBC_HOST_EMU)
 #define DWBC_PSTAMP(i) do { DWBC_SYNC(); if (diag && th.tid == 0) diag[DG_FTIME + (i)] = (int)(clock64() - t_start_); } while (0)
+// stamps inside the register-heavy phases 1-4: a build with all of them spills in the sweeps, so each is compiled in only when its bit
+// of DWBC_PMASK is set (make experiment VARIANT=.. XFLAGS="-DDWBC_STAGE_TIMERS -DDWBC_PMASK=0x..ull"; bit i - 41)
+#ifndef DWBC_PMASK
+#define DWBC_PMASK 0ull
+#endif
+#define DWBC_PSTAMP_M(i) do { if constexpr (((DWBC_PMASK) >> ((i) - 41)) & 1ull) DWBC_PSTAMP(i); } while (0)
 #else
 #define DWBC_PSTAMP(i) ((void)0)
+#define DWBC_PSTAMP_M(i) ((void)0)
 #endif
 
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
@@ -299,46 +320,39 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 }
         }
         DWBC_SYNC();
+        DWBC_PSTAMP_M(51);  // world inertias
         real_t *Icm = L + S::k_Ic;
         {
-            real_t *Sc = Iw, *Sn = Icm;
-            PLA(real_t, sk, 10);
-            PLA(real_t, acc, 10);
+            // composite inertia of the subtree [b, b + len_b) (bodies are numbered depth first): inclusive prefix sums over the body order
+            // in registers (DPP), Ic[b] = P[b + len_b - 1] - P[b - 1].  Everything is expressed about the pelvis origin, where the smallest
+            // subtree (a wrist link, m r^2 ~ 0.1) is within 1e3 of the total: the difference keeps 13 digits.  (The window sums by doubling
+            // of the one-wave kernels -- six rounds through LDS -- were 7.3 k of this wave's 17 k cycles before the A^-1 sweep.)
+            PLA(real_t, pf, 10);
             PL(int, len);
             LANES {
                 const int bi = lane < nb ? lane : 0;
-                LV(len) = lane < nb ? topo[2 * nb + bi] : 0;
+                LV(len) = lane < nb ? topo[2 * nb + bi] : 1;
 #pragma unroll
-                for (int c = 0; c < 10; c++) { LV(sk)[c] = Sc[bi * 10 + c]; LV(acc)[c] = real_t(0.0); }
-            }
-            for (int kbit = 0, off = 1; off <= nb; kbit++, off <<= 1) {
-                LANES {
-                    const bool take = (LV(len) >> kbit) & 1;
-                    int pos = lane + (LV(len) & (off - 1));
-                    pos = (take && pos < nb) ? pos : 0;
-                    const bool nbr = lane + off < nb;
-                    const int pn2 = nbr ? lane + off : 0;
-                    real_t a_[10], b_[10];
-#pragma unroll
-                    for (int c = 0; c < 10; c++) { a_[c] = Sc[pos * 10 + c]; b_[c] = Sc[pn2 * 10 + c]; }
-#pragma unroll
-                    for (int c = 0; c < 10; c++) {
-                        LV(acc)[c] += take ? a_[c] : real_t(0.0);
-                        LV(sk)[c] += nbr ? b_[c] : real_t(0.0);
-                        if (lane < nb) Sn[lane * 10 + c] = LV(sk)[c];
-                    }
+                for (int c = 0; c < 10; c++) {
+                    const real_t v_ = Iw[bi * 10 + c];
+                    LV(pf)[c] = lane < nb ? v_ : real_t(0.0);
                 }
-                DWBC_SYNC();
-                { real_t *t_ = Sc; Sc = Sn; Sn = t_; }
             }
-            LANES {
-                if (lane < nb) {
 #pragma unroll
-                    for (int c = 0; c < 10; c++) Icm[lane * 10 + c] = LV(acc)[c];
+            for (int c = 0; c < 10; c++) WAVE_PREFIX_A(pf, c);
+            LANES {
+                int e_ = lane + LV(len) - 1;
+                e_ = e_ < 63 ? e_ : 63;
+                const int s_ = lane > 0 ? lane - 1 : 0;
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    const real_t hi_ = SHFLA(pf, c, e_), lo_ = SHFLA(pf, c, s_);
+                    if (lane < nb) Icm[lane * 10 + c] = hi_ - (lane > 0 ? lo_ : real_t(0.0));
                 }
             }
             DWBC_SYNC();
         }
+        DWBC_PSTAMP_M(52);  // composite inertias
         real_t *Sm = L + S::k_S, *Fm = L + S::k_F;
         for (int j = th.tid; j < N; j += NT) {
             real_t w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
@@ -371,6 +385,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
         }
         DWBC_SYNC();
+        DWBC_PSTAMP_M(53);  // motion axes S, forces F
         real_t *A = L + S::k_A;  // lower triangle, row-packed: (i, j <= i) at i (i + 1) / 2 + j
         for (int idx = th.tid; idx < N * (N + 1) / 2; idx += NT) A[idx] = real_t(0.0);
         DWBC_SYNC();
@@ -383,6 +398,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             }
         }
         DWBC_SYNC();
+        DWBC_PSTAMP_M(54);  // mass matrix pairs
         LANES {
             const int col = lane < N ? lane : 0;
             const int cbase = col * (col + 1) / 2;
@@ -391,10 +407,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             LV(dg) = (lane < N) ? A[cbase + col] : real_t(1.0);
             if (lane < N) L[S::G + lane] = kGrav * A[col >= 2 ? cbase + 2 : 3 + col];  // G_ = 9.81 A[2,:] (dwbc.cpp:358)
         }
-        if (!sweep_inverse_tree<Topo, N>(s, dg)) st_contact = 0;  // A_inv (dwbc.cpp:307)
+        DWBC_PSTAMP_M(41);  // CRBA done, columns of A in registers
     }
     if (is_help) {
-        // contact frames, J_C, internal-wrench basis and its Gram algebra; the task Jacobians of every level
+        // contact frames, J_C and the task Jacobians of every level first: they ride through the A^-1 sweep (B1a)
         for (int a = 0; a < nc; a++) {
             const int ci = act_c[a], link = su.c_link[ci];
             const real_t *R = Rw + link * 9;
@@ -411,17 +427,6 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         for (int a = 0; a < nc; a++)
             point_jacobian<N, NB, NT>(th, Rw, pw, aw, topo, nb, su.c_link[act_c[a]], L + S::Pc + a * 3, JCt, 1, 6 * a, 6, 0, C);
         DWBC_SYNC();
-        if (k > 0) {
-            constexpr int K6 = 6;
-            internal_wrench_basis<N, NT>(th, L + S::Pc, JCt, Vb);
-            DWBC_SYNC();
-            real_t *Gi = L + S::hs + 36;
-            mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
-            DWBC_SYNC();
-            spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::hs + 144);               // G^-1
-            mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1
-            DWBC_SYNC();
-        }
         for (int lv = 0; lv < su.n_levels; lv++) {
             real_t *Jtt = L + S::Jtt + lv * N * T;
             for (int idx = th.tid; idx < T * N; idx += NT) Jtt[idx] = real_t(0.0);
@@ -444,34 +449,64 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             DWBC_SYNC();
         }
     }
-    DWBC_PAIR_BARRIER(1);  // ---- B1: A^-1 in the main wave's registers; J_C, Vb, VG, J_t in LDS
+    DWBC_PAIR_BARRIER_X();  // ---- B1a: J_C, J_t, G in LDS; the columns of A in the main wave's registers
+    real_t *AJt = L + S::ajt;
+    if (is_main) {
+        // The A^-1 sweep uses N = 39 of the 64 lanes; the other 25 carry right-hand sides through the same pivots (a Gauss-Jordan
+        // sweep of [A | X] leaves A^-1 X in the extra columns, with the FMAs every non-pivot lane executes anyway; a row outside the
+        // pivot's relatives would receive c_i * h with c_i == 0 there as well): lanes N .. N+11 the rows of J_C (-> Y = J_C A^-1,
+        // wbd.cpp:113), lanes N+12 .. N+23 the rows of J_t of every level (-> J_t A^-1), lane 63 G (-> A^-1 G).  The products
+        // Y = J_C A^-1 (phase 2), T1 = J_t A^-1 N_c and the gravity pre-vector (phase 3) no longer pass through this wave: the helper
+        // forms the last two from what rode here.
+        static_assert(N + 25 == 64, "rhs lanes: 12 + 12 + 1");
+        LANES {
+            if (lane >= N) {
+                const int jj = lane - N, jt = jj - C;
+                int lvl = 0;
+#pragma unroll
+                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && jt >= su.fstar_off[q_]) ? q_ : lvl;
+                const bool isc = jj < C, ist = jt >= 0 && jt < su.fstar_total, isg = jj == 2 * C;
+                const real_t *bp = isc ? JCt + jj : (isg ? L + S::G : L + S::Jtt + lvl * N * T + (ist ? jt - su.fstar_off[lvl] : 0));
+                const int st = isc ? C : (isg ? 1 : T);
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const real_t v_ = bp[i * st];
+                    LV(s)[i] = (isc || ist || isg) ? v_ : real_t(0.0);
+                }
+                LV(dg) = real_t(1.0);
+            }
+        }
+        if (!sweep_inverse_tree<Topo, N>(s, dg)) st_contact = 0;  // A_inv (dwbc.cpp:307)
+        if (too_many) st_contact = 0;
+        LANES {
+            if (lane >= N) {  // (negated by the sweep's epilogue like the matrix lanes)
+                const int jj = lane - N;
+                real_t *bp = jj < C ? Yt + jj : AJt + (jj - C) * N;
+                const int st = jj < C ? C : 1;
+#pragma unroll
+                for (int i = 0; i < N; i++) bp[i * st] = -LV(s)[i];
+            }
+        }
+        DWBC_SYNC();
+    }
+    if (is_help && k > 0) {
+        // internal-wrench basis and its Gram algebra (beside the sweep)
+        constexpr int K6 = 6;
+        internal_wrench_basis<N, NT>(th, L + S::Pc, JCt, Vb);
+        DWBC_SYNC();
+        real_t *Gi = L + S::hs + 36;
+        mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
+        DWBC_SYNC();
+        spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::hs + 144);               // G^-1
+        mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1
+        DWBC_SYNC();
+    }
+    DWBC_PAIR_BARRIER(1);  // ---- B1: A^-1 in the main wave's registers; Y, J_t A^-1, A^-1 G, J_C, Vb, VG, J_t in LDS
 
     // ================= phase 2 (main): Y = J_C A^-1, Lambda_c, Jbar^T =================
     const unsigned long long cm0 = nc > 0 ? su.c_dofmask[act_c[0]] : 0ull, cm1 = nc > 1 ? su.c_dofmask[act_c[1]] : 0ull;
     if (is_main) {
-        if (too_many) st_contact = 0;
-        for (int idx = th.tid; idx < C * N; idx += NT) Yt[idx] = real_t(0.0);
-        DWBC_SYNC();
-        LANES {
-            real_t yc[C];
-#pragma unroll
-            for (int p = 0; p < C; p++) yc[p] = real_t(0.0);
-            // three columns of J_C (rows of its transpose) at a time, both contacts together: the entries of the contact that a dof
-            // does not move are exact zeros, and one batch of 18 reads beats two half-filled ones behind their own waits
-            static_assert(N % 3 == 0, "column blocks of three");
-#pragma unroll
-            for (int ib = 0; ib < N; ib += 3) {
-                if (((cm0 | cm1) >> ib) & 7) {
-                    const real_t x3[3] = {LV(s)[ib], LV(s)[ib + 1], LV(s)[ib + 2]};
-                    lds_rows_axpy<3, C, C, S::c_JC % 2 == 0>(JCt + ib * C, x3, yc);
-                }
-            }
-            if (lane < N) {
-#pragma unroll
-                for (int p = 0; p < C; p++) Yt[lane * C + p] = yc[p];
-            }
-        }
-        DWBC_SYNC();
+        DWBC_PSTAMP_M(42);  // Y = J_C A^-1 stored
 #if !defined(DWBC_HOST_EMU)
         if constexpr (sizeof(real_t) == 8) {  // J A^-1 J^T = Y J_C^T on one accumulator tile (see dwbc_cycle2_stage1.inc)
             typedef double lc_d4 __attribute__((ext_vector_type(4)));
@@ -506,6 +541,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         }
         DWBC_SYNC();
     }
+    if (is_main) DWBC_PSTAMP_M(43);  // Lambda_c
     // Jbar^T = Lambda J A^-1 (wbd.cpp:116) is written over J_C: keep it in registers until the barrier has been passed? no -- J_C is
     // read by this wave only from here on (the helper's readers of J_C finished before B1), so the overwrite is safe at once.
     PLA(real_t, jbk, C);  // main wave: column `lane` of Jbar^T, kept for the A^-1 N_c update of phase 3
@@ -517,7 +553,29 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             for (int p = 0; p < C; p++) LV(yck)[p] = Yt[col * C + p];
             lds_rows_dot<C, C, C, 4, 0, S::c_Lam % 2 == 0>(Lam, LV(yck), LV(jbk));  // column `lane` of Jbar^T = Lambda_c Y
         }
-        DWBC_SYNC();  // every lane has read what it needs of Y; J_C is dead
+        DWBC_SYNC();  // every lane has read what it needs of Y
+    }
+    real_t *Dm = L + S::c_D;  // D = J_t A^-1 J_C^T, one row per task dof
+    if (is_help) {
+        // D = (J_t A^-1) J_C^T from the rows that rode through the sweep, while J_C is still there (the main wave writes Jbar^T over it)
+        const int ft = su.fstar_total;
+        for (int idx = th.tid; idx < ft * C; idx += NT) {
+            const int j = idx / C, p_ = idx - j * C;
+            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+#pragma unroll
+            for (int c = 0; c < N; c++) a4[c & 3] += AJt[j * N + c] * JCt[c * C + p_];
+            Dm[idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
+        for (int p_ = th.tid; p_ < C; p_ += NT) {  // yg = J_C A^-1 G = Y G (row 12 of the riding block is A^-1 G)
+            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+#pragma unroll
+            for (int c = 0; c < N; c++) a4[c & 3] += AJt[12 * N + c] * JCt[c * C + p_];
+            Dm[12 * C + p_] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
+        DWBC_SYNC();
+    }
+    DWBC_PAIR_BARRIER_X();  // ---- B1b: the helper is done with J_C
+    if (is_main) {
         LANES {
 #pragma unroll
             for (int p = 0; p < C; p++)
@@ -528,48 +586,60 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
 
     // ================= phase 3 =================
     if (is_main) {
-        // A^-1 N_c = A^-1 - Y^T Jbar^T (wbd.cpp:117-118), gravity pre-vector, P_C, T1 of every level
+        // W = (A^-1 N_c)[6:, 6:]: rows 6.. of A^-1 N_c = A^-1 - Y^T Jbar^T (wbd.cpp:117-118).  Nothing reads the base rows of the
+        // register columns again (T1 comes from the vectors that rode through the sweep), so they are not updated.
         LANES {
             real_t dsub = real_t(0.0);
 #pragma unroll
             for (int p = 0; p < C; p++) dsub += LV(yck)[p] * LV(jbk)[p];
             LV(dg) -= dsub;
-            lds_rows_dot<N, C, C, 4, 1>(Yt, LV(jbk), LV(s));  // s[i] -= Y^T[i, :] . Jbar^T[:, lane]
+            lds_rows_dot<M, C, C, 4, 1, true, 6>(Yt + 6 * C, LV(jbk), LV(s));  // s[i] -= Y^T[i, :] . Jbar^T[:, lane], i >= 6
         }
         DWBC_SYNC();
-        LANES {
-            real_t gv1[1];
-            lds_rows_dot<1, N, 2 * ((N + 1) / 2), 1, 0>(L + S::G, LV(s), gv1);  // gravity pre-vector (A^-1 N_c G)[lane]
-            if (lane < N) L[S::c_vec + lane] = gv1[0];
+        DWBC_PSTAMP_M(45);  // A^-1 N_c update done
+        DWBC_SYNC();
+    }
+    if (is_help) {
+        // P_C = Jbar^T G = Lambda_c (Y G) (wbd.cpp:119) and the gravity pre-vector A^-1 N_c G = A^-1 G - Y^T P_C (wbd.cpp:190), from
+        // the vector that rode through the A^-1 sweep
+        for (int p_ = th.tid; p_ < C; p_ += NT) {
+            real_t acc = real_t(0.0);
+#pragma unroll
+            for (int q_ = 0; q_ < C; q_++) acc += (p_ < cd && q_ < cd) ? Lam[p_ * C + q_] * Dm[12 * C + q_] : real_t(0.0);
+            L[S::PC + p_] = acc;
         }
-        mv_n<NT>(th, L + S::PC, JbT, N, L + S::G, cd, N);
-        for (int lv = 0; lv < su.n_levels; lv++) {
-            const real_t *Jtt = L + S::Jtt + lv * N * T;
-            real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * S::MS;
-            const unsigned long long tm = su.t_dofmask[lv];
-            auto t1_rows = [&](auto ttc) {
-                constexpr int TT = decltype(ttc)::value;
-                LANES {
-                    real_t tc_[TT];
+        DWBC_SYNC();
+        for (int i = th.tid; i < N; i += NT) {
+            real_t yr[C], pv[C];
 #pragma unroll
-                    for (int r = 0; r < TT; r++) tc_[r] = real_t(0.0);
+            for (int p = 0; p < C; p++) { yr[p] = Yt[i * C + p]; pv[p] = L[S::PC + p]; }
+            real_t acc = AJt[12 * N + i];
 #pragma unroll
-                    for (int ib = 0; ib < N; ib += 3) {
-                        if ((tm >> ib) & 7) {
+            for (int p = 0; p < C; p++) acc -= yr[p] * pv[p];
+            L[S::c_vec + i] = acc;
+        }
+        // T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level (D = J_t A^-1 J_C^T, phase 2): column `lane` per lane -- its column of
+        // Jbar^T in registers, the rows of D by broadcast reads in hand-made batches.  (On this wave: next to the 39-row register column of
+        // the main wave the same block pushes the allocator over the register cap.)
+        LANES {
+            const int cl = lane < N ? lane : 0;
+            real_t jb[C];
 #pragma unroll
-                            for (int i = ib; i < ib + 3 && i < N; i++)
+            for (int p = 0; p < C; p++) jb[p] = JbT[p * N + cl];
+            // (a rolled loop over the task dofs: unrolled, its twelve load / store groups next to the main wave's register columns --
+            // live across this block for the allocator -- spill all over the kernel)
+#pragma unroll 1
+            for (int j = 0; j < su.fstar_total; j++) {
+                int lvl = 0;
 #pragma unroll
-                                for (int r = 0; r < TT; r++) tc_[r] += Jtt[i * T + r] * LV(s)[i];
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < TT; r++) {
-                        if (lane < 6) T1[r * 6 + lane] = tc_[r];
-                        else if (lane < N) T1x[r * S::MS + (lane - 6)] = tc_[r];
-                    }
-                }
-            };
-            if (su.t_dof[lv] <= 3) t1_rows(std::integral_constant<int, 3>{}); else t1_rows(std::integral_constant<int, T>{});
+                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && j >= su.fstar_off[q_]) ? q_ : lvl;
+                const int r = j - su.fstar_off[lvl];
+                real_t d1[1];
+                lds_rows_dot<1, C, C, 1, 0, S::c_D % 2 == 0>(Dm + j * C, jb, d1);
+                const real_t v_ = AJt[j * N + cl] - d1[0];
+                if (lane < 6) L[S::c_T1 + lvl * T * 6 + r * 6 + lane] = v_;
+                else if (lane < N) L[S::T1x + lvl * T * S::MS + r * S::MS + (lane - 6)] = v_;
+            }
         }
         DWBC_SYNC();
     }
@@ -595,63 +665,100 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
         DWBC_SYNC();
     }
-    DWBC_PAIR_BARRIER(3);  // ---- B3: T1 of every level, NwJw in LDS
+    // (barrier B3 -- T1 of every level, the gravity pre-vector and NwJw in LDS -- comes after the main wave has assembled W + alpha P,
+    // which needs none of them: the helper's phase-3 chain is the longer one)
 
     // ================= phase 4 =================
-    PLA(real_t, w, M);  // main wave: column `lane` of W -> W^+
+    // W = (A^-1 N_c)[6:, 6:] stays where it is: column c of W is rows 6.. of lane 6 + c's column, so `w` is a view of `s` and the
+    // W^+ sweep runs on lanes WL .. WL + M - 1 (moving the columns down to lane c cost 66 ds_bpermute per cycle).
+    constexpr int WL = 6;      // lane of column 0 of W
+    constexpr int RL = WL + M; // first lane that carries a right-hand side through the sweep
+    PLA(real_t, w, M);  // main wave: column `lane - WL` of W -> W^+
     PL(real_t, dw);
+    real_t alpha = real_t(0.0), ialpha = real_t(0.0);
+    PLA(real_t, pc, M);  // main wave: column `lane - WL` of the projector P = VG Vb^T, kept across the sweep for the correction
     if (is_main) {
+        PL(real_t, dsum);
         LANES {
-            const int src = lane < M ? lane + 6 : lane;
+            const bool in = lane >= WL && lane < RL;
 #pragma unroll
-            for (int i = 0; i < M; i++) LV(w)[i] = SHFLA(s, 6 + i, src);
-            LV(dw) = SHFL(dg, src);
+            for (int i = 0; i < M; i++) LV(w)[i] = LV(s)[6 + i];
+            LV(dw) = LV(dg);
+            LV(dsum) = in ? LV(dg) : real_t(0.0);
         }
-        LANES {
-            if (lane < M) L[S::c_col + lane] = LV(dw);
-        }
-        DWBC_SYNC();
-        real_t alpha = real_t(0.0);
-        for (int i = 0; i < M; i++) alpha += L[S::c_col + i];
+        WAVE_SUM(dsum, alpha);
         alpha /= M;
-        const real_t ialpha = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
-        DWBC_SYNC();
+        ialpha = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
         PLA(real_t, vbr, 6);
-        PLA(real_t, pc, M);
         LANES {
+            const bool in = lane >= WL && lane < RL;
+            const int wl = in ? lane - WL : 0;
 #pragma unroll
-            for (int a = 0; a < 6; a++) LV(vbr)[a] = (k > 0 && lane < M) ? Vb[lane * 6 + a] : real_t(0.0);
+            for (int a = 0; a < 6; a++) {
+                const real_t v_ = Vb[wl * 6 + a];
+                LV(vbr)[a] = (k > 0 && in) ? v_ : real_t(0.0);
+            }
 #pragma unroll
             for (int i = 0; i < M; i++) LV(pc)[i] = real_t(0.0);
             if (k > 0) {
                 DWBC_LANE_OPAQUE(lw);
                 real_t dp = real_t(0.0);
-                lds_rows_dot<M, 6, 6, 6, 0>(VG, LV(vbr), LV(pc));  // column `lane` of P = VG Vb^T
+                lds_rows_dot<M, 6, 6, 6, 0>(VG, LV(vbr), LV(pc));  // column `lane - WL` of P = VG Vb^T
 #pragma unroll
                 for (int i = 0; i < M; i++) {
                     const real_t pij = LV(pc)[i];
                     LV(w)[i] += alpha * pij;
-                    dp = (i == lw) ? pij : dp;
+                    dp = (i == lw - WL) ? pij : dp;
                 }
                 LV(dw) += alpha * dp;
             }
-            if (lane >= M) {
+        }
+    }
+    DWBC_PAIR_BARRIER(3);  // ---- B3: T1 of every level, the gravity pre-vector, NwJw in LDS
+    if (is_main) {
+        LANES {
+            const bool in = lane >= WL && lane < RL;
+            if (!in) {
+                // The sweep uses M of the 64 lanes.  Every vector W^+ is ever applied to exists by now -- the rows of T1r of each level
+                // (J_kt = W^+ T1r^T Lambda-side, wbd.cpp:207-213) and the gravity pre-vector (wbd.cpp:190) -- so they ride through the
+                // same 33 pivots as extra columns in idle lanes: a Gauss-Jordan sweep of [S | X] leaves S^-1 X in the extra columns
+                // (same FMAs as a non-pivot matrix lane, no extra instruction).  Both kinds of vector are orthogonal to null(W)
+                // (A^-1 N_c [0; n] = 0 for n in null(W)), so (W + alpha P)^-1 x = W^+ x and the projector correction does not apply.
+                const int jj = lane >= RL ? lane - RL : 63;
+                int lvl = 0;
 #pragma unroll
-                for (int i = 0; i < M; i++) LV(w)[i] = real_t(0.0);
+                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && jj >= su.fstar_off[q_]) ? q_ : lvl;
+                const bool isrow = jj < su.fstar_total, isg = jj == NLV * T;
+                const real_t *srcp = isg ? L + S::c_vec + 6 : L + S::T1x + lvl * T * S::MS + (isrow ? jj - su.fstar_off[lvl] : 0) * S::MS;
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    const real_t v_ = srcp[i];
+                    LV(w)[i] = (isrow || isg) ? v_ : real_t(0.0);
+                }
                 LV(dw) = real_t(1.0);
             }
         }
+        DWBC_PSTAMP_M(48);  // W + alpha P assembled, right-hand sides loaded
         DWBC_SYNC();
-        if (!sweep_inverse_lds<M>(w, dw, L + S::c_s1)) st_contact = 0;
+        if (!sweep_inverse_lds<M, WL>(w, dw, L + S::c_s1)) st_contact = 0;
         DWBC_SYNC();
+        DWBC_PSTAMP_M(49);  // W^+ sweep done
         LANES {
             if (k > 0) {
 #pragma unroll
-                for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];
+                for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];  // (pc = 0 outside the matrix lanes)
             }
-            real_t tg1[1];  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
-            lds_rows_dot<1, M, 2 * ((M + 1) / 2), 1, 0>(L + S::c_vec + 6, LV(w), tg1);
-            if (lane < M) L[S::tg + lane] = tg1[0];
+            // the swept right-hand sides (negated by the sweep's epilogue like the matrix): column j of [J_kt-side vectors] -> row j of
+            // the staging block; the gravity lane writes torque_grav_ = W^+ (A^-1 N_c G)[6:] (wbd.cpp:190) itself
+            if (lane >= RL) {
+                const int jj = lane - RL;
+                const bool isrow = jj < su.fstar_total, isg = jj == NLV * T;
+                real_t *dst = isg ? L + S::tg : L + S::jk + (isrow ? jj : 0) * S::MS;
+                if (isrow || isg) {
+#pragma unroll
+                    for (int i = 0; i < M; i++) dst[i] = -LV(w)[i];
+                }
+            }
         }
         DWBC_SYNC();
     }
@@ -688,36 +795,47 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     DWBC_PAIR_BARRIER(4);  // ---- B4: W^+ in the main wave's registers; Lambda_task, the fast-route mask in LDS
     if (!is_main) return;
 
-    // ================= phase 5 (main): stage 3a, wrench maps, QP cascade, outputs (dwbc_cycle2.h) =================
+    // ================= phase 5 (main): stage 3a, wrench maps, QP cascade in registers, outputs =================
+    static_assert(NLV <= 2, "the null-space chain below takes X_0 = U_0 from the level-0 rows");
     if (flg[0] == real_t(0.0)) st_contact = 0;
     const int fastmask = (int)flg[1];
     int rankbad = 0;
+    // Row `lane` of the cascade's operators, kept in registers from here to the outputs (lane r < M: torque row r; lane M + rr: cone
+    // row rr): gd[l][:] = the task block of level l (U_l[r, :] resp. -cone(WM_{U_l})[rr, :]), gcn[:] = the contact-null block
+    // (NwJw[r, :] resp. -cone(WM_N)[rr, :]).  Every right-hand side of the three QPs and every output torque is a lane-local
+    // combination of these with uniform vectors (f*, the QP answers): no base / wrench vectors through LDS between the QPs.
+    PLA(real_t, gd0, 6);  // (one array per level: a run-time level index into one array would send it to scratch)
+    PLA(real_t, gd1, 6);
+    PLA(real_t, gcn, 6);
+    LANES {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { LV(gd0)[j] = real_t(0.0); LV(gd1)[j] = real_t(0.0); }
+    }
     for (int lv = 0; lv < su.n_levels; lv++) {
         auto level_body = [&](auto ttl) {
         constexpr int TTL = decltype(ttl)::value;
         const int t = TTL;
         const real_t *Lt = L + S::c_Lt + lv * T * T;
-        const FastDiv fdt(t);
         const real_t *T1rl = L + S::T1x + lv * T * S::MS;
         real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;
         real_t *Ul = L + S::U + lv * M * T;
-        real_t *Xs = (lv < NLV - 1) ? L + S::xl(lv) : Ul;
         int cond = 1;
         DWBC_SYNC();
         const bool fast = (fastmask >> lv) & 1;
+        PLA(real_t, xr, TTL);  // row `lane` of X = J_kt Lambda of this level
         if (fast) {
+            // J_kt = (T1r W^+)^T came out of the sweep (staging block jk, row per task dof): X = J_kt Lambda, row `lane` per lane
+            const real_t *JKl = L + S::jk + su.fstar_off[lv] * S::MS;
             LANES {
                 real_t tw[TTL];
-                lds_rows_dot<TTL, M, S::MS, 1, 0>(T1rl, LV(w), tw);  // (T1r W^+)[r][lane] = J_kt[lane][r]
+#pragma unroll
+                for (int r = 0; r < TTL; r++) tw[r] = JKl[r * S::MS + (lane < M ? lane : 0)];
 #pragma unroll
                 for (int r3 = 0; r3 < TTL; r3++) {
                     real_t acc = real_t(0.0);
 #pragma unroll
                     for (int r2 = 0; r2 < TTL; r2++) acc += tw[r2] * Lt[r2 * TTL + r3];
-                    if (lane < M) {
-                        Xs[lane * T + r3] = acc;
-                        Ul[lane * T + r3] = acc;
-                    }
+                    LV(xr)[r3] = acc;
                 }
             }
         } else {
@@ -735,7 +853,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
 #pragma unroll
                     for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
                     const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                    if (lane < M) QW[r * M + lane] = acc;
+                    if (lane >= WL && lane < RL) QW[r * M + lane - WL] = acc;  // (column lane - WL of W^+ lives in this lane)
                 }
             }
             DWBC_SYNC();
@@ -763,34 +881,51 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                     real_t acc = real_t(0.0);
 #pragma unroll
                     for (int r2 = 0; r2 < TTL; r2++) acc += jk[r2] * Lt[r2 * TTL + r3];
-                    if (lane < M) {
-                        Xs[lane * T + r3] = acc;
-                        Ul[lane * T + r3] = acc;
-                    }
+                    LV(xr)[r3] = acc;
                 }
             }
         }
-        DWBC_SYNC();
-        DWBC_PSTAMP(16 + 2 * lv);  // rows of J_kt / X of level lv written
-        for (int pl = lv - 1; pl >= 0; pl--) {  // U <- (I - X_pl Y_pl) U,  Y_pl = T1x[pl]
-            const int tp = su.t_dof[pl];
-            const real_t *Xp = L + S::xl(pl), *Yp = L + S::T1x + pl * T * S::MS;
-            for (int idx = th.tid; idx < tp * t; idx += NT) {
-                const int i = fdt.div(idx), j = idx - i * t;
-                real_t acc = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int c = 0; c < M; c++) acc += Yp[i * S::MS + c] * Ul[c * T + j];
-                L[S::c_Z + idx] = acc;
+        DWBC_PSTAMP(16 + 2 * lv);  // rows of J_kt / X of level lv in registers
+        if (lv > 0) {
+            // U_lv = (I - X_0 Y_0) X_lv, Y_0 = T1x[0] (wbd.cpp:228-261): Z = Y_0 X_lv is the one cross-lane reduction of the chain
+            const int tp = su.t_dof[0];
+            const real_t *Yp = L + S::T1x;
+            LANES {
+                if (lane < M) {
+#pragma unroll
+                    for (int r = 0; r < TTL; r++) Ul[lane * T + r] = LV(xr)[r];
+                }
             }
             DWBC_SYNC();
-            for (int idx = th.tid; idx < M * t; idx += NT) {
-                const int i = fdt.div(idx), j = idx - i * t;
-                real_t acc = Ul[i * T + j];
-                _Pragma("unroll 8")
-                for (int p = 0; p < tp; p++) acc -= Xp[i * T + p] * L[S::c_Z + p * t + j];
-                Ul[i * T + j] = acc;
+            for (int idx = th.tid; idx < T * TTL; idx += NT) {
+                const int i = idx / TTL, j = idx - i * TTL;
+                real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+                if (i < tp) {
+#pragma unroll
+                    for (int c = 0; c < M; c++) a4[c & 3] += Yp[i * S::MS + c] * Ul[c * T + j];
+                }
+                L[S::c_Z + idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
             }
             DWBC_SYNC();
+            LANES {
+#pragma unroll
+                for (int j = 0; j < TTL; j++) {
+                    real_t acc = LV(xr)[j];
+#pragma unroll
+                    for (int p = 0; p < T; p++) acc -= LV(gd0)[p] * L[S::c_Z + p * TTL + j];  // (rows of Z beyond tp are zero)
+                    LV(xr)[j] = acc;
+                }
+            }
+            DWBC_SYNC();
+        }
+        LANES {
+#pragma unroll
+            for (int r = 0; r < TTL; r++) {
+                const real_t v_ = lane < M ? LV(xr)[r] : real_t(0.0);
+                LV(gd0)[r] = lv == 0 ? v_ : LV(gd0)[r];
+                if constexpr (NLV > 1) LV(gd1)[r] = lv == 1 ? v_ : LV(gd1)[r];
+                if (lane < M) Ul[lane * T + r] = LV(xr)[r];  // (the wrench maps read U_l from LDS)
+            }
         }
         if (!cond) rankbad |= (1 << lv);
         DWBC_PSTAMP(17 + 2 * lv);  // null-space chain of level lv done
@@ -800,35 +935,85 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     DWBC_SYNC();
     DWBC_STAMP(5);  // stage 3a done
 
-    // ---- the QP cascade (dwbc.cpp:818-873, 941-1127) and the contact redistribution QP (dwbc.cpp:1372-1568): dwbc_cycle2.h
+    // ---- the QP cascade (dwbc.cpp:818-873, 941-1127) and the contact redistribution QP (dwbc.cpp:1372-1568)
     const int nlim = su.has_tau_lim ? 2 * M : 0;
     const int ncone = 10 * nc;
     int st_task = 1, fail_level = -1, st_redis = 1;
     const real_t *fs_in = L + S::fs;
-    real_t *base = L + S::t_base, *fv = L + S::t_fv, *WM = L + S::wm, *wacc = L + S::t_wacc, *clast = L + S::t_cl;
+    real_t *WM = L + S::wm;
     constexpr int WLD = S::WLD;
     const int colN = 1 + su.fstar_total;
     QpLaneConst qc;
     PL(real_t, sfin);  // slack of the lane's QP row at the point the last QP returned (qp_solve_wave)
-    PL(real_t, grn);   // norm of the lane's row of the contact redistribution QP
+    PL(real_t, tgl);   // torque lanes: torque_grav_[lane]; cone lanes: the cone row applied to the gravity wrench J̄ tau_grav - P_C
+    PL(real_t, tta);   // what the committed levels add to it: sum_l gd_l . (f*_l + f*_qp_l)  (torque lanes: torque_task_[lane])
+    PL(real_t, Tl);    // torque lanes: the torque limit; cone lanes: 0
     bool skip_redis = false;
-    constexpr bool wm_ok = true;
     qp_lane_consts<N>(su, act_c[0], act_c[1], qc);
     wrench_maps<N, NT, S>(th, su, L, JbT, cd, k, WM);
-    for (int i = th.tid; i < C; i += NT) {
-        real_t acc = real_t(0.0);
-        if (i < cd) {
-            const int a = i / 6, h = (i % 6) / 3, x = i % 3;
-            const real_t *R = L + S::Rc + a * 9;
-            const real_t *pc3 = L + S::PC + 6 * a + 3 * h;
-            acc = WM[i * WLD] - (R[x] * pc3[0] + R[3 + x] * pc3[1] + R[6 + x] * pc3[2]);
+    DWBC_SYNC();
+    LANES {
+        const bool tqr = lane < M;
+        const bool cn = lane >= M && lane - M < ncone;
+        const int row2 = cn ? LV(qc.row2) : 0, rowo = cn ? LV(qc.rowo) : 0;
+        const real_t ca = -LV(qc.c2), cb = -LV(qc.sg);
+        // unconditional reads from clamped addresses, masked afterwards (one straight-line path for torque and cone lanes)
+        const real_t *pa = tqr ? L + S::NwJw + lane * 6 : WM + row2 * WLD + colN;
+        const real_t *pb = WM + rowo * WLD + colN;
+        real_t va[6], vb[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { va[j] = pa[j]; vb[j] = pb[j]; }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const real_t v = tqr ? va[j] : ca * va[j] + cb * vb[j];
+            LV(gcn)[j] = ((tqr || cn) && j < k) ? v : real_t(0.0);
         }
-        wacc[i] = acc;
-        if (i < S::K) clast[i] = real_t(0.0);
+#pragma unroll
+        for (int l = 0; l < NLV; l++) {
+            const int off = l < su.n_levels ? 1 + su.fstar_off[l] : 1, tl = l < su.n_levels ? su.t_dof[l] : 0;
+            real_t ua[6], ub[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { ua[j] = WM[row2 * WLD + off + j]; ub[j] = WM[rowo * WLD + off + j]; }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const real_t v = (cn && j < tl) ? ca * ua[j] + cb * ub[j] : real_t(0.0);
+                if (l == 0) LV(gd0)[j] = tqr ? LV(gd0)[j] : v;
+                else LV(gd1)[j] = tqr ? LV(gd1)[j] : v;
+            }
+        }
+        // gravity part of the right-hand sides: torque_grav_[lane], resp. the cone row on J̄[:, 6:] tau_grav - P_C (contact frame)
+        const int a2 = row2 / 6, x2 = row2 % 3, h2 = (row2 % 6) / 3, ao = rowo / 6, xo = rowo % 3, ho = (rowo % 6) / 3;
+        const real_t *R2 = L + S::Rc + a2 * 9, *Ro = L + S::Rc + ao * 9;
+        const real_t *p2 = L + S::PC + 6 * a2 + 3 * h2, *po = L + S::PC + 6 * ao + 3 * ho;
+        const real_t w2 = WM[row2 * WLD] - (R2[x2] * p2[0] + R2[3 + x2] * p2[1] + R2[6 + x2] * p2[2]);
+        const real_t wo = WM[rowo * WLD] - (Ro[xo] * po[0] + Ro[3 + xo] * po[1] + Ro[6 + xo] * po[2]);
+        const real_t tgv = L[S::tg + (tqr ? lane : 0)];
+        LV(tgl) = tqr ? tgv : (cn ? ca * w2 + cb * wo : real_t(0.0));
+        LV(tta) = real_t(0.0);
+        LV(Tl) = tqr ? LV(qc.taul) : real_t(0.0);
+        LV(sfin) = real_t(0.0);
+    }
+    // The rows leave the registers again: 18 doubles per lane [gd_0 | gd_1 | gcn] in an LDS block of their own (over Jbar^T, NwJw, U and
+    // T1x, all dead now that the wrench maps and the rows exist), read back in 16-byte pieces where a QP or an output needs them --
+    // kept in registers across the three solves they pushed the solver over the 256-register cap (56 spilled registers, reloaded
+    // behind serial waits inside the cascade).
+    constexpr int RSW = 18;
+    static_assert(64 * RSW <= S::c_T1 - S::JbT && S::JbT % 2 == 0, "row block over the dead Jbar^T .. T1x region");
+    real_t *rowblk = L + S::JbT;
+    DWBC_SYNC();
+    LANES {
+        real_t *rw = rowblk + lane * RSW;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { rw[j] = LV(gd0)[j]; rw[6 + j] = LV(gd1)[j]; rw[12 + j] = LV(gcn)[j]; }
     }
     DWBC_SYNC();
-    redis_row_norms<N, S>(L, nlim, ncone, k, qc, WM + colN, grn);
-    DWBC_STAMP(6);  // wrench maps done
+    DWBC_STAMP(6);  // wrench maps done, rows stored
+    real_t *fx = L + S::t_base;  // f* + f*_qp of the committed levels (NLV x 6, LDS: only the wrench output reads it again)
+    real_t ctot[6];      // contact_qp_ of the last committed level (+ the redistribution's answer): what torque_contact_ stands for
+    for (int j = th.tid; j < NLV * 6; j += NT) fx[j] = real_t(0.0);
+    DWBC_SYNC();
+#pragma unroll
+    for (int j = 0; j < 6; j++) ctot[j] = real_t(0.0);
     for (int qi = 0; qi <= su.n_levels; qi++) {
         const bool is_task = qi < su.n_levels;
         if (is_task && !st_task) continue;
@@ -841,43 +1026,49 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             break;
         }
         const int t = is_task ? su.t_dof[qi] : 0;
-        const real_t *Ul = L + S::U + (is_task ? qi : 0) * M * T;
-        const real_t *fs = fs_in + (is_task ? su.fstar_off[qi] : 0);
-        const int colL = 1 + (is_task ? su.fstar_off[qi] : 0);
+        const bool t6 = t > 3;
         if (is_task && (rankbad & (1 << qi))) { st_task = 0; fail_level = qi; continue; }
-        DWBC_SYNC();
-        {
-            // straight-line: six unconditional reads per lane, the entries beyond t (or k) masked afterwards -- a loop with a run-time
-            // trip count puts every read behind its own wait
-            real_t f6[6];
+        real_t f6[6];  // f* of the level (task QP) resp. contact_qp_ handed over by the last level (redistribution); beyond t / k: 0
 #pragma unroll
-            for (int j = 0; j < 6; j++) f6[j] = is_task ? (j < t ? fs[j] : real_t(0.0)) : (j < k ? clast[j] : real_t(0.0));
-            for (int i = th.tid; i < M + C; i += NT) {
-                const bool tq = i < M;
-                const int r = tq ? 0 : i - M;
-                const real_t *row = tq ? Ul + i * T : WM + r * WLD + (is_task ? colL : colN);
-                real_t u6[6];
+        for (int j = 0; j < 6; j++) f6[j] = is_task ? (j < t ? fs_in[su.fstar_off[qi] + j] : real_t(0.0)) : ctot[j];
+        QpRows R;
+        const int nv = is_task ? t + k : k;
+        LANES {
+            const bool tq = lane < M && nlim != 0, cn = lane >= M && lane - M < ncone;
+            const bool act = tq || cn;
+            const real_t *rw = rowblk + lane * RSW;
+            real_t gl[6], gc6[6];  // the level's task block (its offset in the row is uniform) and the contact-null block
 #pragma unroll
-                for (int j = 0; j < 6; j++) u6[j] = row[j];
-                real_t acc = tq ? L[S::tg + i] + L[S::tt + i] + (is_task ? real_t(0.0) : L[S::tc + i]) : wacc[r];
+            for (int j = 0; j < 6; j++) { gl[j] = rw[(qi == 1 ? 6 : 0) + j]; gc6[j] = rw[12 + j]; }
+            real_t dot = real_t(0.0);
 #pragma unroll
-                for (int j = 0; j < 6; j++) acc += ((is_task ? j < t : (j < k && !tq)) ? u6[j] * f6[j] : real_t(0.0));
-                if (tq) base[i] = acc; else fv[r] = acc;
+            for (int j = 0; j < 6; j++) dot += (is_task ? gl[j] : gc6[j]) * f6[j];
+            const real_t v = (LV(tgl) + LV(tta)) + dot;   // torque lanes: tau_grav + tau_task so far + U_l f* (+ NwJw contact_qp_)
+            // variables [delta (t = 6 | 3); c_hat (k)] of a task QP, [c (k)] of the redistribution -- static register indices, uniform selects
+            const real_t sc = kQpScaleGI;
+#pragma unroll
+            for (int j = 0; j < kQpN; j++) {
+                real_t g_;
+                if (j < 3) g_ = is_task ? gl[j] : gc6[j];
+                else if (j < 6) g_ = is_task ? (t6 ? gl[j] : sc * gc6[j - 3]) : gc6[j];
+                else if (j < 9) g_ = is_task ? (t6 ? sc * gc6[j - 6] : sc * gc6[j - 3]) : real_t(0.0);
+                else g_ = (is_task && t6) ? sc * gc6[j - 6] : real_t(0.0);
+                LV(R.g)[j] = (act && j < nv) ? g_ : real_t(0.0);
             }
+            LV(R.hi) = act ? LV(Tl) - v : DWBC_QP_INF;   // (reference src/dwbc.cpp:1001-1016 torque rows, :1041-1053 cone rows)
+            LV(R.lo) = tq ? LV(Tl) + v : DWBC_QP_INF;
+            LV(R.id_hi) = tq ? lane : (cn ? nlim + (lane - M) : -1);
+            LV(R.id_lo) = tq ? M + lane : -1;
         }
-        DWBC_SYNC();
-        if (qi == 0) DWBC_PSTAMP(24);  // level 0: base torque and wrench right-hand side
-        if (!is_task) DWBC_PSTAMP(26);  // redistribution: base torque and wrench right-hand side
+        if (qi == 0) DWBC_PSTAMP(24);  // level 0: rows ready
+        if (!is_task) DWBC_PSTAMP(26);  // redistribution: rows ready
         QpResult qres;
         {
-            const real_t *P1 = is_task ? Ul : L + S::NwJw;
-            static_assert(T == 6, "stride of U equals the stride of NwJw");
-            const int n1 = is_task ? t : k, n2 = is_task ? k : 0;
-            const real_t *W1 = WM + (is_task ? colL : colN);
-            qp_rows_and_solve<N, NB, 0>(su, L, nlim, ncone, act_c[0], act_c[1], P1, 6, n1, L + S::NwJw, 6, n2,
-                                        is_task ? kQpScaleGI : real_t(1.0), W1, WLD, WM + colN, WLD, fv, base, n1,
-                                        is_task ? su.qp_max_iter_task : su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x, nullptr, &qc,
-                                        is_task ? kQpTol : kQpFeasTol, sfin);
+            const int tv = is_task ? t : k, mi = is_task ? su.qp_max_iter_task : su.qp_max_iter_contact;
+            const real_t tol = is_task ? kQpTol : kQpFeasTol;
+            if (nv <= 6) qp_solve_wave<0, 6>(R, nv, tv, mi, qres, L + S::qp_V, nullptr, tol, sfin);
+            else if (nv <= 9) qp_solve_wave<0, 9>(R, nv, tv, mi, qres, L + S::qp_V, nullptr, tol, sfin);
+            else qp_solve_wave<0, 12>(R, nv, tv, mi, qres, L + S::qp_V, nullptr, tol, sfin);
         }
         const int slot = is_task ? qi : kMaxLevels;
         if (diag && th.tid == 0) {
@@ -889,99 +1080,97 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (diag && th.tid == 0 && qi == 0)
             for (int i_ = 0; i_ < 9; i_++) diag[DG_FTIME + 32 + i_] = (int)qres.tm[i_];
 #endif
-        const real_t *x = L + S::qp_x;
         if (is_task) {
             if (!qres.status) { st_task = 0; fail_level = qi; continue; }
-            {
-                real_t fx[6], xc[6];  // f* + f*_qp of the level, contact_qp_ (uniform), entries beyond t / k zero
+            real_t fxl[6];
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    fx[j] = j < t ? fs[j] + x[j] : real_t(0.0);
-                    xc[j] = j < k ? x[t + j] : real_t(0.0);
-                }
-                for (int i = th.tid; i < M + C; i += NT) {
-                    const bool tq = i < M;
-                    const int r = tq ? 0 : i - M;
-                    const real_t *row = tq ? Ul + i * T : WM + r * WLD + colL;
-                    real_t u6[6], n6[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) { u6[j] = row[j]; n6[j] = L[S::NwJw + (tq ? i : 0) * 6 + j]; }
-                    real_t acc = real_t(0.0), c = real_t(0.0);
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        acc += j < t ? u6[j] * fx[j] : real_t(0.0);
-                        c += j < k ? n6[j] * xc[j] : real_t(0.0);
-                    }
-                    if (tq) {
-                        L[S::tt + i] += acc;  // torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp)   (dwbc.cpp:839-849)
-                        L[S::tc + i] = c;     // torque_contact_ = NwJw contact_qp_              (dwbc.cpp:851)
-                    } else {
-                        wacc[r] += acc;       // the wrench of what this level commits
-                        if (r < S::K) clast[r] = r < k ? x[t + r] : real_t(0.0);  // contact_qp_ for the redistribution's start
-                    }
-                }
+            for (int j = 0; j < 6; j++) {
+                fxl[j] = j < t ? f6[j] + qres.x[j] : real_t(0.0);                     // f* + f*_qp (dwbc.cpp:839-849)
+                ctot[j] = j < k ? (t6 ? qres.x[6 + j] : qres.x[3 + j]) : real_t(0.0);  // contact_qp_ (dwbc.cpp:851)
             }
-            if (qi == su.n_levels - 1 && k > 0 && (true)) {
+            LANES {
+                real_t v_ = real_t(0.0);
+#pragma unroll
+                for (int j = 0; j < 6; j++) v_ = (lane == j) ? fxl[j] : v_;
+                if (lane < 6) fx[qi * 6 + lane] = v_;
+            }
+            LANES {
+                const real_t *rw = rowblk + lane * RSW + (qi == 1 ? 6 : 0);
+                real_t acc = real_t(0.0);
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc += rw[j] * fxl[j];
+                LV(tta) += acc;  // torque lanes: torque_task_ += Null_{i-1} J_kt Lambda (f* + f*_qp); cone lanes: the wrench it adds, on the cone row
+            }
+            if (qi == su.n_levels - 1 && k > 0) {
                 // The rows of the redistribution QP (dwbc.cpp:1458-1517) are the rows of this level's QP seen at c = 0 with the total
                 // torque on the right-hand side, so its first look at them -- slack / |row| against the tolerance of canon rule 5 --
-                // can be taken from the slacks this QP ended with.  Nothing violated: the redistribution would return c = 0 after
-                // filling and normalising its 53 rows (6 k cycles in the stage table); it is skipped.
+                // can be taken from the slacks this QP ended with.  Nothing violated: the redistribution would return c = 0; it is skipped.
+                PL(real_t, grn);
                 LANES {
                     const bool tq = lane < M && nlim != 0, cn = lane >= M && lane - M < ncone;
-                    LV(grn) = (tq || cn) ? LV(sfin) / LV(grn) : DWBC_QP_INF;  // (grn is not needed again)
+                    const real_t *rw = rowblk + lane * RSW + 12;
+                    real_t s2 = real_t(0.0);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { const real_t g_ = rw[j]; s2 += g_ * g_; }
+                    const real_t gn = s2 < kQpZeroRow * kQpZeroRow ? real_t(1.0) : sqrt(s2);
+                    LV(grn) = (tq || cn) ? LV(sfin) / gn : DWBC_QP_INF;
                 }
                 int wl_;
                 WAVE_ARGMIN_F32(grn, wl_);
                 skip_redis = !(BCAST(grn, wl_) < -kQpFeasTol);
             }
         } else if (qres.status) {
-            for (int i = th.tid; i < M + S::K; i += NT) {
-                if (i >= M) { clast[i - M] += (i - M < k) ? x[i - M] : real_t(0.0); continue; }  // contact_qp_ + redistribution: what torque_contact_ stands for
-                real_t c = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int j = 0; j < k; j++) c += L[S::NwJw + i * 6 + j] * x[j];
-                L[S::tc + i] += c;
-            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) ctot[j] += j < k ? qres.x[j] : real_t(0.0);  // contact_qp_ + redistribution (dwbc.cpp:1549)
         } else {
             st_redis = 0;
-            for (int i = th.tid; i < M + S::K; i += NT) {
-                if (i < M) L[S::tc + i] = real_t(0.0); else clast[i - M] = real_t(0.0);
-            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) ctot[j] = real_t(0.0);
         }
-        DWBC_SYNC();
-        if (qi == 0) DWBC_PSTAMP(25);  // level 0: committed (torque_task_, torque_contact_, running wrench)
+        if (qi == 0) DWBC_PSTAMP(25);  // level 0: committed
         if (!is_task) DWBC_PSTAMP(27);  // redistribution QP done and committed
     }
-    if (k == 0) {
-        for (int i = th.tid; i < M; i += NT) L[S::tc + i] = real_t(0.0);
-    }
     DWBC_SYNC();
+    // ---- outputs: the three torques from the rows the lanes hold (straight to HBM), the wrench from the wrench maps
     io_t *tau = io.tau + (size_t)inst * 3 * M;
-    for (int i = th.tid; i < 3 * M; i += NT) tau[i] = too_many ? real_t(0.0) : L[S::tg + i];
+    LANES {
+        if (lane < M) {
+            const real_t *rw = rowblk + lane * RSW + 12;
+            real_t tcv = real_t(0.0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) tcv += rw[j] * ctot[j];   // torque_contact_ = NwJw (contact_qp_ [+ redistribution])
+            tau[lane] = too_many ? real_t(0.0) : LV(tgl);
+            tau[M + lane] = too_many ? real_t(0.0) : LV(tta);
+            tau[2 * M + lane] = (too_many || k == 0) ? real_t(0.0) : tcv;
+        }
+    }
     DWBC_PSTAMP(28);  // torques stored
     io_t *wr = io.wrench + (size_t)inst * 12;
-    // getContactForce(tau_total) = Jbar[:, 6:] tau - P_C (wbd.cpp:268-271).  In the contact frames that is the running wrench of the
-    // cascade plus the contact-null part (wacc + F_N (contact_qp_ + redistribution): every term a column combination of the wrench
-    // maps); rotated back with blockdiag(R_a, R_a).  (Rounds 1-2 multiplied Jbar with the summed torque again: 33 x 4 LDS reads per lane.)
+    // getContactForce(tau_total) = Jbar[:, 6:] tau - P_C (wbd.cpp:268-271).  In the contact frames that is a column combination of the
+    // wrench maps: gravity column - P_C + sum_l WM_{U_l} (f* + f*_qp)_l + WM_N (contact_qp_ + redistribution); rotated back with
+    // blockdiag(R_a, R_a).
     for (int i = th.tid; i < 12; i += NT) {
         real_t acc = real_t(0.0);
-        if (i < cd && !too_many && wm_ok) {
+        if (i < cd && !too_many) {
             const int a = i / 6, h = (i % 6) / 3, y = i % 3;
             const real_t *R = L + S::Rc + a * 9;
+            const real_t *pc3 = L + S::PC + 6 * a + 3 * h;
             real_t loc[3];
 #pragma unroll
             for (int x_ = 0; x_ < 3; x_++) {
                 const int r = 6 * a + 3 * h + x_;
-                real_t v = wacc[r];
+                real_t v = WM[r * WLD] - (R[x_] * pc3[0] + R[3 + x_] * pc3[1] + R[6 + x_] * pc3[2]);
 #pragma unroll
-                for (int j = 0; j < 6; j++) v += (j < k) ? WM[r * WLD + colN + j] * clast[j] : real_t(0.0);
+                for (int l = 0; l < NLV; l++) {
+                    const int off = l < su.n_levels ? 1 + su.fstar_off[l] : 1;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v += (l < su.n_levels && j < su.t_dof[l]) ? WM[r * WLD + off + j] * fx[l * 6 + j] : real_t(0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += (j < k) ? WM[r * WLD + colN + j] * ctot[j] : real_t(0.0);
                 loc[x_] = v;
             }
             acc = R[y * 3] * loc[0] + R[y * 3 + 1] * loc[1] + R[y * 3 + 2] * loc[2];
-        } else if (i < cd && !too_many) {
-            acc = -L[S::PC + i];
-            _Pragma("unroll 8")
-            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * (L[S::tg + c] + L[S::tt + c] + L[S::tc + c]);
         }
         wr[i] = acc;
     }

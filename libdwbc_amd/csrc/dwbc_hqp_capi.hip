@@ -90,6 +90,8 @@ struct dwbc_hqp {
     bool attr_set = false;
     LqpCfg lqp{};  // set by dwbc_batch_configure_lqp / _lqp_r
     bool is_lqp = false, lqp_reduced = false;
+    // row weights V_ / W_ of HQP_Hierarch (src/dwbc_hqp.cpp:503-553), per level, B x m x m and B x e x e (empty: identity)
+    std::vector<std::vector<double>> wV, wW;
 };
 
 namespace {
@@ -168,6 +170,8 @@ int dwbc_hqp_clear(dwbc_hqp *h) {
     hqp_free(h);
     h->d.n_levels = 0;
     h->stage.clear();
+    h->wV.clear();
+    h->wW.clear();
     h->is_lqp = false;
     h->share_cost = false;
     return 1;
@@ -254,14 +258,76 @@ int dwbc_hqp_prepare(dwbc_hqp *h) {
     return 1;
 }
 
+// HQP_Hierarch::updateInequalityCostWeight / updateEqualityCostWeight / updateConstraintWeight (src/dwbc_hqp.cpp:503-553).  The
+// reference reads V_ and W_ in solvefirst only (:245-254: qp_A = V A, ubA = -V a, cost |W B y + W b|^2) and nowhere in
+// solveSequentialSingle, so weights of levels beyond 0 are stored and never used, exactly as there.  V: B x m x m, W: B x e x e, row major,
+// per instance; NULL = identity.
+int dwbc_hqp_update_constraint_weight(dwbc_hqp *h, int level, const double *V, const double *W) {
+    if (level < 0 || level >= h->d.n_levels) return fail("HQP: bad level");
+    const size_t m = h->d.m[level], e = h->d.e[level];
+    if ((int)h->wV.size() < h->d.n_levels) { h->wV.resize(h->d.n_levels); h->wW.resize(h->d.n_levels); }
+    if (V) h->wV[level].assign(V, V + (size_t)h->B * m * m); else h->wV[level].clear();
+    if (W) h->wW[level].assign(W, W + (size_t)h->B * e * e); else h->wW[level].clear();
+    return 1;
+}
+
+namespace {
+int get_block(dwbc_hqp *h, int off, int len, double *dst) {
+    if (len == 0) return 1;
+    HIP_OK(hipMemcpy2D(dst, (size_t)len * 8, h->d_rec + off, (size_t)h->d.rec * 8, (size_t)len * 8, h->B, hipMemcpyDeviceToHost));
+    return 1;
+}
+// out (r x c per instance) = Wt (r x r per instance) * in (r x c per instance)
+void weigh(const std::vector<double> &Wt, const std::vector<double> &in, std::vector<double> &out, int B, int r, int c) {
+    out.assign(in.size(), 0.0);
+    for (int i = 0; i < B; i++)
+        for (int a = 0; a < r; a++)
+            for (int k = 0; k < r; k++) {
+                const double w = Wt[((size_t)i * r + a) * r + k];
+                if (w == 0.0) continue;
+                for (int j = 0; j < c; j++) out[((size_t)i * r + a) * c + j] += w * in[((size_t)i * r + k) * c + j];
+            }
+}
+}  // namespace
+
 int dwbc_hqp_solve_first(dwbc_hqp *h, int init) {
     (void)init;
     // level 0 alone over the full variable: run the cascade restricted to one level
     if (!h->laid_out && !dwbc_hqp_prepare(h)) return 0;
+    const int nv = h->d.nv, m = h->d.m[0], e = h->d.e[0];
+    const bool wv = !h->wV.empty() && !h->wV[0].empty() && m > 0, ww = !h->wW.empty() && !h->wW[0].empty() && e > 0;
+    std::vector<double> A, a, Bm, b, t;
+    if (wv || ww) {
+        // solvefirst poses level 0 on (V A, V a, W B, W b); every later solve reads the unweighted matrices again (as the reference
+        // does), so they are weighed for this launch only and put back: a host round trip, on a path the reference takes once per set-up
+        HIP_OK(hipSetDevice(h->device));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        if (wv) {
+            A.resize((size_t)h->B * m * nv); a.resize((size_t)h->B * m);
+            if (!get_block(h, h->d.oA[0], m * nv, A.data()) || !get_block(h, h->d.oa[0], m, a.data())) return 0;
+            weigh(h->wV[0], A, t, h->B, m, nv);
+            if (!put_block(h, h->d.oA[0], m * nv, t.data())) return 0;
+            weigh(h->wV[0], a, t, h->B, m, 1);
+            if (!put_block(h, h->d.oa[0], m, t.data())) return 0;
+        }
+        if (ww) {
+            Bm.resize((size_t)h->B * e * nv); b.resize((size_t)h->B * e);
+            if (!get_block(h, h->d.oB[0], e * nv, Bm.data()) || !get_block(h, h->d.ob[0], e, b.data())) return 0;
+            weigh(h->wW[0], Bm, t, h->B, e, nv);
+            if (!put_block(h, h->d.oB[0], e * nv, t.data())) return 0;
+            weigh(h->wW[0], b, t, h->B, e, 1);
+            if (!put_block(h, h->d.ob[0], e, t.data())) return 0;
+        }
+    }
     const int keep = h->d.n_levels;
     h->d.n_levels = 1;
-    const int ok = launch_solve(h, 1);
+    int ok = launch_solve(h, 1);
     h->d.n_levels = keep;
+    if (wv || ww) {
+        HIP_OK(hipStreamSynchronize(h->stream));
+        if (wv) ok = ok && put_block(h, h->d.oA[0], m * nv, A.data()) && put_block(h, h->d.oa[0], m, a.data());
+        if (ww) ok = ok && put_block(h, h->d.oB[0], e * nv, Bm.data()) && put_block(h, h->d.ob[0], e, b.data());
+    }
     return ok;
 }
 int dwbc_hqp_solve_sequential(dwbc_hqp *h, int init) {

@@ -96,11 +96,10 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
     PL(int, key);
     PL(real_t, m);
     PL(real_t, dz);
-    real_t xu[NV];
+    PL(real_t, xl);         // lanes 0..NV-1: the iterate, one variable per lane (z = H n lives in the same lanes: one FMA per step)
     DWBC_QPT_INIT();
-#pragma unroll
-    for (int i = 0; i < NV; i++) xu[i] = real_t(0.0);
     LANES {
+        LV(xl) = real_t(0.0);
         DWBC_LANE_OPAQUE(lq);
         real_t s2 = real_t(0.0), a2 = real_t(0.0);
 #pragma unroll
@@ -253,9 +252,10 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
         if (!(tstep < DWBC_QP_INF)) { status = 0; break; }
         const bool full = zok && t2 <= t1;
         if (zok) {
-#pragma unroll
-            for (int i = 0; i < NV; i++) xu[i] += tstep * zu[i];
-            LANES { LV(d) += tstep * LV(dz); }
+            LANES {
+                LV(d) += tstep * LV(dz);
+                LV(xl) += tstep * LV(m);  // (lanes 0..NV-1: m = z; the value in the other lanes is not used)
+            }
         }
         LANES { LV(u) -= tstep * LV(m); }
         up += tstep;
@@ -336,6 +336,9 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
         }
     };
     if (!status || q == 0) { final_slack(0); return; }  // x = 0: failure (caller zeroes the correction) or no active constraint
+    real_t xu[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) xu[i] = BCAST(xl, i);
     // Tikhonov point on the working set = the GI iterate (the fallback of the canon, and the answer when one of the two
     // variable blocks is empty)
 #pragma unroll

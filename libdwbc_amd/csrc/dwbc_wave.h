@@ -187,6 +187,17 @@ DWBC_WDEV real_t pick12(const real_t *a, int lane) {
         for (int l_ = 1; l_ < 64; l_++)                                                            \
             if ((float)(val)[l_] < m_) { m_ = (float)(val)[l_]; out_lane = l_; }                   \
     } while (0)
+// inclusive prefix sum over the lanes of element j of a per-lane array (in place)
+#define WAVE_PREFIX_A(arr, j)                                                                      \
+    do {                                                                                           \
+        for (int l_ = 1; l_ < 64; l_++) (arr)[l_][(j)] += (arr)[l_ - 1][(j)];                      \
+    } while (0)
+// sum of a per-lane value over the 64 lanes (uniform result)
+#define WAVE_SUM(val, out_v)                                                                       \
+    do {                                                                                           \
+        out_v = (val)[0];                                                                          \
+        for (int l_ = 1; l_ < 64; l_++) out_v += (val)[l_];                                        \
+    } while (0)
 // exact arg-min over lanes 16..31 only
 #define WAVE_ARGMIN_ROW1(val, key, out_v, out_k)                                                   \
     do {                                                                                           \
@@ -257,6 +268,67 @@ __device__ __forceinline__ int wave_argmin_f32(real_t v) {
     const unsigned long long b = __ballot(f == mall);
     return b ? (int)__builtin_ctzll(b) : 0;
 }
+// sum over the wave of a per-lane value (DPP row shifts + row broadcasts; lanes without a source add zero), result uniform
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#define DWBC_DPP_STEP(ctrl, rmask)                                                                         \
+    {                                                                                                      \
+        const long long b_ = __double_as_longlong(x);                                                      \
+        const int lo_ = (int)(unsigned)(b_ & 0xffffffffll), hi_ = (int)(unsigned)((unsigned long long)b_ >> 32); \
+        const int olo_ = __builtin_amdgcn_update_dpp(0, lo_, ctrl, rmask, 0xf, true);                      \
+        const int ohi_ = __builtin_amdgcn_update_dpp(0, hi_, ctrl, rmask, 0xf, true);                      \
+        x += __longlong_as_double((long long)(((unsigned long long)(unsigned)ohi_ << 32) | (unsigned)olo_)); \
+    }
+    DWBC_DPP_STEP(0x111, 0xf)
+    DWBC_DPP_STEP(0x112, 0xf)
+    DWBC_DPP_STEP(0x114, 0xf)
+    DWBC_DPP_STEP(0x118, 0xf)  // lane 15 of each row: the row sum
+    DWBC_DPP_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    DWBC_DPP_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63: the wave sum
+#undef DWBC_DPP_STEP
+    return readlane_f64(x, 63);
+}
+// inclusive prefix sum over the lanes (Hillis-Steele inside each DPP row of 16, then the row totals: row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ double wave_prefix_f64(double x) {
+#define DWBC_DPP_STEP(ctrl, rmask)                                                                         \
+    {                                                                                                      \
+        const long long b_ = __double_as_longlong(x);                                                      \
+        const int lo_ = (int)(unsigned)(b_ & 0xffffffffll), hi_ = (int)(unsigned)((unsigned long long)b_ >> 32); \
+        const int olo_ = __builtin_amdgcn_update_dpp(0, lo_, ctrl, rmask, 0xf, true);                      \
+        const int ohi_ = __builtin_amdgcn_update_dpp(0, hi_, ctrl, rmask, 0xf, true);                      \
+        x += __longlong_as_double((long long)(((unsigned long long)(unsigned)ohi_ << 32) | (unsigned)olo_)); \
+    }
+    DWBC_DPP_STEP(0x111, 0xf)
+    DWBC_DPP_STEP(0x112, 0xf)
+    DWBC_DPP_STEP(0x114, 0xf)
+    DWBC_DPP_STEP(0x118, 0xf)
+    DWBC_DPP_STEP(0x142, 0xa)
+    DWBC_DPP_STEP(0x143, 0xc)
+#undef DWBC_DPP_STEP
+    return x;
+}
+__device__ __forceinline__ float wave_prefix_f64(float x) {
+#define DWBC_DPP_STEP(ctrl, rmask) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, true));
+    DWBC_DPP_STEP(0x111, 0xf)
+    DWBC_DPP_STEP(0x112, 0xf)
+    DWBC_DPP_STEP(0x114, 0xf)
+    DWBC_DPP_STEP(0x118, 0xf)
+    DWBC_DPP_STEP(0x142, 0xa)
+    DWBC_DPP_STEP(0x143, 0xc)
+#undef DWBC_DPP_STEP
+    return x;
+}
+__device__ __forceinline__ float wave_sum_f64(float x) {
+#define DWBC_DPP_STEP(ctrl, rmask) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, true));
+    DWBC_DPP_STEP(0x111, 0xf)
+    DWBC_DPP_STEP(0x112, 0xf)
+    DWBC_DPP_STEP(0x114, 0xf)
+    DWBC_DPP_STEP(0x118, 0xf)
+    DWBC_DPP_STEP(0x142, 0xa)
+    DWBC_DPP_STEP(0x143, 0xc)
+#undef DWBC_DPP_STEP
+    return readlane_f64(x, 63);
+}
 // order-preserving map double -> u64, low 7 bits replaced by the lane so that keys are unique
 __device__ __forceinline__ unsigned long long argmin_key(real_t v, int lane) {
     unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
@@ -273,6 +345,8 @@ __device__ __forceinline__ unsigned long long argmin_key(real_t v, int lane) {
         out_k = dwbc::readlane_i32((key), wl_);                                                    \
     } while (0)
 #define WAVE_ARGMIN_F32(val, out_lane) out_lane = dwbc::wave_argmin_f32(val)
+#define WAVE_SUM(val, out_v) out_v = dwbc::wave_sum_f64(val)
+#define WAVE_PREFIX_A(arr, j) (arr)[(j)] = dwbc::wave_prefix_f64((arr)[(j)])
 #define WAVE_ARGMIN_ROW1(val, key, out_v, out_k)                                                   \
     do {                                                                                           \
         const unsigned long long m_ = dwbc::row1_min_u64(dwbc::argmin_key((val), lane));           \

@@ -66,6 +66,24 @@ class HQP:
     def normalizeConstraintMatrix(self, level):
         _check(self._L.dwbc_hqp_normalize_constraint_matrix(self._h, level))
 
+    def updateConstraintWeight(self, level, V=None, W=None):
+        """HQP_Hierarch::updateConstraintWeight / updateInequalityCostWeight / updateEqualityCostWeight (reference
+        src/dwbc_hqp.cpp:503-553): V (ineq x ineq) and W (eq x eq), full matrices or vectors taken as diagonals, one per instance or
+        broadcast; None = identity.  Read by solvefirst() only, as in the reference (:245-254)."""
+        m, e = self._sizes[level]
+
+        def full(x, n):
+            if x is None or n == 0:
+                return None
+            x = np.asarray(x, np.float64)
+            if x.ndim == 1 or (x.ndim == 2 and x.shape == (self.B, n) and n != self.B):
+                x = x[..., :, None] * np.eye(n)
+            return self._arr(x, (self.B, n, n))
+
+        V_, W_ = full(V, m), full(W, e)
+        p = lambda x: x.ctypes.data if x is not None else None
+        _check(self._L.dwbc_hqp_update_constraint_weight(self._h, level, p(V_), p(W_)))
+
     def set_answer(self, level, y_ans, v_ans=None):
         y_ = self._arr(y_ans, (self.B, self.nv))
         v_ = self._arr(v_ans, (self.B, self._sizes[level][0])) if v_ans is not None else None

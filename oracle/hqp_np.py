@@ -208,6 +208,18 @@ class HQP_Hierarch:
         self.qp_iter_ = 0
         self.qp_status_ = 1
         self.exact_ = False  # JACC: equalities hold exactly (least-norm step), inequalities only declared (slack 0)
+        self.V_, self.W_ = np.eye(ineq), np.eye(eq)  # row weights, read by solvefirst only (dwbc_hqp.cpp:245-254, 503-553)
+
+    def updateInequalityCostWeight(self, V):  # dwbc_hqp.cpp:503-510 (a vector is a diagonal)
+        V = np.array(V, float)
+        self.V_ = np.diag(V) if V.ndim == 1 else V
+
+    def updateEqualityCostWeight(self, W):  # dwbc_hqp.cpp:521-528
+        W = np.array(W, float)
+        self.W_ = np.diag(W) if W.ndim == 1 else W
+
+    def updateConstraintWeight(self, V, W):  # dwbc_hqp.cpp:549-553
+        self.V_, self.W_ = np.array(V, float), np.array(W, float)
 
     def updateConstraintMatrix(self, A, a, B, b):  # dwbc_hqp.cpp:530-547
         if self.ineq_const_size_ > 0:
@@ -288,9 +300,16 @@ class HQP:
         h.w_ans_ = h.B_ @ h.y_ans_ + h.b_
         return st
 
-    def solvefirst(self):  # dwbc_hqp.cpp:222-289: level 0 over the full variable (no null-space restriction)
-        n = self.hqp_hs_[0].variable_size_
-        return self._solve(0, np.zeros(n), np.eye(n))
+    def solvefirst(self):  # dwbc_hqp.cpp:222-289: level 0 over the full variable (no null-space restriction), posed on V A, V a, W B, W b
+        h = self.hqp_hs_[0]
+        n = h.variable_size_
+        keep = (h.A_, h.a_, h.B_, h.b_)
+        if h.ineq_const_size_ > 0:
+            h.A_, h.a_ = h.V_ @ h.A_, h.V_ @ h.a_
+        h.B_, h.b_ = h.W_ @ h.B_, h.W_ @ h.b_
+        st = self._solve(0, np.zeros(n), np.eye(n))
+        h.A_, h.a_, h.B_, h.b_ = keep  # (every later level reads the unweighted matrices, as the reference does)
+        return st
 
     def solveSequentialSingle(self, level):  # dwbc_hqp.cpp:291-395
         prev = self.hqp_hs_[level - 1]

@@ -55,11 +55,15 @@ def test_emulated_f32_reduced_kernel_within_envelope():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["ds", "ss_L", "mixed"])
+@pytest.mark.parametrize("cfg", ["ds", "ss_L", "mixed", "ds_yaw"])
 def test_gpu_f32_kernel_within_envelope(cfg):
+    """ds_yaw (random yaw, +-0.1 rad roll / pitch: tilted feet) is the distribution where single precision breaks -- the contact-null
+    part of the semi-definite task QPs is decided by the 1e-8 Tikhonov weight, which fp32 cannot resolve -- so it is asserted with its own
+    MEASURED envelope (profiles/r04_f32_bisect.txt, every commit from the end of round 2 to round 4 rebuilt and measured on one box:
+    status agreement 0.981, median 2.2e-2, p99 0.60, 96.1 % within 0.1 Nm, max 10.8 Nm; thresholds ~1.5 x that), not with the flat-feet one."""
     import libdwbc_amd as D
 
-    B = 1024
+    B = 1024 if cfg != "ds_yaw" else 2048
     tasks = cases.TASKS_2LEVEL
     kw = dict(seed=4244)
     if cfg == "ss_L":
@@ -67,6 +71,8 @@ def test_gpu_f32_kernel_within_envelope(cfg):
         tasks = cases.TASKS_3LEVEL_SWING_R
     elif cfg == "mixed":
         kw["contact_mode"] = "mixed"
+    elif cfg == "ds_yaw":
+        kw.update(seed=1234, yaw=True)
     q, fl, fs = cases.synth_batch(B, **kw)
     tau, wr, st, _ = _oracle(q, fl, fs, tasks, cases.TAU_LIM)
     out = {}
@@ -86,8 +92,15 @@ def test_gpu_f32_kernel_within_envelope(cfg):
         if dt == "f32":
             assert wbc.kernel_name().startswith("dwbc_f32::")
     t32, w32, s32 = out["f32"]
-    assert (s32 == st).mean() >= 0.99
     ok = (st == 1) & (s32 == 1)
+    if cfg == "ds_yaw":
+        err = np.abs(t32[ok].sum(axis=1) - tau[ok].sum(axis=1)).max(axis=1)
+        assert (s32 == st).mean() >= 0.97
+        assert np.median(err) < 3.5e-2 and np.quantile(err, 0.99) < 1.0 and err.max() < 20.0 and (err < TOL_F32).mean() >= 0.94
+        assert np.abs(t32[ok][:, 0] - tau[ok][:, 0]).max() < 0.1  # the gravity torque (no QP) stays inside the flat-feet envelope
+        assert np.abs(out["f64"][0][st == 1] - tau[st == 1]).max() < 1e-6
+        return
+    assert (s32 == st).mean() >= 0.99
     assert np.abs(t32[ok].sum(axis=1) - tau[ok].sum(axis=1)).max() < TOL_F32
     assert np.abs(w32[ok] - wr[ok][:, :12]).max() < 1.0  # contact wrench (N, Nm), |f_z| ~ 500 N
     # the fp64 batch next to it is untouched by the fp32 build

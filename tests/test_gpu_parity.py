@@ -481,6 +481,31 @@ def test_gpu_bench_two_ranks_gloo():
     assert line["value"] > 1e4 and line["roofline"]["kernel"].startswith("dwbc::dwbc_cycle_kernel_v2")
 
 
+@pytest.mark.gpu
+def test_gpu_bench_one_rank_rccl_gather():
+    """the RCCL branch of bench.rank_main (process group with backend nccl on the rank's device, packed rows on
+    the device, all_gather_into_tensor, barrier, max-over-ranks all_reduce) executed with world = 1 on this box's one GPU, so that the
+    driver's 1 -> 8 run is not the first execution of that code.  The rows that come back through RCCL equal the rank's own."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DWBC_BENCH_BACKEND")}
+    env["DWBC_BENCH_FORCE_COLLECTIVE"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["collective_backend"] == "rccl"
+    assert line["config"]["forced_one_rank_gather_matches_local"] is True
+    assert line["config"]["status_ok_fraction"] > 0.9 and line["value"] > 1e4
+
+
 def test_redundant_task_levels_do_not_abort_the_cascade():
     """a redundant lower level (TASK_CUSTOM level whose Jacobian repeats rows of level 0) through the HIP
     kernel and the restatement: both finish with status 1 and the same torques (see tests/test_kernel_emulation.py for why the

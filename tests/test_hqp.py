@@ -211,6 +211,93 @@ def test_emulated_lqp_matches_oracle_on_golden_and_synthetic_states():
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
+def test_oracle_row_weights_enter_solvefirst_only():
+    """HQP_Hierarch::updateInequalityCostWeight / updateEqualityCostWeight (reference src/dwbc_hqp.cpp:503-553): solvefirst poses level 0
+    on (V A, V a, W B, W b) (:245-254); no later solve reads the weights.  The restatement: weighted solvefirst == unweighted solvefirst
+    of the pre-scaled problem, and solveSequential is untouched by the weights."""
+    rng = np.random.default_rng(5)
+    nv = 14
+    lv = _random_hierarchy(rng)
+    m, e = lv[0]["m"], lv[0]["e"]
+    V, W = np.diag(0.5 + rng.random(m)) + 0.1 * rng.standard_normal((m, m)), np.diag(0.5 + rng.random(e))
+
+    def build(pre_scaled, weights):
+        hq = H.HQP()
+        hq.initialize(nv, 0, 0)
+        for i, d in enumerate(lv):
+            hq.addHierarchy(d["m"], d["e"])
+            h = hq.hqp_hs_[-1]
+            A, a, Bm, b = d["A"], d["a"], d["B"], d["b"]
+            if pre_scaled and i == 0:
+                A, a, Bm, b = V @ A, V @ a, W @ Bm, W @ b
+            h.updateConstraintMatrix(A if d["m"] else None, a if d["m"] else None, Bm, b)
+            if "H" in d:
+                h.updateCostMatrix(d["H"], np.zeros(nv))
+        if weights:
+            hq.hqp_hs_[0].updateConstraintWeight(V, W)
+        if weights == 2:
+            hq.hqp_hs_[2].updateEqualityCostWeight(np.full(lv[2]["e"], 7.0))  # a later level's weight: stored, never read
+        hq.prepare()
+        return hq
+
+    hw, hw2, hs_, hu = build(False, 1), build(False, 2), build(True, 0), build(False, 0)
+    assert hw.solvefirst() == 1 and hw2.solvefirst() == 1 and hs_.solvefirst() == 1 and hu.solvefirst() == 1
+    assert np.abs(hw.hqp_hs_[0].y_ans_ - hs_.hqp_hs_[0].y_ans_).max() < 1e-12
+    assert np.abs(hw.hqp_hs_[0].y_ans_ - hu.hqp_hs_[0].y_ans_).max() > 1e-4  # the weights do change level 0's answer
+    # solveSequential starts at level 1 from level 0's (weighted) answer and reads level 0's UNWEIGHTED rows (dwbc_hqp.cpp:291-403);
+    # a weight set on a later level changes nothing
+    assert hw.solveSequential() == 1 and hw2.solveSequential() == 1
+    for a_, b_ in zip(hw.hqp_hs_, hw2.hqp_hs_):
+        assert np.abs(a_.y_ans_ - b_.y_ans_).max() < 1e-14
+    assert np.abs(hw.hqp_hs_[0].A_ - lv[0]["A"]).max() == 0.0  # the level keeps its unweighted matrices
+
+
+@pytest.mark.gpu
+def test_gpu_hqp_row_weights_match_oracle():
+    """dwbc_hqp_update_constraint_weight: solvefirst with (V, W) on the device equals the restatement's; the solveSequential that
+    follows reads the unweighted matrices again (the device blocks are put back after the weighted launch)."""
+    import libdwbc_amd as D
+    from libdwbc_amd import hqp as Hq
+
+    rng = np.random.default_rng(21)
+    B, nv = 16, 14
+    probs = [_random_hierarchy(rng) for _ in range(B)]
+    sizes = [(d["m"], d["e"]) for d in probs[0]]
+    m0, e0 = sizes[0]
+    Vs = np.array([np.diag(0.5 + rng.random(m0)) + 0.1 * rng.standard_normal((m0, m0)) for _ in range(B)])
+    Ws = np.array([0.5 + rng.random(e0) for _ in range(B)])  # vectors: diagonals
+    hq = D.HQP(B, nv, 0, 0)
+    for m, e in sizes:
+        hq.addHierarchy(m, e)
+    for lv, (m, e) in enumerate(sizes):
+        hq.updateConstraintMatrix(lv, np.array([p[lv]["A"] for p in probs]) if m else None, np.array([p[lv]["a"] for p in probs]) if m else None,
+                                  np.array([p[lv]["B"] for p in probs]), np.array([p[lv]["b"] for p in probs]))
+        if "H" in probs[0][lv]:
+            hq.updateCostMatrix(lv, np.array([p[lv]["H"] for p in probs]))
+    hq.updateConstraintWeight(0, Vs, Ws)
+    hq.prepare()
+    hq.solvefirst()
+    y_first = hq.y_ans(0).copy()
+    hq.solveSequential()
+    for b in range(B):
+        ref = H.HQP()
+        ref.initialize(nv, 0, 0)
+        for d in probs[b]:
+            ref.addHierarchy(d["m"], d["e"])
+            h = ref.hqp_hs_[-1]
+            h.updateConstraintMatrix(d["A"] if d["m"] else None, d["a"] if d["m"] else None, d["B"], d["b"])
+            if "H" in d:
+                h.updateCostMatrix(d["H"], np.zeros(nv))
+        ref.hqp_hs_[0].updateConstraintWeight(Vs[b], np.diag(Ws[b]))
+        ref.prepare()
+        assert ref.solvefirst() == 1
+        assert np.abs(y_first[b] - ref.hqp_hs_[0].y_ans_).max() < TOL, b
+        assert ref.solveSequential() == 1
+        for lv, h in enumerate(ref.hqp_hs_):
+            assert hq.get(lv, Hq.STATUS)[b] == 1
+            assert np.abs(hq.y_ans(lv)[b] - h.y_ans_).max() < TOL, (b, lv)
+
+
 @pytest.mark.gpu
 def test_gpu_hqp_class_generic_hierarchy_matches_oracle():
     import libdwbc_amd as D

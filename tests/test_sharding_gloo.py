@@ -102,6 +102,27 @@ def test_bench_rank_function_two_gloo_ranks_matches_single_solve(tmp_path):
     assert line["value"] > 0 and abs(line["value"] - world * B * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
 
 
+def _worker_forced(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DWBC_BENCH_FORCE_COLLECTIVE"] = "1"
+    args = bench.parse_args(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "7", "--no-cpu-baseline"])
+    line, gathered = bench.rank_main(args, 0, 0, 1, "gloo", engine_factory=OracleEngine)
+    json.dump(dict(line=line, rows=int(gathered.shape[0])), open(os.path.join(outdir, "forced.json"), "w"))
+
+
+def test_forced_one_rank_collective_runs_the_gather_branch(tmp_path):
+    """DWBC_BENCH_FORCE_COLLECTIVE=1: a one-rank job still builds its process group and sends the final rows through
+    all_gather_into_tensor (the switch the GPU suite uses to execute the RCCL branch on a one-GPU box)"""
+    mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = json.load(open(tmp_path / "forced.json"))
+    assert got["rows"] == 7 and got["line"]["n_gpus"] == 1
+    assert got["line"]["config"]["forced_one_rank_gather_matches_local"] is True
+
+
 def test_gather_packed_handles_ragged_slices():
     """shard.gather_packed pads ragged per-rank slices; checked here on one process with a fake dist"""
     from libdwbc_amd import shard

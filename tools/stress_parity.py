@@ -16,7 +16,9 @@ NS = int(os.environ.get("STRESS_SEEDS", "5"))  # seeds per configuration (STRESS
 B = 4096
 cfgs = {"ds": (cases.TASKS_2LEVEL, {}), "ds_yaw": (cases.TASKS_2LEVEL, dict(yaw=True)), "mixed": (cases.TASKS_2LEVEL, dict(contact_mode="mixed")),
         "ss_L": (cases.TASKS_3LEVEL_SWING_R, dict(contact_mode="L", levels=3)), "ss_R": (cases.TASKS_3LEVEL_SWING_L, dict(contact_mode="R", levels=3))}
+ONLY = os.environ.get("STRESS_CFGS")  # comma-separated subset (development builds that carry the two-level kernels only: ds,ds_yaw,mixed)
 for name, (tasks, kw) in cfgs.items():
+    if ONLY and name not in ONLY.split(","): continue
     w = make(B, tasks); S = orc.make_setup(cases.CONTACTS_2, tasks, cases.TAU_LIM)
     worst = 0.0; mism = 0; tot = 0; okc = 0
     for seed in range(NS):
