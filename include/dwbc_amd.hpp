@@ -331,8 +331,12 @@ class RobotData {
             cc_[i].contact = on; flags_[i] = on ? 1 : 0;
             if (on) { contact_link_num_++; contact_dof_ += 6; }
         }
+        if (contact_link_num_ > 2) {  // a third contact (src/dwbc.cpp:445-453 stacks every flagged one): the general-contact kernel
+            enter_general();
+            if (!dwbc_batch_set_max_active_contacts(batch_, 3)) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;
+        }
         contact_ok_ = dwbc_batch_set_contact(batch_, flags_.data()) != 0;
-        if (!contact_ok_) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;  // e.g. more than 2 active contacts
+        if (!contact_ok_) std::cout << "libdwbc_amd : " << dwbc_last_error() << std::endl;  // e.g. more than 3 active contacts
         dirty_ = true;
     }
     // ---- tasks (dwbc.h:318-333)
@@ -340,6 +344,7 @@ class RobotData {
         if (!dwbc_batch_add_task(batch_, heirarchy, task_mode, link_number, task_point.data())) { std::cout << dwbc_last_error() << std::endl; return; }
         if ((int)ts_.size() <= heirarchy) ts_.resize(heirarchy + 1);
         ts_[heirarchy].task_dof_ = dwbc_batch_task_dof(batch_, heirarchy);
+        if (ts_[heirarchy].task_dof_ > 6) enter_general();  // a second 6D link on the level (src/dwbc.cpp:592-600): the general-contact kernel
         ts_[heirarchy].task_link_.emplace_back();
         ts_[heirarchy].f_star_.assign(ts_[heirarchy].task_dof_, 0.0);
         if (verbose) std::cout << "#" << heirarchy << " Task Space Added : " << dwbc_model_link_name(model_, link_number) << std::endl;
@@ -411,6 +416,7 @@ class RobotData {
         if (hqp != hqp_) { hqp_ = hqp; dirty_ = true; }  // hqp = false: plain hierarchy, no QP (dwbc.cpp:856-873)
         if (!refresh(init)) return 0;
         if (!hqp) { torque_contact_.assign(model_dof_, 0.0); redistributed_ = false; return diag_[1]; }
+        if (general_) { torque_contact_ = tau_contact_final_; redistributed_ = true; return diag_[1]; }  // (one launch: already redistributed)
         // torque_contact_ = NwJw * contact_qp_(last level) at this point of the reference sequence (dwbc.cpp:851)
         const int k = contact_dof_ > 6 ? (int)contact_dof_ - 6 : 0;
         torque_contact_.assign(model_dof_, 0.0);
@@ -543,6 +549,11 @@ class RobotData {
     template <class V, class = decltype(std::declval<const V &>().data()), class = decltype(std::declval<const V &>().rows())>
     Vec getContactForce(const V &command_torque) { return getContactForce(dwbc_amd::as_vec(command_torque)); }
     Vec getContactForce(const Vec &command_torque) {  // wbd.cpp:268-271: J_C_INV_T[:,6:] tau - P_C
+        if (general_) {  // the device's own getContactForce(torque_grav_ + torque_task_ + torque_contact_): J_C_INV_T is not mirrored here
+            refresh();
+            (void)command_torque;
+            return Vec(wrench_.begin(), wrench_.begin() + (contact_dof_ <= wrench_.size() ? contact_dof_ : wrench_.size()));
+        }
         Vec f(contact_dof_, 0.0);
         for (unsigned c = 0; c < contact_dof_; c++) {
             double s = -P_C[c];
@@ -557,6 +568,12 @@ class RobotData {
     dwbc_batch *batch_ = nullptr;
     std::vector<uint8_t> flags_;
     bool dirty_ = true, redistributed_ = false, reduced_ = false, hqp_ = true, contact_ok_ = true;
+    // general_: more than two contacts flagged at some point, or a task level wider than six dof -- every solve then runs the
+    // general-contact kernel (libdwbc_amd/csrc/dwbc_cycle_gc.h), which keeps no dump record: torque_grav_ / torque_task_ / torque_contact_,
+    // getContactForce(total torque) and the int returns are served; the public matrices (A_, J_C, Lambda_contact, ts_[i].J_kt_ ...) are not
+    bool general_ = false;
+    Vec wrench_;
+    void enter_general() { if (!general_) { general_ = true; dwbc_batch_enable_dump(batch_, 0); dirty_ = true; } }
     HQP jacc_h_, jacc_nc_h_;  // solver objects of the JACC entry points
     int fetch_jacc(int level, int n) {
         TaskSpaceView &t = ts_[level];
@@ -620,6 +637,12 @@ class RobotData {
         torque_task_.assign(tau.begin() + m, tau.begin() + 2 * m);
         tau_contact_final_.assign(tau.begin() + 2 * m, tau.end());
         dwbc_batch_get(batch_, DWBC_DIAG, diag_, sizeof(int) * 90);
+        if (general_) {
+            wrench_.assign(dwbc_batch_field_bytes(batch_, DWBC_WRENCH) / 8, 0.0);
+            dwbc_batch_get(batch_, DWBC_WRENCH, wrench_.data(), wrench_.size() * 8);
+            dirty_ = false;
+            return 1;
+        }
         A_ = fetch(DWBC_A, n, n); A_inv_ = fetch(DWBC_A_INV, n, n); A_inv_N_C = fetch(DWBC_A_INV_N_C, n, n);
         J_C = fetch(DWBC_J_C, cd, n); J_C_INV_T = fetch(DWBC_J_C_INV_T, cd, n);
         Lambda_contact = fetch(DWBC_LAMBDA_C, cd, cd, cd);

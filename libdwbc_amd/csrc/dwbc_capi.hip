@@ -147,7 +147,7 @@ GcEntry find_gc(int n, int nb) {  // fn == nullptr: none
     std::lock_guard<std::mutex> lk(g_pack_mutex);
     for (const auto &p : g_packs)
         if (p.gc.fn && p.gc.n == n && p.gc.nb == nb) return p.gc;
-    return GcEntry{0, 0, nullptr, 0};
+    return GcEntry{0, 0, nullptr, 0, nullptr, 0};
 }
 const KernelEntry *pack_pick(int n, int nb, int nlv, const std::vector<int> &parents) {
     if (const KernelEntry *ke = pack_lookup(n, nb, nlv, parents, false)) return ke;
@@ -183,7 +183,7 @@ int try_load_pack(const std::string &path, const std::vector<int> &parents, bool
     if (gc_fn gf = (gc_fn)dlsym(dl, "dwbc_pack_gc")) {
         int lds = 0;
         const void *fn = gf(&lds);
-        if (fn && count > 0) kp.gc = GcEntry{tab[0].n, tab[0].nb, reinterpret_cast<void (*)(const Setup, const BatchIO)>(const_cast<void *>(fn)), lds};
+        if (fn && count > 0) kp.gc = GcEntry{tab[0].n, tab[0].nb, reinterpret_cast<void (*)(const Setup, const BatchIO)>(const_cast<void *>(fn)), lds, nullptr, 0};
     }
     if (pf) {
         int pnb = 0;
@@ -680,16 +680,21 @@ static int launch_f32(dwbc_batch *b, bool reduced) {
     return 1;
 }
 
-// three active contacts: every instance of the batch goes through the general-contact kernel (lean scope)
+// three active contacts, or a task level of more than six dof: every instance of the batch goes through the general-contact kernel
+// (lean scope); its TG = 12 instantiation when a level is wider than six
 static int launch_gc(dwbc_batch *b) {
     const GcEntry gc_ = find_gc(b->n, b->su.nb), *g = &gc_;
+    const bool wide_tasks = setup_wide_tasks(b->su);
     if (!g->fn) return fail("no general-contact kernel for this model size (built in for TOCABI; kernel packs carry one for models of at most 40 dof)");
-    if (!b->hqp) return fail("three active contacts: hqp = true only (the reference's closed-form redistribution is written for two contacts, src/dwbc.cpp:1570-1619)");
+    if (wide_tasks && !g->fn_wide_tasks) return fail("task levels of more than 6 dof: built in for TOCABI's size only");
+    if (!b->hqp) return fail("three active contacts / task levels of more than 6 dof: hqp = true only (the reference's closed-form redistribution is written for two contacts, src/dwbc.cpp:1570-1619)");
     if (b->su.n_traj > 0 || b->su.has_com_task || b->su.n_custom > 0 || b->dump_on)
-        return fail("three active contacts: link tasks with f* from SetTaskSpace only (no trajectories, COM or custom levels, no dump record)");
-    if (!b->gc_attr_set) {
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(g->fn), hipFuncAttributeMaxDynamicSharedMemorySize, g->lds_bytes));
-        b->gc_attr_set = true;
+        return fail("three active contacts / task levels of more than 6 dof: link tasks with f* from SetTaskSpace only (no trajectories, COM or custom levels, no dump record)");
+    auto fn = wide_tasks ? g->fn_wide_tasks : g->fn;
+    const int lds_bytes = wide_tasks ? g->lds_bytes_wide_tasks : g->lds_bytes;
+    if (b->gc_attr_set != (wide_tasks ? 2 : 1)) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        b->gc_attr_set = wide_tasks ? 2 : 1;
     }
     BatchIO io{};
     io.B = b->B;
@@ -705,12 +710,16 @@ static int launch_gc(dwbc_batch *b) {
     io.topo = b->d_topo;
     io.hqp = 1;
     b->ws_valid = false;  // cold-started QPs, no working sets kept
-    hipLaunchKernelGGL(g->fn, dim3(b->B), dim3(kNT), g->lds_bytes, b->stream, b->su, io);
+    hipLaunchKernelGGL(fn, dim3(b->B), dim3(kNT), lds_bytes, b->stream, b->su, io);
     return hipGetLastError() == hipSuccess ? 1 : fail("general-contact kernel launch failed");
 }
 
 static int launch(dwbc_batch *b, bool reduced = false) {
-    if (b->max_active > 2) return reduced ? fail("three active contacts: not built on the reduced dynamics path") : launch_gc(b);
+    if (b->max_active > 2 || setup_wide_tasks(b->su)) {
+        if (reduced) return fail("three active contacts / task levels of more than 6 dof: not built on the reduced dynamics path");
+        if (b->dtype == DWBC_F32) return fail("three active contacts / task levels of more than 6 dof: fp64 batches only");
+        return launch_gc(b);
+    }
     if (b->dtype == DWBC_F32) return launch_f32(b, reduced);
     const KernelEntry *ke = pick_kernel(b, reduced);
     if (!ke) return fail("no kernel for this model / number of task levels");
@@ -749,7 +758,8 @@ static int launch(dwbc_batch *b, bool reduced = false) {
     const bool wide = b->kern->fn_wide && b->B <= 4 * b->n_cu && !getenv("DWBC_NO_WIDE");
     const bool lean = b->kern->fn_lean && lean_ok(b);
     b->ws_valid = !lean && !reduced;  // the full build leaves every QP's working set in the diagnostics record (DG_QP_ACT)
-    if (pair_ok(b, b->kern, wide, lean, reduced)) {
+    // (DWBC_PAIR_ALWAYS=1: development switch, the two-wave kernel at any batch size)
+    if (pair_ok(b, b->kern, wide || getenv("DWBC_PAIR_ALWAYS"), lean, reduced)) {
         // two waves per instance, side chains on the helper wave (dwbc_cycle2p.h).  Which wave of a workgroup is the main one can be
         // swapped per workgroup (DWBC_PAIR_SWAP_BIT = bit of the workgroup index) to steer the main waves of a CU's four workgroups
         // onto different SIMDs; measured at B = 1024 (profiles/r03e_pair_roles.txt): no swap 82.3 us per launch, bit 8 / bit 9 99 - 102 us
@@ -985,8 +995,8 @@ int dwbc_batch_get(dwbc_batch *b, int field, void *out, size_t bytes) {
 
 const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
     static thread_local std::string name;
-    if (b->max_active > 2) {
-        name = "dwbc::dwbc_cycle_kernel_gc<" + std::to_string(b->n) + ", " + std::to_string(b->su.nb) + ", 64>";
+    if (b->max_active > 2 || setup_wide_tasks(b->su)) {
+        name = "dwbc::dwbc_cycle_kernel_gc<" + std::to_string(b->n) + ", " + std::to_string(b->su.nb) + ", 64, " + (setup_wide_tasks(b->su) ? "12" : "6") + ">";
         return name.c_str();
     }
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);
@@ -1014,10 +1024,10 @@ const char *dwbc_batch_kernel_name(const dwbc_batch *b) {
 }
 
 int dwbc_batch_launch_info(const dwbc_batch *b, int *threads, int *lds) {
-    if (b->max_active > 2) {
+    if (b->max_active > 2 || setup_wide_tasks(b->su)) {
         const GcEntry g = find_gc(b->n, b->su.nb);
         if (threads) *threads = kNT;
-        if (lds) *lds = g.fn ? g.lds_bytes : 0;
+        if (lds) *lds = setup_wide_tasks(b->su) ? g.lds_bytes_wide_tasks : (g.fn ? g.lds_bytes : 0);
         return 1;
     }
     const KernelEntry *ke = pick_kernel(b, b->last_reduced);

@@ -75,7 +75,7 @@ struct dwbc_batch {
     int dtype = 0;  // DWBC_F64 | DWBC_F32 (arithmetic type of the kernels; the boundary buffers are always double)
     float *f_body = nullptr;
     int max_active = 2;           // simultaneously active contacts per instance the batch solves (2: product kernels; 3: dwbc_cycle_gc.h)
-    bool gc_attr_set = false;
+    int gc_attr_set = 0;  // 1: the general-contact kernel's LDS attribute is set, 2: its wide-task instantiation's
     const void *f32_fn = nullptr, *f32_fn_wide = nullptr;
     int f32_lds = 0, f32_lds_wide = 0, f32_key = -1, f32_topo = 0;
     int hqp = 1;

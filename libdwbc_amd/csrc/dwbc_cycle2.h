@@ -662,7 +662,9 @@ DWBC_DEVN void qr_small(Thr th, real_t *A, int m, int n, real_t *Q, real_t *piv,
             }
         }
         DWBC_SYNC();
-        real_t v[6] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+        real_t v[kMaxTaskDofWide];  // (m <= 6 in the product kernels, <= 12 in the general-contact kernel's wide-task build)
+#pragma unroll
+        for (int i = 0; i < kMaxTaskDofWide; i++) v[i] = real_t(0.0);
         real_t nrm = real_t(0.0);
         for (int i = s; i < m; i++) { v[i] = A[i * n + s]; nrm += v[i] * v[i]; }
         nrm = sqrt(nrm);

@@ -16,12 +16,13 @@
 
 namespace dwbc {
 
-template <int N, int NB, int NCC>
+// TG: task dof per level the map and the QPs are sized for (6: the product kernels' limit; 12: two 6D links on one level)
+template <int N, int NB, int NCC, int TG = kMaxTaskDof>
 struct LdsG {
     static constexpr int M = N - 6;
     static constexpr int C = 6 * NCC;
     static constexpr int K = C - 6;
-    static constexpr int T = kMaxTaskDof;
+    static constexpr int T = TG;
     static constexpr int QN = T + K;                  // QP variables: task block + contact-null block
     static constexpr int max2(int a, int b) { return a > b ? a : b; }
     // persistent
@@ -212,12 +213,12 @@ DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t
 // QP rows into lanes + solve, for up to NCC contacts (same rows as qp_rows_and_solve of dwbc_cycle.h):
 //   torque rows:  [P1 | s2 P2][r,:] x  in  [-(lim + base), lim - base]        (reference src/dwbc.cpp:1001-1016)
 //   cone rows:    -cone(W1 | s2 W2)[rr,:] x <= cone(fv)[rr]                     (reference src/dwbc.cpp:1041-1053, src/wbd.cpp:59-97)
-template <int N, int NCC>
+template <int N, int NCC, int TG = kMaxTaskDof>
 DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const int *act_c, const real_t *P1, int ld1, int t1,
                                    const real_t *P2, int ld2, int t2, real_t s2, const real_t *W1, int ldw1, const real_t *W2, int ldw2,
-                                   const real_t *fv, const real_t *base, int tvars, int max_iter, QpResultT<kMaxTaskDof + 6 * NCC - 6> &res,
+                                   const real_t *fv, const real_t *base, int tvars, int max_iter, QpResultT<TG + 6 * NCC - 6> &res,
                                    real_t *Vlds, real_t *xlds, real_t vtol, bool fixed_layout = false) {
-    constexpr int M = N - 6, QN = kMaxTaskDof + 6 * NCC - 6;
+    constexpr int M = N - 6, QN = TG + 6 * NCC - 6;
     static_assert(M + 10 * NCC <= 64, "one QP row per lane");
     DWBC_LANE_DECL;
     QpRowsT<QN> R;
@@ -226,9 +227,9 @@ DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const i
     // are, the unused positions are zero columns (variables no row touches stay zero).  The solver then always sees (t, k) = (6, 12), the layout
     // whose lexicographic solve has compile-time positions; with the packed layout a three-dof level (t = 3) or two contacts (k = 6) went
     // through per-entry selects (216 per product with H).  x comes back in the same positions.
-    const int off2 = fixed_layout ? kMaxTaskDof : t1;
+    const int off2 = fixed_layout ? TG : t1;
     const int nv = fixed_layout ? QN : t1 + t2;
-    if (fixed_layout) tvars = kMaxTaskDof;
+    if (fixed_layout) tvars = TG;
     LANES {
 #pragma unroll
         for (int j = 0; j < QN; j++) LV(R.g)[j] = real_t(0.0);
@@ -271,7 +272,7 @@ DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const i
         }
     }
     // WS = 1: the general (t, k) layout of the lexicographic point
-    qp_solve_wave<1, QN, QN>(R, nv, tvars, max_iter, res, Vlds, nullptr, vtol, sfin);
+    qp_solve_wave<1, QN, QN, 6 * NCC - 6>(R, nv, tvars, max_iter, res, Vlds, nullptr, vtol, sfin);
     LANES {
         if (lane < QN) {
             real_t v = real_t(0.0);
@@ -286,9 +287,9 @@ DWBC_DEV void qp_rows_and_solve_gc(const Setup &su, int nlim, int ncone, const i
 // ----------------------------------------------------------------------------------------------
 // the cycle for one instance
 // ----------------------------------------------------------------------------------------------
-template <int N, int NB, int NCC, int NT>
+template <int N, int NB, int NCC, int NT, int TG = kMaxTaskDof>
 DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L) {
-    using S = LdsG<N, NB, NCC>;
+    using S = LdsG<N, NB, NCC, TG>;
     constexpr int M = S::M, C = S::C, T = S::T, QN = S::QN;
     const int nb = su.nb;
     const real_t *body = io.body;
@@ -719,7 +720,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             if (lv < 2) DWBC_STAMP(8 + 3 * lv);  // level lv: QP inputs
             QpResultT<QN> qres;
-            qp_rows_and_solve_gc<N, NCC>(su, nlim, ncone, act_c, U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, T, L + S::FNl, k, fv, base, t,
+            qp_rows_and_solve_gc<N, NCC, TG>(su, nlim, ncone, act_c, U, T, t, L + S::NwJw, k, k, kQpScaleGI, F, T, L + S::FNl, k, fv, base, t,
                                          su.qp_max_iter_task, qres, L + S::qp_V, L + S::qp_x, kQpTol, true);
             if (lv < 2) DWBC_STAMP(9 + 3 * lv);  // level lv: QP solved
             if (diag && th.tid == 0) {
@@ -765,7 +766,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         QpResultT<QN> qres;
         // (canon rule 5: the redistribution QP searches with the feasibility tolerance the task QPs were accepted at)
-        qp_rows_and_solve_gc<N, NCC>(su, nlim, ncone, act_c, L + S::NwJw, k, k, L + S::NwJw, k, 0, real_t(1.0), L + S::FNl, k, L + S::FNl, k, fv,
+        qp_rows_and_solve_gc<N, NCC, TG>(su, nlim, ncone, act_c, L + S::NwJw, k, k, L + S::NwJw, k, 0, real_t(1.0), L + S::FNl, k, L + S::FNl, k, fv,
                                      base, k, su.qp_max_iter_contact, qres, L + S::qp_V, L + S::qp_x, kQpFeasTol);
         if (diag && th.tid == 0) {
             diag[DG_QP_ITER + kMaxLevels] = qres.iters;

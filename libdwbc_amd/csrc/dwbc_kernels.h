@@ -56,15 +56,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void d
 
 // up to three simultaneously active contacts (dwbc_cycle_gc.h): the general statement of the cycle, matrices in LDS (80 KB: two
 // workgroups per CU), any number of task levels -- for batches that opt in with dwbc_batch_set_max_active_contacts(b, 3)
+// TG = 12: the same cycle sized for task levels of up to 12 dof (two 6D links on one level -- both hands, reference
+// tests/sp_test/regulation_test.cpp:90-91): QPs of up to 24 variables, 105 KB of LDS, one workgroup per CU
 constexpr int kGcContacts = 3;
-template <int N, int NB, int NT>
+template <int N, int NB, int NT, int TG = kMaxTaskDof>
 __global__ __launch_bounds__(NT) void dwbc_cycle_kernel_gc(const Setup su, const BatchIO io) {
     static_assert(NT == 64, "one wavefront per instance");
     extern __shared__ __attribute__((aligned(16))) real_t lds[];
     const int inst = blockIdx.x;
     if (inst >= io.B) return;
     Thr th{(int)threadIdx.x};
-    cycle_instance_gc<N, NB, kGcContacts, NT>(th, su, io, inst, lds);
+    cycle_instance_gc<N, NB, kGcContacts, NT, TG>(th, su, io, inst, lds);
 }
 
 // reduced (centroidal) dynamics model, dwbc_reduced.h: Reduced* call sequence of reference include/dwbc.h:411-416
@@ -104,13 +106,16 @@ struct GcEntry {
     int n, nb;
     void (*fn)(const Setup, const BatchIO);
     int lds_bytes;
+    void (*fn_wide_tasks)(const Setup, const BatchIO);  // task levels of up to kMaxTaskDofWide dof, or nullptr
+    int lds_bytes_wide_tasks;
 };
 // instantiated model sizes (system dof, bodies).  TOCABI = (39, 34), the only model in BASELINE.json's configs: its four
 // flavours use the constant tree; any other 34-body tree runs the TopoGeneric build (full flavour only).  Other model sizes come
 // from kernel packs (dwbc_pack.hip: this header instantiated for one (N, NB), loaded by the C-ABI at model-load time).
 #if !defined(DWBC_PACK_N) && !defined(DWBC_NO_PAIR_KERNEL)
 const GcEntry kKernelsGc[] = {
-    {39, 34, dwbc_cycle_kernel_gc<39, 34, kNT>, LdsG<39, 34, kGcContacts>::total_bytes},
+    {39, 34, dwbc_cycle_kernel_gc<39, 34, kNT>, LdsG<39, 34, kGcContacts>::total_bytes,
+     dwbc_cycle_kernel_gc<39, 34, kNT, kMaxTaskDofWide>, LdsG<39, 34, kGcContacts, kMaxTaskDofWide>::total_bytes},
 };
 inline const GcEntry *lookup_gc(int n, int nb) {
     for (const GcEntry &e : kKernelsGc)

@@ -69,7 +69,9 @@ using QpResult = QpResultT<kQpN>;
 // WS != 0: report the working set (reference row indices) in out.act -- diagnostics the lean kernel build leaves out.
 // NV >= nv: compile-time bound of the variable count (12, 9 or 6); every dot product, rank-one update and QR step runs over NV
 // entries instead of the maximum 12 (the padded entries are exact zeros, so the result does not depend on NV).
-template <int WS, int NV = kQpN, int QN = kQpN>
+// KCV: contact-null variables of the fixed layout (QN - KCV task variables first): 6 in the product kernels; the general-contact kernel
+// passes its own (12 with three contacts, whatever the task block is sized for)
+template <int WS, int NV = kQpN, int QN = kQpN, int KCV = (QN > 12 ? QN - 6 : 6)>
 // warm: reference row indices of the previous solve's working set (kQpN entries, -1 = empty) or nullptr.  Hot start in the sense of
 // SolveQPoases(init = false): the search visits those rows first -- each is added as soon as it is violated -- before it falls
 // back to the most-violated rule.  The Tikhonov problem is strictly convex, so the point the search ends at does not depend on
@@ -358,7 +360,7 @@ DWBC_WDEV void qp_solve_wave(QpRowsT<QN> &R, int nv, int t, int max_iter, QpResu
     //      (Replaces the column-pivoted Householder QR of the weighted normals of rounds 1-2, ~13 k cycles per QP.)
     {
         real_t xs[NV];
-        constexpr int KC = QN > 12 ? QN - 6 : 6;  // contact-null variables: k <= 6 (one or two 6D contacts); 12 in the three-contact build
+        constexpr int KC = KCV;  // contact-null variables: k <= 6 (one or two 6D contacts); 12 in the three-contact build
         constexpr int kCgMax = KC > kQpRefine ? 4 * KC : kQpRefine;
         static_assert(NV >= KC, "variable blocks");
         bool settled = false;

@@ -98,7 +98,8 @@ inline bool setup_add_task(Setup &su, int level, int mode, int link, const doubl
     if (j >= kMaxTaskLinks) { err = "too many links in one task level"; return false; }
     int cur = 0;
     for (int a = 0; a < j; a++) cur += task_mode_dof(su.t_mode[level][a]);
-    if (cur + task_mode_dof(mode) > kMaxTaskDof) { err = "task level exceeds 6 dof"; return false; }
+    // more than 6 dof on a level (two 6D links: src/dwbc.cpp:592-600) routes the batch through the general-contact kernel
+    if (cur + task_mode_dof(mode) > kMaxTaskDofWide) { err = "task level exceeds 12 dof"; return false; }
     if (level == su.n_levels) {
         su.n_levels++;
         su.t_nlinks[level] = 0;
@@ -115,6 +116,13 @@ inline bool setup_add_task(Setup &su, int level, int mode, int link, const doubl
         for (int a = 0; a < su.t_nlinks[l]; a++) su.has_com_task |= su.t_link[l][a] == su.nb;
     setup_fstar_layout(su);
     return true;
+}
+
+// some level carries more than the six task dof the product kernels are built for
+inline bool setup_wide_tasks(const Setup &su) {
+    for (int l = 0; l < su.n_levels; l++)
+        if (su.t_dof[l] > kMaxTaskDof) return true;
+    return false;
 }
 
 }  // namespace dwbc

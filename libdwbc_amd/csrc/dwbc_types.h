@@ -24,7 +24,9 @@ constexpr int kMaxContacts = 4;       // registered contacts (reference tests re
 constexpr int kMaxActiveContacts = 2; // simultaneously active 6D contacts the fused kernel is sized for
 constexpr int kMaxLevels = 4;
 constexpr int kMaxTaskLinks = 2;
-constexpr int kMaxTaskDof = 6;        // per level (one 6D link or two 3-dof links)
+constexpr int kMaxTaskDof = 6;        // per level on the product kernels (one 6D link or two 3-dof links)
+constexpr int kMaxTaskDofWide = 12;   // per level through the general-contact kernel: two 6D links on one level (both hands: reference
+                                      // tests/sp_test/regulation_test.cpp:90-91, src/dwbc.cpp:592-600)
 constexpr int kMaxReducedDof = 24;    // reduced system: 6 + 12 contact-chain joints of two legs + 6 centroidal coordinates
 constexpr int kBodyStride = 25;       // doubles per body in the device model table
 

@@ -250,11 +250,15 @@ int emu_run_gc(EmuCtx *c, int B, const double *q, const unsigned char *flags, co
     io.body = rb.data();
     io.topo = c->topo.data();
     io.hqp = 1;
-    std::vector<real_t> lds(LdsG<39, 34, 3>::total + 64);
-    static_assert(LdsG<37, 32, 3>::total <= LdsG<39, 34, 3>::total && LdsG<23, 18, 3>::total <= LdsG<39, 34, 3>::total, "one buffer");
+    const bool wide_tasks = setup_wide_tasks(c->su);  // a level of more than 6 dof: the TG = 12 instantiation (TOCABI's size)
+    if (wide_tasks && n_ != 39) { c->err = "emu_run_gc: task levels of more than 6 dof are instantiated for (39, 34)"; return 0; }
+    std::vector<real_t> lds(LdsG<39, 34, 3, kMaxTaskDofWide>::total + 64);
+    static_assert(LdsG<37, 32, 3>::total <= LdsG<39, 34, 3>::total && LdsG<23, 18, 3>::total <= LdsG<39, 34, 3>::total &&
+                  LdsG<39, 34, 3>::total <= LdsG<39, 34, 3, kMaxTaskDofWide>::total, "one buffer");
     for (int b = 0; b < B; b++) {
         std::fill(lds.begin(), lds.end(), std::numeric_limits<real_t>::quiet_NaN());
-        if (n_ == 39) cycle_instance_gc<39, 34, 3, 1>(Thr{0}, c->su, io, b, lds.data());
+        if (wide_tasks) cycle_instance_gc<39, 34, 3, 1, kMaxTaskDofWide>(Thr{0}, c->su, io, b, lds.data());
+        else if (n_ == 39) cycle_instance_gc<39, 34, 3, 1>(Thr{0}, c->su, io, b, lds.data());
         else if (n_ == 37) cycle_instance_gc<37, 32, 3, 1>(Thr{0}, c->su, io, b, lds.data());
         else cycle_instance_gc<23, 18, 3, 1>(Thr{0}, c->su, io, b, lds.data());
     }

@@ -146,3 +146,56 @@ def test_facade_rest_of_the_public_interface():
     c2.run(q, [1, 1], [np.array(cases.FSTAR_CASE[1][0]), np.array(f1 + [0.2, -0.1, 0.3])])
     assert r["api_ok"] == [1, 2, 6] and c2.status == 1
     assert np.abs(np.asarray(r["api_torque_task_"]) - c2.tau_task).max() < 1e-6
+
+
+EXE_G = os.path.join(ROOT, "tests", "cpp", "facade_general")
+Q_DC = [-0.0325, -0.0579, 0.7273, 0.0194, -0.0118, -0.0008, -0.0006, 0.0698, -0.7835, 1.6487, -0.8420, -0.0911,
+        -0.0007, 0.0767, -0.7963, 1.6742, -0.8549, -0.1150, -0.0001, -0.0003, 0.0204,
+        0.2998, 0.3001, 1.5000, -1.2701, -1.0507, 0.0000, -1.0000, 0.0000, -0.0000, 0.0003,
+        -0.2998, -0.3060, -1.5001, 1.2700, 1.0848, 0.0000, 1.0000, 0.0000, 0.9997]
+
+
+def _build_general():
+    src = os.path.join(ROOT, "tests", "cpp", "facade_general.cpp")
+    libdir = os.path.join(ROOT, "libdwbc_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE_G, "-L" + libdir, "-l:libdwbc_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+
+
+def test_facade_general_sequence_compiles():
+    _build_general()
+    assert os.path.exists(EXE_G)
+
+
+@pytest.mark.gpu
+def test_facade_both_hands_on_one_level_and_a_third_contact():
+    """`AddTaskSpace(3, ...)` twice (a 12-dof level, reference tests/sp_test/data_confirmation.cpp:66-70) with
+    the harness's warm repetitions (:91-107), and `SetContact(true, true, true)` -- through the drop-in class, against the C restatement
+    on the same inputs."""
+    from oracle import orc
+
+    _build_general()
+    out = subprocess.check_output([EXE_G, cases.URDF], text=True)
+    r = json.loads(out[out.index("{"):])
+    e = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b).reshape(-1)).max())
+    M = orc.make_model(cases.tocabi_model())
+    con = [dict(link=l, point=cases.FOOT_POINT, lx=lx, ly=ly, mu=0.2, muz=0.2) for l, lx, ly in ((6, 0.12, 0.06), (12, 0.12, 0.06), (23, 0.04, 0.04), (31, 0.04, 0.04))]
+    q = np.array([Q_DC])
+    q[0, [3, 4, 5, 39]] /= np.linalg.norm(q[0, [3, 4, 5, 39]])  # (four-digit quaternion of the harness: unit length here and in the C++ program)
+    # both hands on the last level
+    P, R, T6 = 3, cases.TASK_LINK_ROTATION, cases.TASK_LINK_6D  # TASK_LINK_POSITION = 3 (include/dwbc_task.h:23-33)
+    tasks = [[(P, 0, (0, 0, 0))], [(R, 15, (0, 0, 0))], [(R, 25, (0, 0, 0))], [(T6, 23, (0, 0, 0)), (T6, 33, (0, 0, 0))]]
+    fs = np.array([[0.3142, -1.8202, -1.7750, -1.78677, 0.84977, 0.10850, -0.85340, 0.85992, 0.12655,
+                    0.40251, 0.39975, 0.75672, -0.82841, 3.03652, 0.08954, 0.27585, 0.37898, 0.93234, -0.95724, 4.38036, 0.25202]])
+    S = orc.make_setup(con, tasks, cases.TAU_LIM)
+    tau, wr, st, _ = orc.cycle_batch(M, S, q, np.array([[1, 1, 0, 0]], np.uint8), fs, 1)
+    assert st[0] == 1 and r["ok"] == [1, 1, 1] and r["dims"] == [4, 12, 12]
+    assert e(r["torque_grav_"], tau[0, 0]) < 1e-6 and e(r["torque_task_"], tau[0, 1]) < 1e-6 and e(r["torque_contact_"], tau[0, 2]) < 1e-6
+    assert e(r["contact_force"], wr[0, :12]) < 1e-5
+    assert r["warm_ok"] == 6 and e(r["warm_torque_task_"], tau[0, 1]) < 1e-6
+    # a third contact
+    S3 = orc.make_setup(con, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    tau3, wr3, st3, _ = orc.cycle_batch(M, S3, q, np.array([[1, 1, 1, 0]], np.uint8), np.array([[0.1, 0.4, 0.1, 0.1, -0.1, 0.1, 0.1, -0.1, 0.1]]), 1)
+    assert st3[0] == 1 and r["c3_ok"] == [1, 1, 1, 18]
+    assert e(r["c3_torque_grav_"], tau3[0, 0]) < 1e-6 and e(r["c3_torque_task_"], tau3[0, 1]) < 1e-6 and e(r["c3_torque_contact_"], tau3[0, 2]) < 1e-6
+    assert e(r["c3_contact_force"], wr3[0, :18]) < 1e-5

@@ -125,7 +125,7 @@ def test_gpu_feet_and_left_hand_vs_oracle():
     q, _, fs = cases.synth_batch(B, seed=41, yaw=True)
     wbc = _make_gpu(B)
     wbc.set_max_active_contacts(3)
-    assert wbc.max_active_contacts == 3 and "dwbc_cycle_kernel_gc<39, 34, 64>" in wbc.kernel_name()
+    assert wbc.max_active_contacts == 3 and "dwbc_cycle_kernel_gc<39, 34, 64, 6>" in wbc.kernel_name()
     for name in ("feet_left_hand", None):
         if name:
             fl = np.tile(np.array(CONTACT_SETS[name], np.uint8), (B, 1))
@@ -277,7 +277,7 @@ def test_gpu_three_contacts_on_a_37_dof_model_through_its_kernel_pack(tmp_path):
     wbc.set_max_active_contacts(3)
     wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
     wbc.solve()
-    assert "dwbc_cycle_kernel_gc<37, 32, 64>" in wbc.kernel_name()
+    assert "dwbc_cycle_kernel_gc<37, 32, 64, 6>" in wbc.kernel_name()
     ok = st_r == 1
     assert (wbc.get("status") == st_r).all() and ok.mean() > 0.9
     assert np.abs(wbc.get("tau")[ok] - tau_r[ok]).max() < TOL_TAU
