@@ -499,6 +499,96 @@ __device__ __forceinline__ void lds_pivot(double (&s)[NN], double &dg2, int &ok,
 }
 #endif
 
+// The tree-sparse A^-1 sweep (sweep_inverse_tree) with the pivot column fed through LDS like the W^+ sweep: per pivot one ds_write_b64
+// publishes it (the swept matrix stays symmetric), and only the 16-byte pieces that hold a relative of the pivot are read back -- the rows
+// outside the relatives are exact zeros in this pivot order.  What it buys is VALU issue slots: a v_readlane-fed row costs two v_readlane
+// and a hazard s_nop next to its FMA (753 rows: 2.3 k of the kernel's ~18 k VALU / SALU instructions), an LDS-fed row half a ds_read_b128
+// on the LDS port.  Used by the two-wave kernel (dwbc_cycle2p.h: 71.2 -> 69.0 us per launch at B = 1024).  In the register-capped compact
+// kernel the same sweep -- hand-batched or with compiler-scheduled plain loads alike -- makes the allocator spill inside the sweep
+// (830 spilled registers, measured in round 4), so that kernel keeps the v_readlane feed.  colbuf: 64 doubles (every lane writes its
+// slot; lanes beyond NN may carry right-hand sides, see dwbc_cycle2p.h).
+#if !defined(DWBC_HOST_EMU)
+// pieces P0 .. P1-1 of the pivot column (16 bytes = rows 2P, 2P + 1), those that hold a relative of pivot K
+template <class Topo, int K, int P, int P1, int NP>
+__device__ __forceinline__ void lds_rel_issue(dwbc_d2v (&c)[NP], unsigned addr) {
+    if constexpr (P < P1) {
+        if constexpr (((Topo::relatives(K) >> (2 * P)) & 3ull) != 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[P]) : "v"(addr), "n"(16 * P));
+        lds_rel_issue<Topo, K, P + 1, P1, NP>(c, addr);
+    }
+}
+template <class Topo, int K, int P, int P1, int NP>
+__device__ __forceinline__ void lds_rel_pin(dwbc_d2v (&c)[NP]) {
+    if constexpr (P < P1) {
+        if constexpr (((Topo::relatives(K) >> (2 * P)) & 3ull) != 0) asm volatile("" : "+v"(c[P]));
+        lds_rel_pin<Topo, K, P + 1, P1, NP>(c);
+    }
+}
+// CHP: pieces per batch of reads (a batch pins up to 4 CHP registers next to the 2 NN of the column)
+template <class Topo, int NN, int K, int CHP>
+__device__ __forceinline__ void lds_pivot_tree(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
+    constexpr unsigned long long rel = Topo::relatives(K);
+    constexpr int NP = (NN + 1) / 2;
+    dwbc_d2v col[NP];
+    asm volatile("ds_write_b64 %0, %1" ::"v"(cb + 8 * lane), "v"(s[K]) : "memory");
+    lds_rel_issue<Topo, K, 0, (CHP < NP ? CHP : NP), NP>(col, cb);
+    double d = readlane_f64(dg2, K) + 2.0;
+    int pos = d > 0.0 ? 1 : 0;
+    DWBC_FLAG_VGPR(pos);
+    ok &= pos;
+    if (!(d > 0.0)) d = 1.0;
+    const double rp = fast_rcp(d);
+    const double cj = s[K];     // pivot lane: d - 1 (the diagonal is carried shifted, see lds_pivot)
+    const double h = cj * rp;
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += CHP) {
+        if (p0 > 0) {
+            if (p0 == CHP) lds_rel_issue<Topo, K, (CHP < NP ? CHP : NP), (2 * CHP < NP ? 2 * CHP : NP), NP>(col, cb);
+            else lds_rel_issue<Topo, K, (2 * CHP < NP ? 2 * CHP : NP), NP, NP>(col, cb);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p0 == 0) lds_rel_pin<Topo, K, 0, (CHP < NP ? CHP : NP), NP>(col);
+        else if (p0 == CHP) lds_rel_pin<Topo, K, (CHP < NP ? CHP : NP), (2 * CHP < NP ? 2 * CHP : NP), NP>(col);
+        else lds_rel_pin<Topo, K, (2 * CHP < NP ? 2 * CHP : NP), NP, NP>(col);
+#pragma unroll
+        for (int i = 2 * p0; i < NN && i < 2 * (p0 + CHP); i++)
+            if ((rel >> i) & 1ull) s[i] -= col[i / 2][i & 1] * h;
+    }
+    static_assert(3 * CHP >= NP, "at most three batches");
+    dg2 -= cj * h;
+    if constexpr (K > 0) lds_pivot_tree<Topo, NN, K - 1, CHP>(s, dg2, ok, cb, lane);
+}
+#endif
+template <class Topo, int NN, int CHP = (NN + 1) / 2>
+DWBC_WDEV int sweep_inverse_tree_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
+#if defined(DWBC_HOST_EMU)
+    (void)colbuf;
+    return sweep_inverse_tree<Topo, NN>(s, dg);
+#else
+    if constexpr (sizeof(real_t) != 8) {
+        return sweep_inverse_tree<Topo, NN>(s, dg);
+    } else {
+        static_assert(NN == Topo::ndof, "topology / kernel size mismatch");
+        const int lane = (int)(threadIdx.x & 63u);
+        int ok = 1;
+        {
+            DWBC_LANE_OPAQUE(lp);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == lp) ? dg - 1.0 : s[i];
+        }
+        double dg2 = dg - 2.0;
+        lds_pivot_tree<Topo, NN, NN - 1, CHP>(s, dg2, ok, (unsigned)(size_t)colbuf, lane);
+        ok = DWBC_FLAG_UNIFORM(ok);
+        {
+            DWBC_LANE_OPAQUE(le);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == le) ? -dg2 : -s[i];
+            dg = -dg2;
+        }
+        return ok;
+    }
+#endif
+}
+
 // LO: lane of matrix column 0 (the columns sit in lanes LO .. LO + NN - 1; colbuf: 64 doubles)
 template <int NN, int LO = 0>
 DWBC_WDEV int sweep_inverse_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {

@@ -476,7 +476,9 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 LV(dg) = real_t(1.0);
             }
         }
-        if (!sweep_inverse_tree<Topo, N>(s, dg)) st_contact = 0;  // A_inv (dwbc.cpp:307)
+        DWBC_SYNC();
+        if (!sweep_inverse_tree_lds<Topo, N>(s, dg, L + S::c_s1)) st_contact = 0;  // A_inv (dwbc.cpp:307), pivot column through LDS
+        DWBC_SYNC();
         if (too_many) st_contact = 0;
         LANES {
             if (lane >= N) {  // (negated by the sweep's epilogue like the matrix lanes)
@@ -1149,30 +1151,41 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     // getContactForce(tau_total) = Jbar[:, 6:] tau - P_C (wbd.cpp:268-271).  In the contact frames that is a column combination of the
     // wrench maps: gravity column - P_C + sum_l WM_{U_l} (f* + f*_qp)_l + WM_N (contact_qp_ + redistribution); rotated back with
     // blockdiag(R_a, R_a).
-    for (int i = th.tid; i < 12; i += NT) {
-        real_t acc = real_t(0.0);
-        if (i < cd && !too_many) {
-            const int a = i / 6, h = (i % 6) / 3, y = i % 3;
-            const real_t *R = L + S::Rc + a * 9;
-            const real_t *pc3 = L + S::PC + 6 * a + 3 * h;
-            real_t loc[3];
+    // (lane r forms row r of the local wrench -- its reads in one straight-line batch --, the rows regroup through LDS for the rotation:
+    // twelve lanes that each walked three rows one dependent read after the other were 6 k cycles of this phase)
+    real_t *wloc = L + S::t_fv;
+    LANES {
+        const int r = lane < C ? lane : 0;
+        const int a = r / 6, h = (r % 6) / 3, x_ = r % 3;
+        const real_t *R = L + S::Rc + a * 9;
+        const real_t *pc3 = L + S::PC + 6 * a + 3 * h;
+        const real_t *row = WM + r * WLD;
+        real_t wv[1 + NLV * 6 + 6];
 #pragma unroll
-            for (int x_ = 0; x_ < 3; x_++) {
-                const int r = 6 * a + 3 * h + x_;
-                real_t v = WM[r * WLD] - (R[x_] * pc3[0] + R[3 + x_] * pc3[1] + R[6 + x_] * pc3[2]);
+        for (int j = 0; j < 1 + NLV * 6 + 6; j++) wv[j] = row[j < 1 + NLV * 6 ? j : colN + (j - 1 - NLV * 6)];
+        real_t v = wv[0] - (R[x_] * pc3[0] + R[3 + x_] * pc3[1] + R[6 + x_] * pc3[2]);
 #pragma unroll
-                for (int l = 0; l < NLV; l++) {
-                    const int off = l < su.n_levels ? 1 + su.fstar_off[l] : 1;
+        for (int l = 0; l < NLV; l++) {
+            const int off = l < su.n_levels ? su.fstar_off[l] : 0, tl = l < su.n_levels ? su.t_dof[l] : 0;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v += (l < su.n_levels && j < su.t_dof[l]) ? WM[r * WLD + off + j] * fx[l * 6 + j] : real_t(0.0);
-                }
-#pragma unroll
-                for (int j = 0; j < 6; j++) v += (j < k) ? WM[r * WLD + colN + j] * ctot[j] : real_t(0.0);
-                loc[x_] = v;
+            for (int j = 0; j < 6; j++) {
+                // (column 1 + off + j of the row: the levels' blocks follow each other, so with two levels the offsets are 0 and t_0)
+                real_t wj = wv[1 + j];
+                if (l == 1) wj = (off == 3) ? wv[1 + 3 + j] : wv[1 + 6 + j];
+                v += (j < tl) ? wj * fx[l * 6 + j] : real_t(0.0);
             }
-            acc = R[y * 3] * loc[0] + R[y * 3 + 1] * loc[1] + R[y * 3 + 2] * loc[2];
         }
-        wr[i] = acc;
+#pragma unroll
+        for (int j = 0; j < 6; j++) v += (j < k) ? wv[1 + NLV * 6 + j] * ctot[j] : real_t(0.0);
+        if (lane < C) wloc[lane] = (lane < cd && !too_many) ? v : real_t(0.0);
+    }
+    DWBC_SYNC();
+    LANES {
+        const int i = lane < C ? lane : 0;
+        const int a = i / 6, y = i % 3, g3 = 3 * (i / 3);
+        const real_t *R = L + S::Rc + a * 9;
+        const real_t acc = R[y * 3] * wloc[g3] + R[y * 3 + 1] * wloc[g3 + 1] + R[y * 3 + 2] * wloc[g3 + 2];
+        if (lane < 12) wr[lane] = (lane < cd && !too_many) ? acc : real_t(0.0);
     }
     DWBC_STAMP(15);
     if (th.tid == 0) {
