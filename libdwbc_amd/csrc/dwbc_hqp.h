@@ -29,11 +29,20 @@
 #else
 #define HQP_SYNC() __syncthreads()
 #endif
+// ordering point inside ONE wavefront (its lanes run in lockstep and its LDS operations execute in order: only the compiler has to be kept
+// from moving LDS accesses across it) -- for the steps that wave 0 runs alone between two workgroup barriers
+#if defined(DWBC_HOST_EMU)
+#define HQP_WSYNC() ((void)0)
+#else
+#define HQP_WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#endif
 
 namespace dwbc {
 
 constexpr int kHqpMaxLevels = 8;
 constexpr int kHqpMaxQ = 32;   // working-set capacity of one level's QP
+constexpr int kHqpW0 = 64;     // lanes of the one wave that refreshes the Cholesky factor of the working set's matrix
+constexpr int kArgMax = 32;    // groups of 16 rows in the two-stage arg-min: up to 512 constraint rows of one level's QP
 constexpr int kHqpMaxEq = 32;  // equality rows of one level
 constexpr int kHqpMaxVar = 64; // y size (acceleration + torque + contact)
 
@@ -63,7 +72,7 @@ struct HqpIO {
 
 // LDS map of the solver (doubles)
 struct HqpLds {
-    int Hinv, T, Mm, Lc, Bz, u, g, zu, tp, yp, cp, hy, rr, r, lam, rhs, vv, dd, sl, inw, wl, total;
+    int Hinv, T, Mm, Lc, Bz, u, g, zu, tp, yp, cp, hy, rr, r, lam, rhs, vv, dd, sl, inw, wl, am, total;
     __host__ __device__ static HqpLds make(int nv, int max_rows) {
         HqpLds l;
         int o = 0;
@@ -89,6 +98,7 @@ struct HqpLds {
         l.sl = o; o += ev(max_rows);
         l.inw = o; o += ev(max_rows);
         l.wl = o; o += kHqpMaxQ;
+        l.am = o; o += 2 * kArgMax;   // group minima of the arg-min and their rows
         l.total = o + 8;
         return l;
     }
@@ -307,7 +317,7 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
             double *Hinv = L + l.Hinv, *T = L + l.T, *Mm = L + l.Mm, *Lc = L + l.Lc, *Bz = L + l.Bz;
             double *u = L + l.u, *g = L + l.g, *zu = L + l.zu, *tp = L + l.tp, *yp = L + l.yp, *cp = L + l.cp, *hy = L + l.hy;
             double *rr = L + l.rr, *r = L + l.r, *lam = L + l.lam, *rhs = L + l.rhs, *vv = L + l.vv, *dd = L + l.dd, *sl = L + l.sl;
-            double *inw = L + l.inw, *wl = L + l.wl;
+            double *inw = L + l.inw, *wl = L + l.wl, *rhs2 = L + l.am;
             int status = 1, iters = 0;
             HQP_SYNC();
             for (int i = th.tid; i < nv; i += NT) yp[i] = lv > 0 ? rec[d.oy[lv - 1] + i] : 0.0;
@@ -399,10 +409,23 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
                     sl[row] = inw[row] != 0.0 ? 1.0e300 : s;
                 }
                 HQP_SYNC();
+                // arg-min (first row of the smallest slack) in two stages: groups of kArgG rows by one thread each, then the group minima
+                // by every thread -- 16 + ceil(nrows / 16) reads per thread instead of nrows by every thread (152 for the TOCABI LQP)
+                const int kArgG = nrows <= 16 * kArgMax ? 16 : (nrows + kArgMax - 1) / kArgMax;
+                const int ngrp = (nrows + kArgG - 1) / kArgG;
+                for (int gi = th.tid; gi < ngrp; gi += NT) {
+                    int bp = -1;
+                    double bw = 1.0e300;
+                    for (int row = gi * kArgG; row < nrows && row < (gi + 1) * kArgG; row++)
+                        if (sl[row] < bw) { bw = sl[row]; bp = row; }
+                    rhs2[gi] = bw;
+                    rhs2[kArgMax + gi] = (double)bp;
+                }
+                HQP_SYNC();
                 int p = -1;
                 double worst = 1.0e300;
-                for (int row = 0; row < nrows; row++)
-                    if (sl[row] < worst) { worst = sl[row]; p = row; }
+                for (int gi = 0; gi < ngrp; gi++)
+                    if (rhs2[gi] < worst) { worst = rhs2[gi]; p = (int)rhs2[kArgMax + gi]; }
                 if (p < 0 || !(worst < -d.tol)) break;
                 const bool psoft = p < mo;
                 double lam_p = 0.0;
@@ -423,22 +446,38 @@ DWBC_DEV void hqp_instance(Thr th, const HqpDesc &d, const HqpIO &io, int inst, 
                         rhs[a] = acc;
                     }
                     HQP_SYNC();
-                    if (nw > 0 && th.tid == 0) {  // r = M^-1 rhs by a fresh Cholesky factor (q <= 32: serial, in LDS)
-                        for (int i = 0; i < nw; i++)
-                            for (int j = 0; j <= i; j++) {
-                                double s = Mm[i * kHqpMaxQ + j];
-                                for (int c = 0; c < j; c++) s -= Lc[i * kHqpMaxQ + c] * Lc[j * kHqpMaxQ + c];
-                                Lc[i * kHqpMaxQ + j] = (i == j) ? sqrt(s > 1e-300 ? s : 1e-300) : s / Lc[j * kHqpMaxQ + j];
+                    if (nw > 0 && th.tid < kHqpW0) {
+                        // r = M^-1 rhs by a fresh Cholesky factor (q <= 32), on wave 0 alone: row i of the factor per lane, column by column
+                        // (left-looking: L[i][j] = (M[i][j] - sum_{c<j} L[i][c] L[j][c]) / L[j][j]), then the two triangular solves in their
+                        // column-oriented form.  Between the columns only this wave has to see its own LDS writes: no workgroup barrier.
+                        // (One thread doing all of it serially was O(q^3 / 6) dependent LDS round trips per active-set step.)
+                        constexpr int WS_ = NT < kHqpW0 ? NT : kHqpW0;
+                        for (int j = 0; j < nw; j++) {
+                            for (int i = j + th.tid; i < nw; i += WS_) {
+                                double s_ = Mm[i * kHqpMaxQ + j];
+                                for (int c = 0; c < j; c++) s_ -= Lc[i * kHqpMaxQ + c] * Lc[j * kHqpMaxQ + c];
+                                Lc[i * kHqpMaxQ + j] = s_;  // (row j: the squared pivot; the rows below it are scaled once it is known)
                             }
-                        for (int i = 0; i < nw; i++) {
-                            double s = rhs[i];
-                            for (int c = 0; c < i; c++) s -= Lc[i * kHqpMaxQ + c] * r[c];
-                            r[i] = s / Lc[i * kHqpMaxQ + i];
+                            HQP_WSYNC();
+                            const double pj = Lc[j * kHqpMaxQ + j];
+                            const double dj_ = sqrt(pj > 1e-300 ? pj : 1e-300);
+                            HQP_WSYNC();
+                            for (int i = j + th.tid; i < nw; i += WS_) Lc[i * kHqpMaxQ + j] = (i == j) ? dj_ : Lc[i * kHqpMaxQ + j] / dj_;
+                            HQP_WSYNC();
                         }
-                        for (int i = nw - 1; i >= 0; i--) {
-                            double s = r[i];
-                            for (int c = i + 1; c < nw; c++) s -= Lc[c * kHqpMaxQ + i] * r[c];
-                            r[i] = s / Lc[i * kHqpMaxQ + i];
+                        for (int i = th.tid; i < nw; i += WS_) r[i] = rhs[i];
+                        HQP_WSYNC();
+                        for (int c = 0; c < nw; c++) {  // L y = rhs
+                            const double yc = r[c] / Lc[c * kHqpMaxQ + c];
+                            HQP_WSYNC();
+                            for (int i = c + th.tid; i < nw; i += WS_) r[i] = (i == c) ? yc : r[i] - Lc[i * kHqpMaxQ + c] * yc;
+                            HQP_WSYNC();
+                        }
+                        for (int c = nw - 1; c >= 0; c--) {  // L^T r = y
+                            const double xc = r[c] / Lc[c * kHqpMaxQ + c];
+                            HQP_WSYNC();
+                            for (int i = th.tid; i <= c; i += WS_) r[i] = (i == c) ? xc : r[i] - Lc[c * kHqpMaxQ + i] * xc;
+                            HQP_WSYNC();
                         }
                     }
                     HQP_SYNC();
