@@ -432,6 +432,7 @@ DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out
                     for (int i = 0; i < NC; i++) a4[i & 3] += c[q][i / 2][i & 1] * x[i];
                     const real_t d = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                     if (MODE == 0) out[OFF + r0 + q] = d; else out[OFF + r0 + q] -= d;
+                    asm volatile("" : "+v"(out[OFF + r0 + q]));  // (keeps the products here: sunk into a later conditional user they would hold every piece alive)
                 }
             }
         }
@@ -449,28 +450,40 @@ DWBC_WDEV void lds_rows_dot(const real_t *A, const real_t (&x)[NC], real_t (&out
 }
 
 // acc[p] += sum_{r < NR} A[r][p] * x[r]  for NR consecutive rows (NC entries each, row stride RS) of an LDS-resident matrix: the
-// "own column . uniform operand" product with the rows as the reduction index (Y = J_C A^-1: A = rows of J_C^T, x = the lane's
-// entries of its A^-1 column).  All NR * NC / 2 reads are issued back to back and waited for once (see lds_rows_dot).
-template <int NR, int NC, int RS, bool ALIGNED = true>
+// "own coefficients . uniform rows" product with the rows as the reduction index (the inverse-dynamics form of W^+ in dwbc_cycle2p.h:
+// A = the vectors stored transposed, x = the lane's entries of its row of the mass matrix).  The reads of CH rows are issued back to
+// back and waited for once (see lds_rows_dot); the accumulators are pinned behind the last batch so that the products stay here.
+template <int NR, int NC, int RS, int CH, bool ALIGNED = true>
 DWBC_WDEV void lds_rows_axpy(const real_t *A, const real_t (&x)[NR], real_t (&acc)[NC]) {
 #if !defined(DWBC_HOST_EMU)
     if constexpr (sizeof(real_t) == 8 && RS % 2 == 0 && NC % 2 == 0 && ALIGNED) {
         constexpr int NP = NC / 2;
         const unsigned a0 = (unsigned)(size_t)A;
-        dwbc_d2v c[NR][NP];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < NR; r++) lds_col_issue<0, NP>(c[r], a0 + (unsigned)(r * RS * 8));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int r0 = 0; r0 < NR; r0 += CH) {
+            dwbc_d2v c[CH][NP];
 #pragma unroll
-        for (int r = 0; r < NR; r++) lds_col_pin<0, NP>(c[r]);
+            for (int q = 0; q < CH; q++)
+                if (r0 + q < NR) lds_col_issue<0, NP>(c[q], a0 + (unsigned)((r0 + q) * RS * 8));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < NR; r++)
+            for (int q = 0; q < CH; q++)
+                if (r0 + q < NR) lds_col_pin<0, NP>(c[q]);
 #pragma unroll
-            for (int p = 0; p < NC; p++) acc[p] += c[r][p / 2][p & 1] * x[r];
+            for (int q = 0; q < CH; q++) {
+                if (r0 + q < NR) {
+#pragma unroll
+                    for (int p = 0; p < NC; p++) acc[p] += c[q][p / 2][p & 1] * x[r0 + q];
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NC; p++) asm volatile("" : "+v"(acc[p]));
         return;
     }
 #endif
+#pragma unroll
     for (int r = 0; r < NR; r++)
 #pragma unroll
         for (int p = 0; p < NC; p++) acc[p] += A[r * RS + p] * x[r];
@@ -584,6 +597,11 @@ DWBC_WDEV int sweep_inverse_tree_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg),
             for (int i = 0; i < NN; i++) s[i] = (i == le) ? -dg2 : -s[i];
             dg = -dg2;
         }
+        // (the swept columns are pinned here: when their only readers sit in a conditional block -- the stores of the riding lanes in
+        // dwbc_cycle2p.h -- the compiler sinks the row updates of every pivot into that block and keeps all the pivot columns alive
+        // for it: 900 spilled registers inside the sweep)
+#pragma unroll
+        for (int i = 0; i < NN; i++) asm volatile("" : "+v"(s[i]));
         return ok;
     }
 #endif

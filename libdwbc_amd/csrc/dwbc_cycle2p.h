@@ -59,31 +59,33 @@ struct Lds4 {
     static constexpr int c_vec = G + ev(N);
     static constexpr int c_col = c_vec + ev(N);
     static constexpr int hend = c_col + ev(M);
-    // ---- link frames (stage 0 .. B1)
+    // ---- link frames (phase 0 .. 1a); then what rode through the A^-1 sweep next to Y (phase 1b .. 3); then the QP scratch (phase 5)
     static constexpr int Rw = hend;
     static constexpr int pw = Rw + NB * 9;
     static constexpr int aw = pw + NB * 3;
     static constexpr int Rw0 = Rw;
     static constexpr int fend = aw + NB * 3;
-    // phase 4 -> 5: (W + alpha P)^-1 T1r^T of every level, one row per task dof (the right-hand sides that ride through the W^+
-    // sweep in its idle lanes), over the link frames, which are dead after B1
-    // phase 1b -> 3: what rode through the A^-1 sweep next to Y: rows of J_t A^-1 (one per task dof, <= 12) and A^-1 G (row 12), stride N
+    // phase 1b -> 3: rows of J_t A^-1 (slot l * T + r, stride N) and A^-1 G (row NLV * T)
+    static constexpr int NVS = NLV * T + 1;                    // vectors W^+ is applied to: one slot per task dof of every level + the gravity pre-vector
     static constexpr int ajt = Rw;
-    static_assert(13 * N <= fend - Rw, "J_t A^-1 and A^-1 G borrow the link frames");
-    static constexpr int jk = Rw;
-    static_assert(Rw % 2 == 0, "16-byte aligned rows");
+    static_assert(NVS * N <= fend - Rw && Rw % 2 == 0, "J_t A^-1 and A^-1 G borrow the link frames");
+    // phase 4: the vectors transposed, AT[j][v] (M x VS)
+    static constexpr int VS = ev(NVS);
+    static constexpr int at = Rw;
+    static_assert(M * VS <= fend - Rw, "the transposed vectors borrow the link frames");
     // ---- long-lived
-    static constexpr int JbT = fend;                           // C x N; J_C (N x C) until Jbar^T is written over it
-    static constexpr int c_JC = JbT;
-    static constexpr int NwJw = JbT + C * N;
-    static constexpr int NL2 = NLV < 2 ? 2 : NLV;              // (the U / T1x regions also host the staged mass matrix)
-    static constexpr int U = NwJw + M * K;                     // levels x (M x T)
+    static constexpr int c_JC = fend;                          // N x C: J_C, phase 1a .. 4 (the inverse-dynamics form of W^+ reads it)
+    static constexpr int NwJw = c_JC + C * N;
+    static constexpr int NL2 = NLV < 2 ? 2 : NLV;              // (the U / T1x-sized region hosts the staged mass matrix until phase 4)
+    static constexpr int U = NwJw + M * K;                     // levels x (M x T), phase 5
     static constexpr int MS = ev(M);                           // row stride of T1x: even, so that every row is 16-byte aligned (lds_rows_dot)
-    static constexpr int T1x = U + NL2 * M * T;                // levels x (T x MS): joint columns of T1 of every level
-    static constexpr int c_T1 = T1x + NL2 * T * MS;            // levels x (T x 6): base columns of T1
-    static constexpr int c_Lt = c_T1 + NLV * T * 6;            // levels x T x T
-    static constexpr int Jtt = c_Lt + NLV * T * T;             // levels x (N x T): J_task transposed, helper phase 1 -> main phase 3, helper phase 4
-    static constexpr int c_Vb = Jtt + NLV * N * T;             // M x K
+    static constexpr int UAend = U + NL2 * M * T + NL2 * T * MS;
+    static constexpr int c_Hb = UAend;                         // 6 x C: (J_Cb^T J_Cb)^-1 J_Cb^T (A_bb^-1 when no contact is active), phase 1b .. 4
+    static constexpr int c_Lt = c_Hb + 6 * C;                  // levels x T x T
+    static constexpr int Jtt = c_Lt + NLV * T * T;             // levels x (N x T): J_task transposed, phase 1a .. 2; then Jbar^T
+    static constexpr int JbT = Jtt;                            // C x N, phase 2 .. 5
+    static_assert(C * N <= NLV * N * T || NLV < 2, "Jbar^T takes the place of J_t^T");
+    static constexpr int c_Vb = Jtt + max2(NLV * N * T, C * N);  // M x K
     static constexpr int c_VG = c_Vb + M * K;                  // M x K
     static constexpr int hs = c_VG + M * K;                    // helper's small scratch: 4 x 36 + 72
     static constexpr int hs_size = 4 * 36 + 72;
@@ -92,7 +94,7 @@ struct Lds4 {
     static constexpr int c_s2 = ms + max2(C * K, 64);
     static constexpr int c_Lam = c_s2;
     static constexpr int ms_size = max2(C * K, 64) + C * C;
-    static constexpr int kin = ms + ms_size;                   // stage-0 scratch of the main wave; afterwards Y, then stage 3a / QP scratch
+    static constexpr int kin = ms + ms_size;                   // phase-1a scratch of the main wave; afterwards Y, D, T1x, then phase 4 / 5 scratch
     static constexpr int k_Iw = kin;
     static constexpr int k_Ic = k_Iw + NB * 10;
     static constexpr int k_Rl = k_Iw + NB * 3;
@@ -102,33 +104,45 @@ struct Lds4 {
     static constexpr int k_F = k_S + N * 6;
     static constexpr int kin_end = k_F + N * 6;
     static constexpr bool a_overlay = false, a_packed = true;
-    static constexpr int k_A = U;                              // packed lower triangle over U / T1x (written from phase 3 / stage 3a on)
-    static_assert(N * (N + 1) / 2 <= (c_T1 - U), "the staged mass matrix borrows the U / T1x region");
-    static constexpr int c_Y = kin;                            // N x C (phase 2-3)
-    static constexpr int c_D = kin + C * N;                    // helper, phase 2-3: D = J_t A^-1 J_C^T (<= 12 x C), then Y G (C)
-    static_assert(C * N + 13 * C <= kin_end - kin && (kin + C * N) % 2 == 0, "Y and D borrow the stage-0 scratch");
-    // stage 3a scratch of the main wave (phase 5) and the QP scratch, over the dead stage-0 scratch
+    static constexpr int k_A = U;                              // packed lower triangle, phase 1a .. 4 (U itself is written in phase 5)
+    static_assert(N * (N + 1) / 2 <= (UAend - U), "the staged mass matrix borrows the U / T1x-sized region");
+    static constexpr int c_Y = kin;                            // N x C (phase 1b .. 3)
+    static constexpr int c_D = kin + C * N;                    // phase 2 .. 3: D = J_t A^-1 J_C^T (NLV * T x C), then Y G (C)
+    static constexpr int c_BJ = c_D + (NLV * T + 1) * C;       // phase 2 .. 3: (J_t A^-1) J_t^T of every level (T x T each)
+    // (T1x: levels x (T x MS), the joint columns of T1 of every level, phase 3 .. 5 -- behind the task Gram blocks AND behind the
+    // slow-route scratch of phase 5, which starts at `kin` as well)
+    static constexpr int T1x = ev(max2(c_BJ + NLV * T * T, kin + 2 * T * M + 6 * T * T + 3 * T));
+    static_assert(T1x + NLV * T * MS <= kin_end, "Y, D, the task Gram blocks and T1x borrow the phase-1a scratch");
+    // phase 4 scratch over Y (dead after phase 3): b (C x VS), qb (6 x VS), cv (6 x VS), lam (C x VS), w (K x VS); the torque staging
+    // TS (M x VS) overlays b .. lam once they are consumed
+    static constexpr int p4_b = kin;                           // b = J_Cj a (C x VS); lam = -Hb^T cv takes its place once qb exists
+    static constexpr int p4_qb = p4_b + C * VS;
+    static constexpr int p4_cv = p4_qb + 6 * VS;
+    static constexpr int p4_lam = p4_b;
+    static constexpr int p4_ts = kin;                          // tau_any transposed (M x VS), over all of the above
+    static constexpr int p4_w = at;                            // Vb^T tau_any (K x VS): over the vectors themselves, dead by then
+    static_assert(kin % 2 == 0 && at % 2 == 0, "16-byte aligned rows of the phase-4 blocks (lds_rows_axpy)");
+    static_assert(p4_cv + 6 * VS <= c_D && p4_ts + M * VS <= c_D, "phase-4 scratch stays below D and the task Gram blocks (the helper reads them in parallel)");
     static constexpr int c_QW = kin;                           // Q (slow route)
     static constexpr int c_QWp = c_QW + T * M;                 // Q W^+ (slow route)
     static constexpr int c_Pi = c_QWp + T * M;
     static constexpr int c_Z = c_Pi + T * T;
     static constexpr int c_s2b = c_Z + T * T;
     static constexpr int cod_Q = c_s2b + T * T, cod_v = cod_Q + T * T, cod_G = cod_v + 3 * T, cod_T = cod_G + T * T;
-    static constexpr int Xl = cod_T + T * T;                   // X of levels 1 .. NLV-2
-    static constexpr int xl(int lv) { return lv == 0 ? U : Xl + (lv - 1) * M * T; }
-    static constexpr int t_base = Xl + (NLV > 2 ? (NLV - 2) * M * T : 0);
-    static constexpr int wm = ev(t_base + M);
+    static_assert(cod_T + T * T <= T1x, "slow-route scratch stays below T1x");
+    static constexpr int xl(int lv) { return U; }
+    // QP scratch of phase 5, over the link frames
+    static constexpr int t_base = Rw;                          // (f* + f*_qp of the committed levels: NLV x 6)
+    static constexpr int wm = ev(t_base + NLV * 6);
     static constexpr int t_fv = wm + C * WLD;
-    static constexpr int t_wacc = t_fv + C;
-    static constexpr int t_cl = t_wacc + C;
-    static constexpr int qp_V = t_cl + K;
-    static constexpr int qp_x = qp_V + kQpLd;
-    static constexpr int p5_end = qp_x + kQpLd;
-    static_assert(NLV * T * MS <= fend - Rw, "the J_kt staging block borrows the link frames");
-    static constexpr int total = max2(kin_end, p5_end);
+    static constexpr int qp_V = t_fv + C;
+    static constexpr int p5_end = qp_V + kQpLd;
+    static_assert(p5_end <= fend, "QP scratch over the link frames");
+    static constexpr int c_T1 = 0;                             // (base columns of T1: not formed in this kernel)
+    static constexpr int total = kin_end;
     static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
     // names of the other maps that shared helpers mention but this kernel does not use
-    static constexpr int FNl = NwJw, comp = flg, Jcm = 0, Pt = 0, c_Gi = 0, T1r = T1x, c_Q = T1x, c_Jt = Jtt, t_F = wm, t_s1 = wm;
+    static constexpr int FNl = NwJw, comp = flg, Jcm = 0, Pt = 0, c_Gi = 0, T1r = T1x, c_Q = T1x, c_Jt = Jtt, t_F = wm, t_s1 = wm, jk = 0;
 };
 
 #if defined(DWBC_HOST_EMU)
@@ -161,6 +175,56 @@ struct Lds4 {
 #define DWBC_PSTAMP(i) ((void)0)
 #define DWBC_PSTAMP_M(i) ((void)0)
 #endif
+
+// D = A B for the small dense products of phases 3 - 4 on the matrix cores: MT row tiles of 16, 16 columns, KB reduction blocks of 4
+// (v_mfma_f64_16x16x4_f64; operand layout as in wrench_maps, dwbc_cycle2.h: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+// D[i = (l >> 4) + 4 r][j = l & 15]).  fa(i, k) / fb(k, j) return the operand entries (zero outside the matrices: each is one LDS
+// read from a clamped address and a select), fstore(i, j, v) takes every entry of the result tiles.  SYNC_STORE: a wave-level
+// fence between the last read and the first store, for results written over their own operands; fc(i, j): the value the
+// accumulation starts from.  One wave.  The host emulation
+// (and nothing else) takes the plain triple loop.
+template <int MT, int KB, bool SYNC_STORE, class FA, class FB, class FS, class FC>
+DWBC_WDEV void wave_gemm(FA fa, FB fb, FS fstore, FC fc) {
+#if !defined(DWBC_HOST_EMU)
+    static_assert(sizeof(real_t) == 8, "fp64 build");
+    typedef double g_d4 __attribute__((ext_vector_type(4)));
+    const int lane = (int)(threadIdx.x & 63u), li = lane & 15, lk = lane >> 4;
+    g_d4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[t][r] = fc(16 * t + lk + 4 * r, li);
+#pragma unroll
+    for (int s_ = 0; s_ < KB; s_++) {
+        const int kk = 4 * s_ + lk;
+        const double bv = fb(kk, li);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const double av = fa(16 * t + li, kk);
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+    if (SYNC_STORE) DWBC_SYNC();
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) fstore(16 * t + lk + 4 * r, li, acc[t][r]);
+#else
+    real_t tmp[MT * 16][16];
+    for (int i = 0; i < MT * 16; i++)
+        for (int j = 0; j < 16; j++) {
+            real_t a_ = fc(i, j);
+            for (int kk = 0; kk < 4 * KB; kk++) a_ += fa(i, kk) * fb(kk, j);
+            tmp[i][j] = a_;
+        }
+    for (int i = 0; i < MT * 16; i++)
+        for (int j = 0; j < 16; j++) fstore(i, j, tmp[i][j]);
+#endif
+}
+template <int MT, int KB, bool SYNC_STORE, class FA, class FB, class FS>
+DWBC_WDEV void wave_gemm(FA fa, FB fb, FS fstore) {
+    wave_gemm<MT, KB, SYNC_STORE>(fa, fb, fstore, [](int, int) { return real_t(0.0); });
+}
 
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
 template <int N, int NB, int NLV, int NT, class Topo>
@@ -451,22 +515,20 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     }
     DWBC_PAIR_BARRIER_X();  // ---- B1a: J_C, J_t, G in LDS; the columns of A in the main wave's registers
     real_t *AJt = L + S::ajt;
+    constexpr int NVS = S::NVS, VS = S::VS, GV = NLV * T;  // vector slots: l * T + r for task dof r of level l, GV = the gravity pre-vector
     if (is_main) {
         // The A^-1 sweep uses N = 39 of the 64 lanes; the other 25 carry right-hand sides through the same pivots (a Gauss-Jordan
         // sweep of [A | X] leaves A^-1 X in the extra columns, with the FMAs every non-pivot lane executes anyway; a row outside the
         // pivot's relatives would receive c_i * h with c_i == 0 there as well): lanes N .. N+11 the rows of J_C (-> Y = J_C A^-1,
-        // wbd.cpp:113), lanes N+12 .. N+23 the rows of J_t of every level (-> J_t A^-1), lane 63 G (-> A^-1 G).  The products
-        // Y = J_C A^-1 (phase 2), T1 = J_t A^-1 N_c and the gravity pre-vector (phase 3) no longer pass through this wave: the helper
-        // forms the last two from what rode here.
-        static_assert(N + 25 == 64, "rhs lanes: 12 + 12 + 1");
+        // wbd.cpp:113), the next NLV * T lanes the rows of J_t (slot l * T + r -> J_t A^-1), one more G (-> A^-1 G).  Nothing else of
+        // A^-1 is used in this kernel: every later product is written in terms of these vectors.
+        static_assert(N + C + NVS <= 64, "rhs lanes");
         LANES {
             if (lane >= N) {
                 const int jj = lane - N, jt = jj - C;
-                int lvl = 0;
-#pragma unroll
-                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && jt >= su.fstar_off[q_]) ? q_ : lvl;
-                const bool isc = jj < C, ist = jt >= 0 && jt < su.fstar_total, isg = jj == 2 * C;
-                const real_t *bp = isc ? JCt + jj : (isg ? L + S::G : L + S::Jtt + lvl * N * T + (ist ? jt - su.fstar_off[lvl] : 0));
+                const int lvl = (jt >= 0 && jt < GV) ? jt / T : 0, r_ = (jt >= 0 && jt < GV) ? jt - lvl * T : 0;
+                const bool isc = jj < C, ist = jt >= 0 && jt < GV && lvl < su.n_levels && r_ < su.t_dof[lvl], isg = jt == GV;
+                const real_t *bp = isc ? JCt + jj : (isg ? L + S::G : L + S::Jtt + lvl * N * T + r_);
                 const int st = isc ? C : (isg ? 1 : T);
 #pragma unroll
                 for (int i = 0; i < N; i++) {
@@ -481,7 +543,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         DWBC_SYNC();
         if (too_many) st_contact = 0;
         LANES {
-            if (lane >= N) {  // (negated by the sweep's epilogue like the matrix lanes)
+            if (lane >= N && lane - N < C + NVS) {  // (negated by the sweep's epilogue like the matrix lanes)
                 const int jj = lane - N;
                 real_t *bp = jj < C ? Yt + jj : AJt + (jj - C) * N;
                 const int st = jj < C ? C : 1;
@@ -491,22 +553,57 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         }
         DWBC_SYNC();
     }
-    if (is_help && k > 0) {
-        // internal-wrench basis and its Gram algebra (beside the sweep)
-        constexpr int K6 = 6;
-        internal_wrench_basis<N, NT>(th, L + S::Pc, JCt, Vb);
-        DWBC_SYNC();
-        real_t *Gi = L + S::hs + 36;
-        mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
-        DWBC_SYNC();
-        spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::hs + 144);               // G^-1
-        mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1
-        DWBC_SYNC();
+    real_t *Hb = L + S::c_Hb;
+    const real_t *Ap = L + S::k_A;  // staged mass matrix: lower triangle, row-packed -- alive until phase 4 in this kernel
+    if (is_help) {
+        if (k > 0) {
+            // internal-wrench basis and its Gram algebra (beside the sweep)
+            constexpr int K6 = 6;
+            internal_wrench_basis<N, NT>(th, L + S::Pc, JCt, Vb);
+            DWBC_SYNC();
+            real_t *Gi = L + S::hs + 36;
+            mm_tn<NT>(th, Gi, K6, Vb, K6, Vb, K6, K6, M, K6);                      // G
+            DWBC_SYNC();
+            spd_inverse_small(Gi, K6, K6, Gi, K6, L + S::hs + 144);               // G^-1
+            mm_nn<NT>(th, VG, K6, Vb, K6, Gi, K6, M, K6, K6);                       // VG = Vb G^-1
+            DWBC_SYNC();
+        }
+        // Hb: what turns the contact rows into a base acceleration and a base wrench into contact forces in phase 4:
+        //   contacts:     Hb = (J_Cb^T J_Cb)^-1 J_Cb^T  (6 x cd; J_Cb = the base columns of J_C, full column rank)
+        //   no contact:   Hb[:, 0:6] = A_bb^-1
+        {
+            real_t *Gb = L + S::hs + 72, *Gbi = L + S::hs + 108;
+            for (int idx = th.tid; idx < 36; idx += NT) {
+                const int x = idx / 6, y = idx - x * 6;
+                real_t acc = real_t(0.0);
+                if (nc > 0) {
+#pragma unroll
+                    for (int p = 0; p < C; p++) acc += (p < cd) ? JCt[x * C + p] * JCt[y * C + p] : real_t(0.0);
+                } else {
+                    acc = x >= y ? Ap[x * (x + 1) / 2 + y] : Ap[y * (y + 1) / 2 + x];
+                }
+                Gb[idx] = acc;
+            }
+            DWBC_SYNC();
+            if (!spd_inverse_small(Gb, 6, 6, Gbi, 6, L + S::hs + 144)) { if (th.tid == 0) flg[0] = real_t(0.0); }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < 6 * C; idx += NT) {
+                const int x = idx / C, p = idx - x * C;
+                real_t acc = real_t(0.0);
+                if (nc > 0) {
+#pragma unroll
+                    for (int y = 0; y < 6; y++) acc += (p < cd) ? Gbi[x * 6 + y] * JCt[y * C + p] : real_t(0.0);
+                } else {
+                    acc = p < 6 ? Gbi[x * 6 + p] : real_t(0.0);
+                }
+                Hb[idx] = acc;
+            }
+            DWBC_SYNC();
+        }
     }
-    DWBC_PAIR_BARRIER(1);  // ---- B1: A^-1 in the main wave's registers; Y, J_t A^-1, A^-1 G, J_C, Vb, VG, J_t in LDS
+    DWBC_PAIR_BARRIER(1);  // ---- B1: Y, J_t A^-1, A^-1 G in LDS; J_C, Vb, VG, Hb
 
-    // ================= phase 2 (main): Y = J_C A^-1, Lambda_c, Jbar^T =================
-    const unsigned long long cm0 = nc > 0 ? su.c_dofmask[act_c[0]] : 0ull, cm1 = nc > 1 ? su.c_dofmask[act_c[1]] : 0ull;
+    // ================= phase 2: Lambda_c, Jbar^T (main) | D, Y G, the task Gram blocks (helper) =================
     if (is_main) {
         DWBC_PSTAMP_M(42);  // Y = J_C A^-1 stored
 #if !defined(DWBC_HOST_EMU)
@@ -540,43 +637,44 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         }
         if (cd > 0) {
             if (!spd_inverse_small(L + S::c_s2, C, cd, Lam, C, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
+        } else {
+            for (int idx = th.tid; idx < C * C; idx += NT) Lam[idx] = real_t(0.0);
         }
         DWBC_SYNC();
     }
     if (is_main) DWBC_PSTAMP_M(43);  // Lambda_c
-    // Jbar^T = Lambda J A^-1 (wbd.cpp:116) is written over J_C: keep it in registers until the barrier has been passed? no -- J_C is
-    // read by this wave only from here on (the helper's readers of J_C finished before B1), so the overwrite is safe at once.
-    PLA(real_t, jbk, C);  // main wave: column `lane` of Jbar^T, kept for the A^-1 N_c update of phase 3
-    PLA(real_t, yck, C);
+    PLA(real_t, jbk, C);  // main wave: column `lane` of Jbar^T = Lambda_c Y (wbd.cpp:116), kept for T1 in phase 3
     if (is_main) {
         LANES {
             const int col = lane < N ? lane : 0;
+            real_t yck[C];
 #pragma unroll
-            for (int p = 0; p < C; p++) LV(yck)[p] = Yt[col * C + p];
-            lds_rows_dot<C, C, C, 4, 0, S::c_Lam % 2 == 0>(Lam, LV(yck), LV(jbk));  // column `lane` of Jbar^T = Lambda_c Y
+            for (int p = 0; p < C; p++) yck[p] = Yt[col * C + p];
+            lds_rows_dot<C, C, C, 4, 0, S::c_Lam % 2 == 0>(Lam, yck, LV(jbk));
         }
-        DWBC_SYNC();  // every lane has read what it needs of Y
+        DWBC_SYNC();
     }
-    real_t *Dm = L + S::c_D;  // D = J_t A^-1 J_C^T, one row per task dof
+    real_t *Dm = L + S::c_D;   // D = J_t A^-1 J_C^T, one row per vector slot; row GV: Y G
+    real_t *BJ = L + S::c_BJ;  // (J_t A^-1) J_t^T of every level
     if (is_help) {
-        // D = (J_t A^-1) J_C^T from the rows that rode through the sweep, while J_C is still there (the main wave writes Jbar^T over it)
-        const int ft = su.fstar_total;
-        for (int idx = th.tid; idx < ft * C; idx += NT) {
+        for (int idx = th.tid; idx < NVS * C; idx += NT) {
             const int j = idx / C, p_ = idx - j * C;
             real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
             for (int c = 0; c < N; c++) a4[c & 3] += AJt[j * N + c] * JCt[c * C + p_];
             Dm[idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
-        for (int p_ = th.tid; p_ < C; p_ += NT) {  // yg = J_C A^-1 G = Y G (row 12 of the riding block is A^-1 G)
+        for (int idx = th.tid; idx < su.n_levels * T * T; idx += NT) {
+            const int lv = idx / (T * T), ij = idx - lv * T * T, i = ij / T, j = ij - i * T;
+            const real_t *Jtt = L + S::Jtt + lv * N * T;
             real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
-            for (int c = 0; c < N; c++) a4[c & 3] += AJt[12 * N + c] * JCt[c * C + p_];
-            Dm[12 * C + p_] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            for (int c = 0; c < N; c++) a4[c & 3] += AJt[(lv * T + i) * N + c] * Jtt[c * T + j];
+            BJ[idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
         DWBC_SYNC();
     }
-    DWBC_PAIR_BARRIER_X();  // ---- B1b: the helper is done with J_C
+    DWBC_PAIR_BARRIER_X();  // ---- B1b: the helper is done with J_t^T: Jbar^T takes its place
     if (is_main) {
         LANES {
 #pragma unroll
@@ -584,71 +682,172 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 if (lane < N) JbT[p * N + lane] = LV(jbk)[p];
         }
     }
-    DWBC_PAIR_BARRIER(2);  // ---- B2: Jbar^T in LDS
+    DWBC_PAIR_BARRIER(2);  // ---- B2: Jbar^T, Lambda_c, D, Y G, the task Gram blocks in LDS
 
-    // ================= phase 3 =================
-    if (is_main) {
-        // W = (A^-1 N_c)[6:, 6:]: rows 6.. of A^-1 N_c = A^-1 - Y^T Jbar^T (wbd.cpp:117-118).  Nothing reads the base rows of the
-        // register columns again (T1 comes from the vectors that rode through the sweep), so they are not updated.
-        LANES {
-            real_t dsub = real_t(0.0);
-#pragma unroll
-            for (int p = 0; p < C; p++) dsub += LV(yck)[p] * LV(jbk)[p];
-            LV(dg) -= dsub;
-            lds_rows_dot<M, C, C, 4, 1, true, 6>(Yt + 6 * C, LV(jbk), LV(s));  // s[i] -= Y^T[i, :] . Jbar^T[:, lane], i >= 6
+    // ================= phases 3 + 4: the main wave applies W^+ without forming it; the helper finishes NwJw and Lambda_task =================
+    // W = (A^-1 N_c)[6:, 6:] is the map joint torque -> joint acceleration of the contact-constrained robot, so W^+ a -- all this cycle
+    // ever asks of W^+, for a = the rows of T1r of each level (J_kt = W^+ T1r^T ..., wbd.cpp:207-213) and the gravity pre-vector
+    // (wbd.cpp:190), every one of them in range(W) -- is constrained INVERSE dynamics: with qdd = [qb; a],
+    //     J_C qdd = 0                        ->  qb  = -Hb (J_Cj a)                 (least squares, exact: the rows are consistent)
+    //     base rows of A qdd + J_C^T lam = 0 ->  lam = -Hb^T (A_bb qb + A_bj a)     (a particular solution)
+    //     tau_any = A_jb qb + A_jj a + J_Cj^T lam,    W^+ a = (I - P) tau_any       (P = VG Vb^T: the projector on null(W), internal wrenches)
+    // -- products with A, J_C and 6 x 6 blocks instead of the 33-pivot sweep of W + alpha P, its assembly (the rank-12 update A^-1 N_c, the
+    // projector column) and the staging of what rode through it: 21 k + 12 k cycles of round 4's first version of this kernel.
+    // W^+ applied to the NVS vectors stored transposed in AT (M x VS): out[v] = (W^+ a_v)[lane] for lane < M.  One wave; called by the main
+    // wave in phase 4 and again by the slow route of phase 5 (on the rows of Q).
+    auto wplus = [&](auto &tvo) {
+        real_t *AT = L + S::at;
+        real_t *Bv = L + S::p4_b, *Qb = L + S::p4_qb, *Cv = L + S::p4_cv, *Lm = L + S::p4_lam, *Wv = L + S::p4_w, *TS = L + S::p4_ts;
+        const real_t zero = real_t(0.0);
+        auto apk = [&](int r, int c) { const int hi = r >= c ? r : c, lo = r >= c ? c : r; return Ap[hi * (hi + 1) / 2 + lo]; };  // packed symmetric A
+        auto vec = [&](const real_t *X, int row, int v) { const real_t v_ = X[row * VS + (v < VS ? v : 0)]; return v < VS ? v_ : zero; };
+        constexpr int MT3 = (M + 15) / 16;
+        if (nc > 0) {
+            wave_gemm<1, (M + 3) / 4, false>(  // b = J_Cj a
+                [&](int p, int j) { const real_t v_ = JCt[(6 + (j < M ? j : 0)) * C + (p < C ? p : 0)]; return (p < cd && j < M) ? v_ : zero; },
+                [&](int j, int v) { const real_t v_ = vec(AT, j < M ? j : 0, v); return j < M ? v_ : zero; },
+                [&](int p, int v, real_t d) { if (p < C && v < VS) Bv[p * VS + v] = d; });
+            DWBC_SYNC();
+            static_assert(C % 4 == 0, "whole reduction blocks");
+            wave_gemm<1, C / 4, false>(  // qb = -Hb b
+                [&](int x, int p) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + p]; return x < 6 ? -v_ : zero; },
+                [&](int p, int v) { return vec(Bv, p, v); },
+                [&](int x, int v, real_t d) { if (x < 6 && v < VS) Qb[x * VS + v] = d; });
+            DWBC_SYNC();
+        }
+        DWBC_PSTAMP_M(46);  // W^+: b, qb
+        wave_gemm<1, (N + 3) / 4, false>(  // cv = A_bb qb + A_bj a   (no contact: cv = A_bj a, qb follows from it)
+            [&](int x, int kk) { const real_t v_ = apk(x < 6 ? x : 0, kk < N ? kk : 0); return (x < 6 && kk < N) ? v_ : zero; },
+            [&](int kk, int v) {
+                const real_t v_ = vec(kk < 6 ? Qb : AT, kk < 6 ? kk : (kk < N ? kk - 6 : 0), v);
+                return ((kk < 6 && nc > 0) || (kk >= 6 && kk < N)) ? v_ : zero;
+            },
+            [&](int x, int v, real_t d) { if (x < 6 && v < VS) Cv[x * VS + v] = d; });
+        DWBC_SYNC();
+        if (nc > 0) {
+            wave_gemm<1, 2, false>(  // lam = -Hb^T cv
+                [&](int p, int x) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + (p < C ? p : 0)]; return (p < C && x < 6) ? -v_ : zero; },
+                [&](int x, int v) { const real_t v_ = vec(Cv, x < 6 ? x : 0, v); return x < 6 ? v_ : zero; },
+                [&](int p, int v, real_t d) { if (p < C && v < VS) Lm[p * VS + v] = d; });
+        } else {
+            wave_gemm<1, 2, false>(  // qb = -A_bb^-1 cv
+                [&](int x, int y) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + (y < 6 ? y : 0)]; return (x < 6 && y < 6) ? -v_ : zero; },
+                [&](int y, int v) { const real_t v_ = vec(Cv, y < 6 ? y : 0, v); return y < 6 ? v_ : zero; },
+                [&](int x, int v, real_t d) { if (x < 6 && v < VS) Qb[x * VS + v] = d; });
         }
         DWBC_SYNC();
-        DWBC_PSTAMP_M(45);  // A^-1 N_c update done
+        DWBC_PSTAMP_M(47);  // W^+: cv, lam
+        // tau_any = [A_jb | A_jj | J_Cj^T] [qb; a; lam], stored transposed over its own operands (TS: M x VS)
+        wave_gemm<MT3, (N + C + 3) / 4, true>(
+            [&](int i, int kk) {
+                const int ii = i < M ? i : 0, p = kk - N;
+                const real_t va = apk(6 + ii, kk < N ? kk : 0), vj = JCt[(6 + ii) * C + ((p >= 0 && p < C) ? p : 0)];
+                return i < M ? (kk < N ? va : ((p < cd) ? vj : zero)) : zero;
+            },
+            [&](int kk, int v) {
+                const int p = kk - N;
+                const real_t *X = kk < 6 ? Qb : (kk < N ? AT : Lm);
+                const int row = kk < 6 ? kk : (kk < N ? kk - 6 : ((p < C) ? p : 0));
+                const real_t v_ = vec(X, row, v);
+                return (kk < N || (p < cd)) ? v_ : zero;
+            },
+            [&](int i, int v, real_t d) { if (i < M && v < VS) TS[i * VS + v] = d; });
         DWBC_SYNC();
-    }
-    if (is_help) {
-        // P_C = Jbar^T G = Lambda_c (Y G) (wbd.cpp:119) and the gravity pre-vector A^-1 N_c G = A^-1 G - Y^T P_C (wbd.cpp:190), from
-        // the vector that rode through the A^-1 sweep
+        DWBC_PSTAMP_M(48);  // W^+: tau_any
+        if (k > 0) {  // W^+ a = (I - P) tau_any,  P tau = VG (Vb^T tau)
+            wave_gemm<1, (M + 3) / 4, false>(
+                [&](int a, int i) { const real_t v_ = Vb[(i < M ? i : 0) * 6 + (a < 6 ? a : 0)]; return (a < 6 && i < M) ? v_ : zero; },
+                [&](int i, int v) { const real_t v_ = vec(TS, i < M ? i : 0, v); return i < M ? v_ : zero; },
+                [&](int a, int v, real_t d) { if (a < 6 && v < VS) Wv[a * VS + v] = d; });
+            DWBC_SYNC();
+        }
+        LANES {
+            const int i = lane < M ? lane : 0;
+#pragma unroll
+            for (int v = 0; v < VS; v++) LV(tvo)[v] = TS[i * VS + v];
+            if (k > 0) {
+                real_t ga[6];
+#pragma unroll
+                for (int a = 0; a < 6; a++) ga[a] = -VG[i * 6 + a];
+                lds_rows_axpy<6, VS, VS, 3, S::p4_w % 2 == 0>(Wv, ga, LV(tvo));
+            }
+        }
+    };
+    PLA(real_t, tv, VS);  // main wave, lane i < M: (W^+ a_v)[i] for every vector slot v: column i of J_kt of every level, torque_grav_[i]
+    if (is_main) {
+        // ---- P_C = Lambda_c (Y G) (wbd.cpp:119), the gravity pre-vector (A^-1 N_c G)[6:] = (A^-1 G - Y^T P_C)[6:], and the joint
+        //      columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level: the vectors a_v, stored transposed AT[j][v]
+        real_t *AT = L + S::at;
         for (int p_ = th.tid; p_ < C; p_ += NT) {
             real_t acc = real_t(0.0);
 #pragma unroll
-            for (int q_ = 0; q_ < C; q_++) acc += (p_ < cd && q_ < cd) ? Lam[p_ * C + q_] * Dm[12 * C + q_] : real_t(0.0);
+            for (int q_ = 0; q_ < C; q_++) acc += (p_ < cd && q_ < cd) ? Lam[p_ * C + q_] * Dm[GV * C + q_] : real_t(0.0);
             L[S::PC + p_] = acc;
         }
+        // the vectors a_v = (J_t A^-1 - D Jbar^T)[v][6:], and with row GV of D = Y G: (A^-1 G - Jbar (Y G))[6:] -- the same thing as
+        // A^-1 G - Y^T P_C (Lambda_c is symmetric); one product on the matrix cores, the riding block read as its starting value
+        wave_gemm<(M + 15) / 16, C / 4, true>(
+            [&](int j, int p) { const real_t v_ = JbT[p * N + 6 + (j < M ? j : 0)]; return j < M ? -v_ : real_t(0.0); },
+            [&](int p, int v) { const real_t v_ = Dm[(v < NVS ? v : 0) * C + p]; return v < NVS ? v_ : real_t(0.0); },
+            [&](int j, int v, real_t d) {
+                if (j < M && v < NVS) {
+                    AT[j * VS + v] = d;                                                        // (empty slots are zero vectors: J_t A^-1 and D are zero there)
+                    if (v < GV) L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d;    // T1x: the chain and the slow route of phase 5 read it
+                }
+            },
+            [&](int j, int v) { const real_t v_ = AJt[(v < NVS ? v : 0) * N + 6 + (j < M ? j : 0)]; return (j < M && v < NVS) ? v_ : real_t(0.0); });
         DWBC_SYNC();
-        for (int i = th.tid; i < N; i += NT) {
-            real_t yr[C], pv[C];
-#pragma unroll
-            for (int p = 0; p < C; p++) { yr[p] = Yt[i * C + p]; pv[p] = L[S::PC + p]; }
-            real_t acc = AJt[12 * N + i];
-#pragma unroll
-            for (int p = 0; p < C; p++) acc -= yr[p] * pv[p];
-            L[S::c_vec + i] = acc;
-        }
-        // T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level (D = J_t A^-1 J_C^T, phase 2): column `lane` per lane -- its column of
-        // Jbar^T in registers, the rows of D by broadcast reads in hand-made batches.  (On this wave: next to the 39-row register column of
-        // the main wave the same block pushes the allocator over the register cap.)
+        DWBC_PSTAMP_M(45);  // vectors ready
+        wplus(tv);
+        DWBC_PSTAMP_M(49);  // W^+: projected
         LANES {
-            const int cl = lane < N ? lane : 0;
-            real_t jb[C];
-#pragma unroll
-            for (int p = 0; p < C; p++) jb[p] = JbT[p * N + cl];
-            // (a rolled loop over the task dofs: unrolled, its twelve load / store groups next to the main wave's register columns --
-            // live across this block for the allocator -- spill all over the kernel)
-#pragma unroll 1
-            for (int j = 0; j < su.fstar_total; j++) {
-                int lvl = 0;
-#pragma unroll
-                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && j >= su.fstar_off[q_]) ? q_ : lvl;
-                const int r = j - su.fstar_off[lvl];
-                real_t d1[1];
-                lds_rows_dot<1, C, C, 1, 0, S::c_D % 2 == 0>(Dm + j * C, jb, d1);
-                const real_t v_ = AJt[j * N + cl] - d1[0];
-                if (lane < 6) L[S::c_T1 + lvl * T * 6 + r * 6 + lane] = v_;
-                else if (lane < N) L[S::T1x + lvl * T * S::MS + r * S::MS + (lane - 6)] = v_;
-            }
+            if (lane < M) L[S::tg + lane] = LV(tv)[GV];  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         }
         DWBC_SYNC();
+    }
+    if (is_help) {
+        // Lambda_task of every level from the Gram blocks: J_t A^-1 N_c J_t^T = (J_t A^-1) J_t^T - D Lambda_c D^T (wbd.cpp:210), and the
+        // condition verdict (dwbc_cycle2.h, task-Jacobian stage)
+        int fm = 0;
+        for (int lv = 0; lv < su.n_levels; lv++) {
+            const int t = su.t_dof[lv];
+            real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs, *DL = L + S::c_s1;  // (c_s1: the main wave's sweep column, idle since phase 2; T x C fits its 72 doubles)
+            static_assert(T * C <= S::c_s2 - S::c_s1, "D Lambda_c borrows the sweep column");
+            const real_t *Dl = Dm + lv * T * C;
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < t * C; idx += NT) {  // DL = D Lambda_c  (t x C)
+                const int i = idx / C, p = idx - i * C;
+                real_t acc = real_t(0.0);
+#pragma unroll
+                for (int q_ = 0; q_ < C; q_++) acc += Dl[i * C + q_] * Lam[q_ * C + p];
+                DL[idx] = acc;
+            }
+            DWBC_SYNC();
+            for (int idx = th.tid; idx < t * t; idx += NT) {
+                const int i = idx / t, j = idx - i * t;
+                real_t acc = BJ[lv * T * T + i * T + j];
+#pragma unroll
+                for (int p = 0; p < C; p++) acc -= DL[i * C + p] * Dl[j * C + p];
+                Li[idx] = acc;
+            }
+            DWBC_SYNC();
+            const int ok_lt = spd_inverse_small(Li, t, t, Lt, t, L + S::hs + 144);
+            real_t da = real_t(0.0), dl = real_t(0.0);
+            for (int i = 0; i < t; i++) {
+                const real_t a_ = Li[i * t + i], l_ = Lt[i * t + i];
+                da = a_ > da ? a_ : da;
+                dl = l_ > dl ? l_ : dl;
+            }
+            if (ok_lt && nc > 0 && da * dl < kCodCondFast) fm |= 1 << lv;
+        }
+        DWBC_SYNC();
+        if (th.tid == 0) flg[1] = (real_t)fm;
     }
     if (is_help && k > 0) {
         // NwJw = VG X^T with X = (JV G^-1 JV^T)^-1 JV, JV = Jbar[0:k, 6:] Vb (dwbc_cycle2.h: SPD inverses only)
         constexpr int K6 = 6;
         real_t *JV = L + S::hs, *Gi = L + S::hs + 36, *Bm = L + S::hs + 72, *Sm6 = L + S::hs + 108;
+        DWBC_SYNC();
         for (int idx = th.tid; idx < K6 * K6; idx += NT) {
             const int i = idx / 6, j = idx - i * 6;
             real_t acc = real_t(0.0);
@@ -667,134 +866,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
         DWBC_SYNC();
     }
-    // (barrier B3 -- T1 of every level, the gravity pre-vector and NwJw in LDS -- comes after the main wave has assembled W + alpha P,
-    // which needs none of them: the helper's phase-3 chain is the longer one)
-
-    // ================= phase 4 =================
-    // W = (A^-1 N_c)[6:, 6:] stays where it is: column c of W is rows 6.. of lane 6 + c's column, so `w` is a view of `s` and the
-    // W^+ sweep runs on lanes WL .. WL + M - 1 (moving the columns down to lane c cost 66 ds_bpermute per cycle).
-    constexpr int WL = 6;      // lane of column 0 of W
-    constexpr int RL = WL + M; // first lane that carries a right-hand side through the sweep
-    PLA(real_t, w, M);  // main wave: column `lane - WL` of W -> W^+
-    PL(real_t, dw);
-    real_t alpha = real_t(0.0), ialpha = real_t(0.0);
-    PLA(real_t, pc, M);  // main wave: column `lane - WL` of the projector P = VG Vb^T, kept across the sweep for the correction
-    if (is_main) {
-        PL(real_t, dsum);
-        LANES {
-            const bool in = lane >= WL && lane < RL;
-#pragma unroll
-            for (int i = 0; i < M; i++) LV(w)[i] = LV(s)[6 + i];
-            LV(dw) = LV(dg);
-            LV(dsum) = in ? LV(dg) : real_t(0.0);
-        }
-        WAVE_SUM(dsum, alpha);
-        alpha /= M;
-        ialpha = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
-        PLA(real_t, vbr, 6);
-        LANES {
-            const bool in = lane >= WL && lane < RL;
-            const int wl = in ? lane - WL : 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                const real_t v_ = Vb[wl * 6 + a];
-                LV(vbr)[a] = (k > 0 && in) ? v_ : real_t(0.0);
-            }
-#pragma unroll
-            for (int i = 0; i < M; i++) LV(pc)[i] = real_t(0.0);
-            if (k > 0) {
-                DWBC_LANE_OPAQUE(lw);
-                real_t dp = real_t(0.0);
-                lds_rows_dot<M, 6, 6, 6, 0>(VG, LV(vbr), LV(pc));  // column `lane - WL` of P = VG Vb^T
-#pragma unroll
-                for (int i = 0; i < M; i++) {
-                    const real_t pij = LV(pc)[i];
-                    LV(w)[i] += alpha * pij;
-                    dp = (i == lw - WL) ? pij : dp;
-                }
-                LV(dw) += alpha * dp;
-            }
-        }
-    }
-    DWBC_PAIR_BARRIER(3);  // ---- B3: T1 of every level, the gravity pre-vector, NwJw in LDS
-    if (is_main) {
-        LANES {
-            const bool in = lane >= WL && lane < RL;
-            if (!in) {
-                // The sweep uses M of the 64 lanes.  Every vector W^+ is ever applied to exists by now -- the rows of T1r of each level
-                // (J_kt = W^+ T1r^T Lambda-side, wbd.cpp:207-213) and the gravity pre-vector (wbd.cpp:190) -- so they ride through the
-                // same 33 pivots as extra columns in idle lanes: a Gauss-Jordan sweep of [S | X] leaves S^-1 X in the extra columns
-                // (same FMAs as a non-pivot matrix lane, no extra instruction).  Both kinds of vector are orthogonal to null(W)
-                // (A^-1 N_c [0; n] = 0 for n in null(W)), so (W + alpha P)^-1 x = W^+ x and the projector correction does not apply.
-                const int jj = lane >= RL ? lane - RL : 63;
-                int lvl = 0;
-#pragma unroll
-                for (int q_ = 1; q_ < NLV; q_++) lvl = (q_ < su.n_levels && jj >= su.fstar_off[q_]) ? q_ : lvl;
-                const bool isrow = jj < su.fstar_total, isg = jj == NLV * T;
-                const real_t *srcp = isg ? L + S::c_vec + 6 : L + S::T1x + lvl * T * S::MS + (isrow ? jj - su.fstar_off[lvl] : 0) * S::MS;
-#pragma unroll
-                for (int i = 0; i < M; i++) {
-                    const real_t v_ = srcp[i];
-                    LV(w)[i] = (isrow || isg) ? v_ : real_t(0.0);
-                }
-                LV(dw) = real_t(1.0);
-            }
-        }
-        DWBC_PSTAMP_M(48);  // W + alpha P assembled, right-hand sides loaded
-        DWBC_SYNC();
-        if (!sweep_inverse_lds<M, WL>(w, dw, L + S::c_s1)) st_contact = 0;
-        DWBC_SYNC();
-        DWBC_PSTAMP_M(49);  // W^+ sweep done
-        LANES {
-            if (k > 0) {
-#pragma unroll
-                for (int i = 0; i < M; i++) LV(w)[i] -= ialpha * LV(pc)[i];  // (pc = 0 outside the matrix lanes)
-            }
-            // the swept right-hand sides (negated by the sweep's epilogue like the matrix): column j of [J_kt-side vectors] -> row j of
-            // the staging block; the gravity lane writes torque_grav_ = W^+ (A^-1 N_c G)[6:] (wbd.cpp:190) itself
-            if (lane >= RL) {
-                const int jj = lane - RL;
-                const bool isrow = jj < su.fstar_total, isg = jj == NLV * T;
-                real_t *dst = isg ? L + S::tg : L + S::jk + (isrow ? jj : 0) * S::MS;
-                if (isrow || isg) {
-#pragma unroll
-                    for (int i = 0; i < M; i++) dst[i] = -LV(w)[i];
-                }
-            }
-        }
-        DWBC_SYNC();
-    }
-    if (is_help) {
-        // J_t A^-1 N_c J_t^T, Lambda_task (wbd.cpp:210) and the condition verdict of every level (dwbc_cycle2.h, task-Jacobian stage)
-        int fm = 0;
-        for (int lv = 0; lv < su.n_levels; lv++) {
-            const int t = su.t_dof[lv];
-            const real_t *Jtt = L + S::Jtt + lv * N * T;
-            const real_t *T1 = L + S::c_T1 + lv * T * 6, *T1x = L + S::T1x + lv * T * S::MS;
-            real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs;
-            const unsigned long long tm = su.t_dofmask[lv];
-            DWBC_SYNC();
-            for (int idx = th.tid; idx < t * t; idx += NT) {
-                const int i = idx / t, j = idx - i * t;
-                real_t acc = real_t(0.0);
-#pragma unroll
-                for (int c = 0; c < N; c++)
-                    if ((tm >> c) & 1) acc += (c < 6 ? T1[i * 6 + c] : T1x[i * S::MS + (c < 6 ? 0 : c - 6)]) * Jtt[c * T + j];
-                Li[idx] = acc;
-            }
-            const int ok_lt = spd_inverse_small(Li, t, t, Lt, t, L + S::hs + 144);
-            real_t da = real_t(0.0), dl = real_t(0.0);
-            for (int i = 0; i < t; i++) {
-                const real_t a_ = Li[i * t + i], l_ = Lt[i * t + i];
-                da = a_ > da ? a_ : da;
-                dl = l_ > dl ? l_ : dl;
-            }
-            if (ok_lt && nc > 0 && da * dl < kCodCondFast) fm |= 1 << lv;
-        }
-        DWBC_SYNC();
-        if (th.tid == 0) flg[1] = (real_t)fm;
-    }
-    DWBC_PAIR_BARRIER(4);  // ---- B4: W^+ in the main wave's registers; Lambda_task, the fast-route mask in LDS
+    DWBC_PAIR_BARRIER(4);  // ---- B4: J_kt-side vectors in the main wave's registers; Lambda_task, the fast-route mask, NwJw in LDS
     if (!is_main) return;
 
     // ================= phase 5 (main): stage 3a, wrench maps, QP cascade in registers, outputs =================
@@ -820,18 +892,20 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         const real_t *Lt = L + S::c_Lt + lv * T * T;
         const real_t *T1rl = L + S::T1x + lv * T * S::MS;
         real_t *Q = L + S::c_QW, *QW = L + S::c_QWp, *Pi = L + S::c_Pi;
-        real_t *Ul = L + S::U + lv * M * T;
         int cond = 1;
         DWBC_SYNC();
         const bool fast = (fastmask >> lv) & 1;
         PLA(real_t, xr, TTL);  // row `lane` of X = J_kt Lambda of this level
         if (fast) {
-            // J_kt = (T1r W^+)^T came out of the sweep (staging block jk, row per task dof): X = J_kt Lambda, row `lane` per lane
-            const real_t *JKl = L + S::jk + su.fstar_off[lv] * S::MS;
+            // J_kt = W^+ T1r^T is in this lane's registers (vector slots lv * T + r): X = J_kt Lambda, row `lane` per lane
             LANES {
                 real_t tw[TTL];
 #pragma unroll
-                for (int r = 0; r < TTL; r++) tw[r] = JKl[r * S::MS + (lane < M ? lane : 0)];
+                for (int r = 0; r < TTL; r++) {
+                    real_t v_ = LV(tv)[r];
+                    if constexpr (NLV > 1) v_ = lv == 1 ? LV(tv)[T + r] : v_;
+                    tw[r] = v_;
+                }
 #pragma unroll
                 for (int r3 = 0; r3 < TTL; r3++) {
                     real_t acc = real_t(0.0);
@@ -849,13 +923,28 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 Q[idx] = acc;
             }
             DWBC_SYNC();
-            for (int r = 0; r < TTL; r++) {
+            // Q W^+ = (W^+ Q^T)^T: the rows of Q (in range(W) like T1r) through the same inverse-dynamics form, as vector slots 0 .. t-1
+            {
+                real_t *AT = L + S::at;
+                for (int idx = th.tid; idx < M * VS; idx += NT) {
+                    const int j = idx / VS, v = idx - j * VS;
+                    AT[idx] = v < t ? Q[v * M + j] : real_t(0.0);
+                }
+                DWBC_SYNC();
+                PLA(real_t, tq, VS);
+                wplus(tq);  // (its scratch runs over Q: Q is formed again below)
+                DWBC_SYNC();
                 LANES {
-                    real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
+                    if (lane < M) {
 #pragma unroll
-                    for (int i = 0; i < M; i++) a4[i & 3] += Q[r * M + i] * LV(w)[i];
-                    const real_t acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-                    if (lane >= WL && lane < RL) QW[r * M + lane - WL] = acc;  // (column lane - WL of W^+ lives in this lane)
+                        for (int r = 0; r < TTL; r++) QW[r * M + lane] = LV(tq)[r];
+                    }
+                }
+                for (int idx = th.tid; idx < t * M; idx += NT) {
+                    const int i = idx / M, j = idx - i * M;
+                    real_t acc = real_t(0.0);
+                    for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * S::MS + j];
+                    Q[idx] = acc;
                 }
             }
             DWBC_SYNC();
@@ -888,6 +977,32 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             }
         }
         DWBC_PSTAMP(16 + 2 * lv);  // rows of J_kt / X of level lv in registers
+        LANES {
+#pragma unroll
+            for (int r = 0; r < TTL; r++) {
+                const real_t v_ = lane < M ? LV(xr)[r] : real_t(0.0);
+                LV(gd0)[r] = lv == 0 ? v_ : LV(gd0)[r];
+                if constexpr (NLV > 1) LV(gd1)[r] = lv == 1 ? v_ : LV(gd1)[r];
+            }
+        }
+        if (!cond) rankbad |= (1 << lv);
+            };
+        if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
+    }
+    // second pass, once nothing reads the staged mass matrix any more (U shares its place): U_0 = X_0; U_1 = (I - X_0 Y_0) X_1
+    for (int lv = 0; lv < su.n_levels; lv++) {
+        auto chain_body = [&](auto ttl) {
+        constexpr int TTL = decltype(ttl)::value;
+        real_t *Ul = L + S::U + lv * M * T;
+        PLA(real_t, xr, TTL);
+        LANES {
+#pragma unroll
+            for (int r = 0; r < TTL; r++) {
+                real_t v_ = LV(gd0)[r];
+                if constexpr (NLV > 1) v_ = lv == 1 ? LV(gd1)[r] : v_;
+                LV(xr)[r] = v_;
+            }
+        }
         if (lv > 0) {
             // U_lv = (I - X_0 Y_0) X_lv, Y_0 = T1x[0] (wbd.cpp:228-261): Z = Y_0 X_lv is the one cross-lane reduction of the chain
             const int tp = su.t_dof[0];
@@ -929,10 +1044,9 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 if (lane < M) Ul[lane * T + r] = LV(xr)[r];  // (the wrench maps read U_l from LDS)
             }
         }
-        if (!cond) rankbad |= (1 << lv);
         DWBC_PSTAMP(17 + 2 * lv);  // null-space chain of level lv done
             };
-        if (su.t_dof[lv] <= 3) level_body(std::integral_constant<int, 3>{}); else level_body(std::integral_constant<int, T>{});
+        if (su.t_dof[lv] <= 3) chain_body(std::integral_constant<int, 3>{}); else chain_body(std::integral_constant<int, T>{});
     }
     DWBC_SYNC();
     DWBC_STAMP(5);  // stage 3a done
@@ -995,13 +1109,13 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         LV(Tl) = tqr ? LV(qc.taul) : real_t(0.0);
         LV(sfin) = real_t(0.0);
     }
-    // The rows leave the registers again: 18 doubles per lane [gd_0 | gd_1 | gcn] in an LDS block of their own (over Jbar^T, NwJw, U and
-    // T1x, all dead now that the wrench maps and the rows exist), read back in 16-byte pieces where a QP or an output needs them --
+    // The rows leave the registers again: 18 doubles per lane [gd_0 | gd_1 | gcn] in an LDS block of their own (over J_C, NwJw and U,
+    // all dead now that the wrench maps and the rows exist), read back in 16-byte pieces where a QP or an output needs them --
     // kept in registers across the three solves they pushed the solver over the 256-register cap (56 spilled registers, reloaded
     // behind serial waits inside the cascade).
     constexpr int RSW = 18;
-    static_assert(64 * RSW <= S::c_T1 - S::JbT && S::JbT % 2 == 0, "row block over the dead Jbar^T .. T1x region");
-    real_t *rowblk = L + S::JbT;
+    static_assert(64 * RSW <= S::UAend - S::c_JC && S::c_JC % 2 == 0, "row block over the dead J_C, NwJw, U region");
+    real_t *rowblk = L + S::c_JC;
     DWBC_SYNC();
     LANES {
         real_t *rw = rowblk + lane * RSW;
