@@ -571,6 +571,141 @@ __device__ __forceinline__ void lds_pivot_tree(double (&s)[NN], double &dg2, int
     if constexpr (K > 0) lds_pivot_tree<Topo, NN, K - 1, CHP>(s, dg2, ok, cb, lane);
 }
 #endif
+// f(std::integral_constant<int, I>) for I = I0 .. I1 - 1: a loop whose index is a constant expression inside the body
+template <int I0, int I1, class F>
+DWBC_WDEV void static_for(F &&f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+// ---- several pivots per step.  Two dofs that are not relatives (different branches of the tree) do not see each other's pivot:
+// the sweep of k touches the entries (i, j) with i, j both relatives of k, and neither column k' nor its diagonal is among them
+// when k' is not -- fill between two branches arises only when a COMMON ancestor is swept, and ancestors come last.  So the pivots
+// of up to W branches are taken in one step: their columns are published and read back together, their multipliers formed
+// together, and one LDS round trip and one reciprocal chain are paid per step instead of per pivot -- TOCABI's 39 pivots take 17
+// steps of up to four (legs, arms and head side by side; the waist and the base one by one).  Any order that sweeps a dof after
+// all of its descendants gives the same inverse (rounding aside); the schedule below takes, per step, the highest-numbered ready
+// dofs that are pairwise unrelated.
+template <int NN, int W>
+struct TreeSchedule {
+    int nsteps;
+    int cnt[NN];
+    int piv[NN][W];
+};
+template <class Topo, int NN, int W>
+constexpr TreeSchedule<NN, W> make_tree_schedule() {
+    TreeSchedule<NN, W> sch{};
+    bool done[NN] = {};
+    int left = NN, st = 0;
+    while (left > 0) {
+        int c = 0;
+        for (int k = NN - 1; k >= 0 && c < W; k--) {
+            if (done[k]) continue;
+            const unsigned long long rel = Topo::relatives(k);
+            bool ready = true;
+            for (int j = k + 1; j < NN; j++)
+                if (((rel >> j) & 1ull) && !done[j]) ready = false;
+            for (int q = 0; q < c; q++)
+                if ((rel >> sch.piv[st][q]) & 1ull) ready = false;
+            if (ready) sch.piv[st][c++] = k;
+        }
+        for (int q = 0; q < c; q++) done[sch.piv[st][q]] = true;
+        left -= c;
+        sch.cnt[st] = c;
+        st++;
+    }
+    sch.nsteps = st;
+    return sch;
+}
+template <class Topo, int NN, int W>
+struct TreeScheduleOf {
+    static constexpr TreeSchedule<NN, W> value = make_tree_schedule<Topo, NN, W>();
+};
+#if !defined(DWBC_HOST_EMU)
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(unsigned addr, double v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <class Topo, int NN, int W, int STEP>
+__device__ __forceinline__ void lds_step_tree(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
+    using Sch = TreeScheduleOf<Topo, NN, W>;
+    constexpr int cnt = Sch::value.cnt[STEP];
+    constexpr int NP = (NN + 1) / 2, CS = 2 * NP;  // column stride in LDS: the rows of the matrix only (lanes beyond carry right-hand sides)
+    dwbc_d2v col[W][NP];
+    double cj[W], h[W];
+    const unsigned slot = cb + 8u * (unsigned)(lane < CS - 1 ? lane : CS - 1);  // (row CS - 1 is padding when NN is odd; lanes beyond write there)
+    static_assert(NN % 2 == 1 || W == 1, "an even NN has no padding row for the lanes beyond the matrix");
+    static_for<0, cnt>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
+        lds_write_b64<8 * q * CS>(slot, s[K]);
+    });
+    static_for<0, cnt>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
+        lds_rel_issue<Topo, K, 0, NP, NP>(col[q], cb + (unsigned)(8 * q * CS));
+    });
+    static_for<0, cnt>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
+        double d = readlane_f64(dg2, K) + 2.0;
+        int pos = d > 0.0 ? 1 : 0;
+        DWBC_FLAG_VGPR(pos);
+        ok &= pos;
+        if (!(d > 0.0)) d = 1.0;
+        const double rp = fast_rcp(d);
+        cj[q] = s[K];
+        h[q] = cj[q] * rp;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, cnt>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
+        lds_rel_pin<Topo, K, 0, NP, NP>(col[q]);
+    });
+    static_for<0, cnt>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
+        constexpr unsigned long long rel = Topo::relatives(K);
+#pragma unroll
+        for (int i = 0; i < NN; i++)
+            if ((rel >> i) & 1ull) s[i] -= col[q][i / 2][i & 1] * h[q];
+        dg2 -= cj[q] * h[q];
+    });
+    if constexpr (STEP + 1 < Sch::value.nsteps) lds_step_tree<Topo, NN, W, STEP + 1>(s, dg2, ok, cb, lane);
+}
+#endif
+// colbuf: W * 2 * ((NN + 1) / 2) doubles
+template <class Topo, int NN, int W>
+DWBC_WDEV int sweep_inverse_tree_lds_multi(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
+#if defined(DWBC_HOST_EMU)
+    (void)colbuf;
+    return sweep_inverse_tree<Topo, NN>(s, dg);
+#else
+    if constexpr (sizeof(real_t) != 8) {
+        return sweep_inverse_tree<Topo, NN>(s, dg);
+    } else {
+        static_assert(NN == Topo::ndof, "topology / kernel size mismatch");
+        const int lane = (int)(threadIdx.x & 63u);
+        int ok = 1;
+        {
+            DWBC_LANE_OPAQUE(lp);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == lp) ? dg - 1.0 : s[i];
+        }
+        double dg2 = dg - 2.0;
+        lds_step_tree<Topo, NN, W, 0>(s, dg2, ok, (unsigned)(size_t)colbuf, lane);
+        ok = DWBC_FLAG_UNIFORM(ok);
+        {
+            DWBC_LANE_OPAQUE(le);
+#pragma unroll
+            for (int i = 0; i < NN; i++) s[i] = (i == le) ? -dg2 : -s[i];
+            dg = -dg2;
+        }
+#pragma unroll
+        for (int i = 0; i < NN; i++) asm volatile("" : "+v"(s[i]));  // (see sweep_inverse_tree_lds)
+        return ok;
+    }
+#endif
+}
+
 template <class Topo, int NN, int CHP = (NN + 1) / 2>
 DWBC_WDEV int sweep_inverse_tree_lds(PLA_REF(real_t, s, NN), PL_REF(real_t, dg), real_t *colbuf) {
 #if defined(DWBC_HOST_EMU)

@@ -176,54 +176,87 @@ struct Lds4 {
 #define DWBC_PSTAMP_M(i) ((void)0)
 #endif
 
-// D = A B for the small dense products of phases 3 - 4 on the matrix cores: MT row tiles of 16, 16 columns, KB reduction blocks of 4
-// (v_mfma_f64_16x16x4_f64; operand layout as in wrench_maps, dwbc_cycle2.h: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
-// D[i = (l >> 4) + 4 r][j = l & 15]).  fa(i, k) / fb(k, j) return the operand entries (zero outside the matrices: each is one LDS
-// read from a clamped address and a select), fstore(i, j, v) takes every entry of the result tiles.  SYNC_STORE: a wave-level
-// fence between the last read and the first store, for results written over their own operands; fc(i, j): the value the
-// accumulation starts from.  One wave.  The host emulation
-// (and nothing else) takes the plain triple loop.
-template <int MT, int KB, bool SYNC_STORE, class FA, class FB, class FS, class FC>
+// D = C0 + A B for the small dense products of phases 3 - 4 on the matrix cores: A is MR x KV, B is KV x NCV (NCV <= 16), tiles of 16
+// rows, reduction blocks of 4 (v_mfma_f64_16x16x4_f64; operand layout as in wrench_maps, dwbc_cycle2.h: A[i = l & 15][k = l >> 4],
+// B[k = l >> 4][j = l & 15], D[i = (l >> 4) + 4 r][j = l & 15]).
+//   fa(tc, sc, i, k) / fb(sc, k, j): the operand entries, called with indices INSIDE the matrices (the padding of the last tile / block
+//     is clamped and masked here, and only in the tile / block that has any): tc, sc are std::integral_constant tile and block numbers,
+//     i = 16 tc + (l & 15), k = 4 sc + (l >> 4) wherever the tile / block is whole -- so an accessor written as base[lane part] +
+//     constant gets its constant folded into the instruction's offset field, and one that needs index arithmetic (the packed
+//     symmetric mass matrix) can choose its form per block at compile time;
+//   fc(i, j): the value the accumulation starts from;  fstore(i, j, v): takes every entry of the result (i < MR, j < NCV).
+// Every operand is loaded before the first MFMA is issued (one LDS round trip per product, not one per block -- the dependent
+// load -> wait -> MFMA steps of a lone wave cost ~500 cycles per block).  SYNC_STORE: a wave-level fence between the last read and
+// the first store, for results written over their own operands.  One wave.  The host emulation (and nothing else) takes plain loops.
+template <int MR, int NCV, int KV, bool SYNC_STORE, class FA, class FB, class FS, class FC>
 DWBC_WDEV void wave_gemm(FA fa, FB fb, FS fstore, FC fc) {
+    constexpr int MT = (MR + 15) / 16, KB = (KV + 3) / 4;
+    static_assert(NCV <= 16, "one column tile");
 #if !defined(DWBC_HOST_EMU)
     static_assert(sizeof(real_t) == 8, "fp64 build");
     typedef double g_d4 __attribute__((ext_vector_type(4)));
     const int lane = (int)(threadIdx.x & 63u), li = lane & 15, lk = lane >> 4;
+    const int jc = (NCV < 16 && li >= NCV) ? NCV - 1 : li;  // (columns beyond NCV repeat the last one: computed, not stored)
+    double av[MT][KB], bv[KB];
+    static_for<0, KB>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        constexpr bool kwhole = 4 * s_ + 3 < KV;
+        const int kk = kwhole ? 4 * s_ + lk : (4 * s_ + lk < KV ? 4 * s_ + lk : KV - 1);
+        const bool kin = kwhole || 4 * s_ + lk < KV;
+        const double b_ = fb(sc, kk, jc);
+        bv[s_] = kin ? b_ : 0.0;
+        static_for<0, MT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr bool rwhole = 16 * t + 15 < MR;
+            const int ic = rwhole ? 16 * t + li : (16 * t + li < MR ? 16 * t + li : MR - 1);  // (rows beyond MR repeat the last one)
+            const double a_ = fa(tc, sc, ic, kk);
+            av[t][s_] = kin ? a_ : 0.0;
+        });
+    });
     g_d4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[t][r] = fc(16 * t + lk + 4 * r, li);
-#pragma unroll
-    for (int s_ = 0; s_ < KB; s_++) {
-        const int kk = 4 * s_ + lk;
-        const double bv = fb(kk, li);
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const double av = fa(16 * t + li, kk);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+        for (int r = 0; r < 4; r++) {
+            const int i = 16 * t + lk + 4 * r;
+            acc[t][r] = fc(i < MR ? i : MR - 1, jc);
         }
-    }
+#pragma unroll
+    for (int s_ = 0; s_ < KB; s_++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][s_], bv[s_], acc[t], 0, 0, 0);
     if (SYNC_STORE) DWBC_SYNC();
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) fstore(16 * t + lk + 4 * r, li, acc[t][r]);
-#else
-    real_t tmp[MT * 16][16];
-    for (int i = 0; i < MT * 16; i++)
-        for (int j = 0; j < 16; j++) {
-            real_t a_ = fc(i, j);
-            for (int kk = 0; kk < 4 * KB; kk++) a_ += fa(i, kk) * fb(kk, j);
-            tmp[i][j] = a_;
+        for (int r = 0; r < 4; r++) {
+            const int i = 16 * t + lk + 4 * r;
+            if (i < MR && li < NCV) fstore(i, li, acc[t][r]);
         }
-    for (int i = 0; i < MT * 16; i++)
-        for (int j = 0; j < 16; j++) fstore(i, j, tmp[i][j]);
+#else
+    real_t tmp[MR][NCV];
+    for (int i = 0; i < MR; i++)
+        for (int j = 0; j < NCV; j++) tmp[i][j] = fc(i, j);
+    static_for<0, KB>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        static_for<0, MT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            for (int li = 0; li < 16; li++)
+                for (int lk = 0; lk < 4; lk++) {
+                    const int i = 16 * t + li, kk = 4 * s_ + lk;
+                    if (i >= MR || kk >= KV) continue;
+                    const real_t a_ = fa(tc, sc, i, kk);
+                    for (int j = 0; j < NCV; j++) tmp[i][j] += a_ * fb(sc, kk, j);
+                }
+        });
+    });
+    for (int i = 0; i < MR; i++)
+        for (int j = 0; j < NCV; j++) fstore(i, j, tmp[i][j]);
 #endif
 }
-template <int MT, int KB, bool SYNC_STORE, class FA, class FB, class FS>
+template <int MR, int NCV, int KV, bool SYNC_STORE, class FA, class FB, class FS>
 DWBC_WDEV void wave_gemm(FA fa, FB fb, FS fstore) {
-    wave_gemm<MT, KB, SYNC_STORE>(fa, fb, fstore, [](int, int) { return real_t(0.0); });
+    wave_gemm<MR, NCV, KV, SYNC_STORE>(fa, fb, fstore, [](int, int) { return real_t(0.0); });
 }
 
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
@@ -539,7 +572,11 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             }
         }
         DWBC_SYNC();
-        if (!sweep_inverse_tree_lds<Topo, N>(s, dg, L + S::c_s1)) st_contact = 0;  // A_inv (dwbc.cpp:307), pivot column through LDS
+#ifndef DWBC_SWEEP_W
+#define DWBC_SWEEP_W 4
+#endif
+        static_assert(DWBC_SWEEP_W * 2 * ((N + 1) / 2) <= S::ms_size, "pivot columns of one step in the main wave's small scratch");
+        if (!sweep_inverse_tree_lds_multi<Topo, N, DWBC_SWEEP_W>(s, dg, L + S::c_s1)) st_contact = 0;  // A_inv (dwbc.cpp:307), pivot column through LDS
         DWBC_SYNC();
         if (too_many) st_contact = 0;
         LANES {
@@ -657,21 +694,17 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     real_t *Dm = L + S::c_D;   // D = J_t A^-1 J_C^T, one row per vector slot; row GV: Y G
     real_t *BJ = L + S::c_BJ;  // (J_t A^-1) J_t^T of every level
     if (is_help) {
-        for (int idx = th.tid; idx < NVS * C; idx += NT) {
-            const int j = idx / C, p_ = idx - j * C;
-            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-            for (int c = 0; c < N; c++) a4[c & 3] += AJt[j * N + c] * JCt[c * C + p_];
-            Dm[idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        }
-        for (int idx = th.tid; idx < su.n_levels * T * T; idx += NT) {
-            const int lv = idx / (T * T), ij = idx - lv * T * T, i = ij / T, j = ij - i * T;
-            const real_t *Jtt = L + S::Jtt + lv * N * T;
-            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-            for (int c = 0; c < N; c++) a4[c & 3] += AJt[(lv * T + i) * N + c] * Jtt[c * T + j];
-            BJ[idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        }
+        wave_gemm<NVS, C, N, false>(  // D = (J_t A^-1) J_C^T of every slot; row GV: Y G = (A^-1 G)^T J_C^T
+            [&](auto, auto, int v, int c) { return AJt[v * N + c]; },
+            [&](auto, int c, int p_) { return JCt[c * C + p_]; },
+            [&](int v, int p_, real_t d) { Dm[v * C + p_] = d; });
+        wave_gemm<GV, GV, N, false>(  // (J_t A^-1) J_t^T: the diagonal T x T blocks are the levels' own
+            [&](auto, auto, int i, int c) { return AJt[i * N + c]; },
+            [&](auto, int c, int j) { return L[S::Jtt + (j / T) * N * T + c * T + (j % T)]; },
+            [&](int i, int j, real_t d) {
+                const int lv = i / T, c_ = j - lv * T;
+                if (c_ >= 0 && c_ < T && lv < su.n_levels) BJ[lv * T * T + (i - lv * T) * T + c_] = d;
+            });
         DWBC_SYNC();
     }
     DWBC_PAIR_BARRIER_X();  // ---- B1b: the helper is done with J_t^T: Jbar^T takes its place
@@ -699,66 +732,96 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         real_t *AT = L + S::at;
         real_t *Bv = L + S::p4_b, *Qb = L + S::p4_qb, *Cv = L + S::p4_cv, *Lm = L + S::p4_lam, *Wv = L + S::p4_w, *TS = L + S::p4_ts;
         const real_t zero = real_t(0.0);
-        auto apk = [&](int r, int c) { const int hi = r >= c ? r : c, lo = r >= c ? c : r; return Ap[hi * (hi + 1) / 2 + lo]; };  // packed symmetric A
-        auto vec = [&](const real_t *X, int row, int v) { const real_t v_ = X[row * VS + (v < VS ? v : 0)]; return v < VS ? v_ : zero; };
-        constexpr int MT3 = (M + 15) / 16;
+#if defined(DWBC_HOST_EMU)
+        const int glk = 0;
+#else
+        const int glk = (int)((threadIdx.x & 63u) >> 4);  // this lane's place in a reduction block (wave_gemm)
+#endif
+        // entry (r, c) of the packed symmetric mass matrix for an operand block whose rows lie in [RMIN, RMAX] and whose columns are
+        // 4 sb .. 4 sb + 3: below / above the diagonal the index is linear in the lane's part (constant folded into the offset field);
+        // only the blocks that cross the diagonal pay the max / min / multiply
+        auto apk = [&](auto rmin_c, auto rmax_c, auto sc, int r, int c) {
+            constexpr int RMIN = decltype(rmin_c)::value, RMAX = decltype(rmax_c)::value, sb = decltype(sc)::value;
+#if !defined(DWBC_HOST_EMU)
+            if constexpr (RMIN >= 4 * sb + 3) return Ap[r * (r + 1) / 2 + c];
+            else if constexpr (RMAX <= 4 * sb) return Ap[(glk * (glk + 1) / 2 + r + sb * 4 * glk) + (8 * sb * sb + 2 * sb)];  // c = 4 sb + glk: c (c + 1) / 2 + r
+            else
+#endif
+            {
+                const int hi = r >= c ? r : c, lo = r >= c ? c : r;
+                return Ap[hi * (hi + 1) / 2 + lo];
+            }
+        };
         if (nc > 0) {
-            wave_gemm<1, (M + 3) / 4, false>(  // b = J_Cj a
-                [&](int p, int j) { const real_t v_ = JCt[(6 + (j < M ? j : 0)) * C + (p < C ? p : 0)]; return (p < cd && j < M) ? v_ : zero; },
-                [&](int j, int v) { const real_t v_ = vec(AT, j < M ? j : 0, v); return j < M ? v_ : zero; },
-                [&](int p, int v, real_t d) { if (p < C && v < VS) Bv[p * VS + v] = d; });
+            wave_gemm<C, VS, M, false>(  // b = J_Cj a
+                [&](auto, auto, int p, int j) { const real_t v_ = JCt[(6 + j) * C + p]; return p < cd ? v_ : zero; },
+                [&](auto, int j, int v) { return AT[j * VS + v]; },
+                [&](int p, int v, real_t d) { Bv[p * VS + v] = d; });
             DWBC_SYNC();
-            static_assert(C % 4 == 0, "whole reduction blocks");
-            wave_gemm<1, C / 4, false>(  // qb = -Hb b
-                [&](int x, int p) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + p]; return x < 6 ? -v_ : zero; },
-                [&](int p, int v) { return vec(Bv, p, v); },
-                [&](int x, int v, real_t d) { if (x < 6 && v < VS) Qb[x * VS + v] = d; });
+            wave_gemm<6, VS, C, false>(  // qb = -Hb b
+                [&](auto, auto, int x, int p) { return -Hb[x * C + p]; },
+                [&](auto, int p, int v) { return Bv[p * VS + v]; },
+                [&](int x, int v, real_t d) { Qb[x * VS + v] = d; });
             DWBC_SYNC();
         }
         DWBC_PSTAMP_M(46);  // W^+: b, qb
-        wave_gemm<1, (N + 3) / 4, false>(  // cv = A_bb qb + A_bj a   (no contact: cv = A_bj a, qb follows from it)
-            [&](int x, int kk) { const real_t v_ = apk(x < 6 ? x : 0, kk < N ? kk : 0); return (x < 6 && kk < N) ? v_ : zero; },
-            [&](int kk, int v) {
-                const real_t v_ = vec(kk < 6 ? Qb : AT, kk < 6 ? kk : (kk < N ? kk - 6 : 0), v);
-                return ((kk < 6 && nc > 0) || (kk >= 6 && kk < N)) ? v_ : zero;
+        wave_gemm<6, VS, N, false>(  // cv = A_bb qb + A_bj a   (no contact: cv = A_bj a, qb follows from it)
+            [&](auto, auto sc, int x, int kk) { return apk(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, sc, x, kk); },
+            [&](auto, int kk, int v) {
+                const real_t v_ = (kk < 6 ? Qb + kk * VS : AT + (kk - 6) * VS)[v];
+                return (kk >= 6 || nc > 0) ? v_ : zero;
             },
-            [&](int x, int v, real_t d) { if (x < 6 && v < VS) Cv[x * VS + v] = d; });
+            [&](int x, int v, real_t d) { Cv[x * VS + v] = d; });
         DWBC_SYNC();
         if (nc > 0) {
-            wave_gemm<1, 2, false>(  // lam = -Hb^T cv
-                [&](int p, int x) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + (p < C ? p : 0)]; return (p < C && x < 6) ? -v_ : zero; },
-                [&](int x, int v) { const real_t v_ = vec(Cv, x < 6 ? x : 0, v); return x < 6 ? v_ : zero; },
-                [&](int p, int v, real_t d) { if (p < C && v < VS) Lm[p * VS + v] = d; });
+            wave_gemm<C, VS, 6, false>(  // lam = -Hb^T cv
+                [&](auto, auto, int p, int x) { return -Hb[x * C + p]; },
+                [&](auto, int x, int v) { return Cv[x * VS + v]; },
+                [&](int p, int v, real_t d) { Lm[p * VS + v] = d; });
         } else {
-            wave_gemm<1, 2, false>(  // qb = -A_bb^-1 cv
-                [&](int x, int y) { const real_t v_ = Hb[(x < 6 ? x : 0) * C + (y < 6 ? y : 0)]; return (x < 6 && y < 6) ? -v_ : zero; },
-                [&](int y, int v) { const real_t v_ = vec(Cv, y < 6 ? y : 0, v); return y < 6 ? v_ : zero; },
-                [&](int x, int v, real_t d) { if (x < 6 && v < VS) Qb[x * VS + v] = d; });
+            wave_gemm<6, VS, 6, false>(  // qb = -A_bb^-1 cv
+                [&](auto, auto, int x, int y) { return -Hb[x * C + y]; },
+                [&](auto, int y, int v) { return Cv[y * VS + v]; },
+                [&](int x, int v, real_t d) { Qb[x * VS + v] = d; });
         }
         DWBC_SYNC();
         DWBC_PSTAMP_M(47);  // W^+: cv, lam
         // tau_any = [A_jb | A_jj | J_Cj^T] [qb; a; lam], stored transposed over its own operands (TS: M x VS)
-        wave_gemm<MT3, (N + C + 3) / 4, true>(
-            [&](int i, int kk) {
-                const int ii = i < M ? i : 0, p = kk - N;
-                const real_t va = apk(6 + ii, kk < N ? kk : 0), vj = JCt[(6 + ii) * C + ((p >= 0 && p < C) ? p : 0)];
-                return i < M ? (kk < N ? va : ((p < cd) ? vj : zero)) : zero;
+        wave_gemm<M, VS, N + C, true>(
+            [&](auto tc, auto sc, int i, int kk) {
+                constexpr int t = decltype(tc)::value, sb = decltype(sc)::value;
+                constexpr int RMIN = 6 + 16 * t, RMAX = (6 + 16 * t + 15 < N - 1) ? 6 + 16 * t + 15 : N - 1;
+                if constexpr (4 * sb + 3 < N) {
+                    return apk(std::integral_constant<int, RMIN>{}, std::integral_constant<int, RMAX>{}, sc, 6 + i, kk);
+                } else if constexpr (4 * sb >= N) {
+                    return JCt[(6 + i) * C + (kk - N)];  // (rows of inactive contacts are zero)
+                } else {
+                    const int r = 6 + i, c = kk < N ? kk : 0, hi = r >= c ? r : c, lo = r >= c ? c : r;
+                    const real_t va = Ap[hi * (hi + 1) / 2 + lo], vj = JCt[(6 + i) * C + (kk >= N ? kk - N : 0)];
+                    return kk < N ? va : vj;
+                }
             },
-            [&](int kk, int v) {
-                const int p = kk - N;
-                const real_t *X = kk < 6 ? Qb : (kk < N ? AT : Lm);
-                const int row = kk < 6 ? kk : (kk < N ? kk - 6 : ((p < C) ? p : 0));
-                const real_t v_ = vec(X, row, v);
-                return (kk < N || (p < cd)) ? v_ : zero;
+            [&](auto sc, int kk, int v) {
+                constexpr int sb = decltype(sc)::value;
+                if constexpr (4 * sb >= 6 && 4 * sb + 3 < N) {
+                    return AT[(kk - 6) * VS + v];
+                } else if constexpr (4 * sb >= N) {
+                    const real_t v_ = Lm[(kk - N) * VS + v];
+                    return nc > 0 ? v_ : zero;
+                } else {
+                    const real_t *X = kk < 6 ? Qb + kk * VS : (kk < N ? AT + (kk - 6) * VS : Lm + (kk - N) * VS);
+                    const real_t v_ = X[v];
+                    return (kk < N || nc > 0) ? v_ : zero;
+                }
             },
-            [&](int i, int v, real_t d) { if (i < M && v < VS) TS[i * VS + v] = d; });
+            [&](int i, int v, real_t d) { TS[i * VS + v] = d; });
         DWBC_SYNC();
         DWBC_PSTAMP_M(48);  // W^+: tau_any
         if (k > 0) {  // W^+ a = (I - P) tau_any,  P tau = VG (Vb^T tau)
-            wave_gemm<1, (M + 3) / 4, false>(
-                [&](int a, int i) { const real_t v_ = Vb[(i < M ? i : 0) * 6 + (a < 6 ? a : 0)]; return (a < 6 && i < M) ? v_ : zero; },
-                [&](int i, int v) { const real_t v_ = vec(TS, i < M ? i : 0, v); return i < M ? v_ : zero; },
-                [&](int a, int v, real_t d) { if (a < 6 && v < VS) Wv[a * VS + v] = d; });
+            wave_gemm<6, VS, M, false>(
+                [&](auto, auto, int a, int i) { return Vb[i * 6 + a]; },
+                [&](auto, int i, int v) { return TS[i * VS + v]; },
+                [&](int a, int v, real_t d) { Wv[a * VS + v] = d; });
             DWBC_SYNC();
         }
         LANES {
@@ -778,24 +841,22 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         // ---- P_C = Lambda_c (Y G) (wbd.cpp:119), the gravity pre-vector (A^-1 N_c G)[6:] = (A^-1 G - Y^T P_C)[6:], and the joint
         //      columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level: the vectors a_v, stored transposed AT[j][v]
         real_t *AT = L + S::at;
-        for (int p_ = th.tid; p_ < C; p_ += NT) {
-            real_t acc = real_t(0.0);
+        for (int p_ = th.tid; p_ < C; p_ += NT) {  // (rows and columns of inactive contacts are zero in Lambda_c and in Y G: no conditions)
+            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
 #pragma unroll
-            for (int q_ = 0; q_ < C; q_++) acc += (p_ < cd && q_ < cd) ? Lam[p_ * C + q_] * Dm[GV * C + q_] : real_t(0.0);
-            L[S::PC + p_] = acc;
+            for (int q_ = 0; q_ < C; q_++) a4[q_ & 3] += Lam[p_ * C + q_] * Dm[GV * C + q_];
+            L[S::PC + p_] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         }
         // the vectors a_v = (J_t A^-1 - D Jbar^T)[v][6:], and with row GV of D = Y G: (A^-1 G - Jbar (Y G))[6:] -- the same thing as
         // A^-1 G - Y^T P_C (Lambda_c is symmetric); one product on the matrix cores, the riding block read as its starting value
-        wave_gemm<(M + 15) / 16, C / 4, true>(
-            [&](int j, int p) { const real_t v_ = JbT[p * N + 6 + (j < M ? j : 0)]; return j < M ? -v_ : real_t(0.0); },
-            [&](int p, int v) { const real_t v_ = Dm[(v < NVS ? v : 0) * C + p]; return v < NVS ? v_ : real_t(0.0); },
+        wave_gemm<M, NVS, C, true>(
+            [&](auto, auto, int j, int p) { return -JbT[p * N + 6 + j]; },
+            [&](auto, int p, int v) { return Dm[v * C + p]; },
             [&](int j, int v, real_t d) {
-                if (j < M && v < NVS) {
-                    AT[j * VS + v] = d;                                                        // (empty slots are zero vectors: J_t A^-1 and D are zero there)
-                    if (v < GV) L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d;    // T1x: the chain and the slow route of phase 5 read it
-                }
+                AT[j * VS + v] = d;                                                        // (empty slots are zero vectors: J_t A^-1 and D are zero there)
+                if (v < GV) L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d;    // T1x: the chain and the slow route of phase 5 read it
             },
-            [&](int j, int v) { const real_t v_ = AJt[(v < NVS ? v : 0) * N + 6 + (j < M ? j : 0)]; return (j < M && v < NVS) ? v_ : real_t(0.0); });
+            [&](int j, int v) { return AJt[v * N + 6 + j]; });
         DWBC_SYNC();
         DWBC_PSTAMP_M(45);  // vectors ready
         wplus(tv);
@@ -809,28 +870,34 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         // Lambda_task of every level from the Gram blocks: J_t A^-1 N_c J_t^T = (J_t A^-1) J_t^T - D Lambda_c D^T (wbd.cpp:210), and the
         // condition verdict (dwbc_cycle2.h, task-Jacobian stage)
         int fm = 0;
+        real_t *DLx = L + S::q;  // D Lambda_c (GV x C) in the header scratch (q, G, ...: dead since phase 1b)
+        static_assert(GV * C <= S::hend - S::q && NLV <= 2, "D Lambda_c borrows the header scratch; two Lambda_task blocks in the helper's scratch");
+        DWBC_SYNC();
+        wave_gemm<GV, C, C, false>(
+            [&](auto, auto, int i, int p) { return Dm[i * C + p]; },
+            [&](auto, int p, int q_) { return Lam[p * C + q_]; },
+            [&](int i, int q_, real_t d) { DLx[i * C + q_] = d; });
+        DWBC_SYNC();
+        wave_gemm<GV, GV, C, false>(  // the diagonal blocks of (J_t A^-1) J_t^T - (D Lambda_c) D^T, level lv at hs + 72 lv, row stride t_lv
+            [&](auto, auto, int i, int p) { return -DLx[i * C + p]; },
+            [&](auto, int p, int j) { return Dm[j * C + p]; },
+            [&](int i, int j, real_t d) {
+                const int lv = i / T, r = i - lv * T, c_ = j - lv * T;
+                if (c_ >= 0 && c_ < T && lv < su.n_levels) {
+                    const int t = su.t_dof[lv];
+                    if (r < t && c_ < t) L[S::hs + 72 * lv + r * t + c_] = d;
+                }
+            },
+            [&](int i, int j) {
+                const int lv = i / T, c_ = j - lv * T;
+                const bool in = c_ >= 0 && c_ < T;
+                const real_t v_ = BJ[lv * T * T + (i - lv * T) * T + (in ? c_ : 0)];
+                return in ? v_ : real_t(0.0);
+            });
+        DWBC_SYNC();
         for (int lv = 0; lv < su.n_levels; lv++) {
             const int t = su.t_dof[lv];
-            real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs, *DL = L + S::c_s1;  // (c_s1: the main wave's sweep column, idle since phase 2; T x C fits its 72 doubles)
-            static_assert(T * C <= S::c_s2 - S::c_s1, "D Lambda_c borrows the sweep column");
-            const real_t *Dl = Dm + lv * T * C;
-            DWBC_SYNC();
-            for (int idx = th.tid; idx < t * C; idx += NT) {  // DL = D Lambda_c  (t x C)
-                const int i = idx / C, p = idx - i * C;
-                real_t acc = real_t(0.0);
-#pragma unroll
-                for (int q_ = 0; q_ < C; q_++) acc += Dl[i * C + q_] * Lam[q_ * C + p];
-                DL[idx] = acc;
-            }
-            DWBC_SYNC();
-            for (int idx = th.tid; idx < t * t; idx += NT) {
-                const int i = idx / t, j = idx - i * t;
-                real_t acc = BJ[lv * T * T + i * T + j];
-#pragma unroll
-                for (int p = 0; p < C; p++) acc -= DL[i * C + p] * Dl[j * C + p];
-                Li[idx] = acc;
-            }
-            DWBC_SYNC();
+            real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs + 72 * lv;
             const int ok_lt = spd_inverse_small(Li, t, t, Lt, t, L + S::hs + 144);
             real_t da = real_t(0.0), dl = real_t(0.0);
             for (int i = 0; i < t; i++) {
@@ -848,13 +915,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         constexpr int K6 = 6;
         real_t *JV = L + S::hs, *Gi = L + S::hs + 36, *Bm = L + S::hs + 72, *Sm6 = L + S::hs + 108;
         DWBC_SYNC();
-        for (int idx = th.tid; idx < K6 * K6; idx += NT) {
-            const int i = idx / 6, j = idx - i * 6;
-            real_t acc = real_t(0.0);
-            _Pragma("unroll 8")
-            for (int c = 0; c < M; c++) acc += JbT[i * N + 6 + c] * Vb[c * K6 + j];
-            JV[idx] = acc;
-        }
+        wave_gemm<K6, K6, M, false>(
+            [&](auto, auto, int i, int c) { return JbT[i * N + 6 + c]; },
+            [&](auto, int c, int j) { return Vb[c * K6 + j]; },
+            [&](int i, int j, real_t d) { JV[i * K6 + j] = d; });
         DWBC_SYNC();
         mm_nn<NT>(th, Bm, K6, JV, K6, Gi, K6, K6, K6, K6);                       // B = JV G^-1
         DWBC_SYNC();
@@ -863,7 +927,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         if (!spd_inverse_small(Sm6, K6, K6, Sm6, K6, L + S::hs + 144)) { if (th.tid == 0) flg[0] = real_t(0.0); }
         mm_nn<NT>(th, Bm, K6, Sm6, K6, JV, K6, K6, K6, K6);                      // X = S^-1 JV
         DWBC_SYNC();
-        mm_nt<NT>(th, L + S::NwJw, K6, VG, K6, Bm, K6, M, K6, K6);              // NwJw = VG X^T
+        wave_gemm<M, K6, K6, false>(                                             // NwJw = VG X^T
+            [&](auto, auto, int i, int a) { return VG[i * K6 + a]; },
+            [&](auto, int a, int j) { return Bm[j * K6 + a]; },
+            [&](int i, int j, real_t d) { L[S::NwJw + i * K6 + j] = d; });
         DWBC_SYNC();
     }
     DWBC_PAIR_BARRIER(4);  // ---- B4: J_kt-side vectors in the main wave's registers; Lambda_task, the fast-route mask, NwJw in LDS
