@@ -628,6 +628,22 @@ template <int OFF>
 __device__ __forceinline__ void lds_write_b64(unsigned addr, double v) {
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+template <int CNT>
+__device__ __forceinline__ void lds_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");
+}
+// 16-byte pieces of the pivot columns of step STEP that are asked for after those of its pivot number q
+template <class Topo, int NN, int W, int STEP>
+constexpr int lds_pieces_after(int q) {
+    constexpr TreeSchedule<NN, W> sch = TreeScheduleOf<Topo, NN, W>::value;
+    int n = 0;
+    for (int r = q + 1; r < sch.cnt[STEP]; r++) {
+        const unsigned long long rel = Topo::relatives(sch.piv[STEP][r]);
+        for (int P = 0; P < (NN + 1) / 2; P++)
+            if ((rel >> (2 * P)) & 3ull) n++;
+    }
+    return n;
+}
 template <class Topo, int NN, int W, int STEP>
 __device__ __forceinline__ void lds_step_tree(double (&s)[NN], double &dg2, int &ok, unsigned cb, int lane) {
     using Sch = TreeScheduleOf<Topo, NN, W>;
@@ -656,14 +672,14 @@ __device__ __forceinline__ void lds_step_tree(double (&s)[NN], double &dg2, int 
         cj[q] = s[K];
         h[q] = cj[q] * rp;
     });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    static_for<0, cnt>([&](auto qc) {
-        constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
-        lds_rel_pin<Topo, K, 0, NP, NP>(col[q]);
-    });
+    // the columns come back in the order they were asked for: the rows of pivot q are updated as soon as ITS pieces are in, while
+    // the later columns are still on their way (the counter saturates at 15: a wait for more than that waits for 15)
     static_for<0, cnt>([&](auto qc) {
         constexpr int q = decltype(qc)::value, K = Sch::value.piv[STEP][q];
         constexpr unsigned long long rel = Topo::relatives(K);
+        constexpr int later = lds_pieces_after<Topo, NN, W, STEP>(q);
+        lds_wait_lgkm<(later < 15 ? later : 15)>();
+        lds_rel_pin<Topo, K, 0, NP, NP>(col[q]);
 #pragma unroll
         for (int i = 0; i < NN; i++)
             if ((rel >> i) & 1ull) s[i] -= col[q][i / 2][i & 1] * h[q];

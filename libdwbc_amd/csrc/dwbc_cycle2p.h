@@ -389,9 +389,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     DWBC_PAIR_BARRIER(0);  // ---- B0: Rw, pw, aw
 
     // ================= phase 1 =================
-    if (is_main) {
-        // world inertias, composite inertias, S, F, CRBA, A -> registers, A^-1  (dwbc_cycle2_stage0.inc)
-        real_t *Iw = L + S::k_Iw;
+    // world inertias and composite inertias: both waves (each forms the world inertias for itself -- identical values to identical
+    // places -- and takes five of the ten components through the prefix scan; the halves meet at B0a)
+    real_t *Iw = L + S::k_Iw, *Icm = L + S::k_Ic;
+    auto world_inertias = [&]() {
         for (int i = th.tid; i < nb; i += NT) {
             const real_t *bd = body + i * kBodyStride;
             const real_t *R = Rw + i * 9;
@@ -417,40 +418,50 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 }
         }
         DWBC_SYNC();
-        DWBC_PSTAMP_M(51);  // world inertias
-        real_t *Icm = L + S::k_Ic;
-        {
+    };
+    auto composite_part = [&](auto c0c, auto c1c) {
             // composite inertia of the subtree [b, b + len_b) (bodies are numbered depth first): inclusive prefix sums over the body order
             // in registers (DPP), Ic[b] = P[b + len_b - 1] - P[b - 1].  Everything is expressed about the pelvis origin, where the smallest
             // subtree (a wrist link, m r^2 ~ 0.1) is within 1e3 of the total: the difference keeps 13 digits.  (The window sums by doubling
             // of the one-wave kernels -- six rounds through LDS -- were 7.3 k of this wave's 17 k cycles before the A^-1 sweep.)
-            PLA(real_t, pf, 10);
+            constexpr int C0 = decltype(c0c)::value, C1 = decltype(c1c)::value, NCP = C1 - C0;
+            PLA(real_t, pf, NCP);
             PL(int, len);
             LANES {
                 const int bi = lane < nb ? lane : 0;
                 LV(len) = lane < nb ? topo[2 * nb + bi] : 1;
 #pragma unroll
-                for (int c = 0; c < 10; c++) {
-                    const real_t v_ = Iw[bi * 10 + c];
+                for (int c = 0; c < NCP; c++) {
+                    const real_t v_ = Iw[bi * 10 + C0 + c];
                     LV(pf)[c] = lane < nb ? v_ : real_t(0.0);
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 10; c++) WAVE_PREFIX_A(pf, c);
+            for (int c = 0; c < NCP; c++) WAVE_PREFIX_A(pf, c);
             LANES {
                 int e_ = lane + LV(len) - 1;
                 e_ = e_ < 63 ? e_ : 63;
                 const int s_ = lane > 0 ? lane - 1 : 0;
 #pragma unroll
-                for (int c = 0; c < 10; c++) {
+                for (int c = 0; c < NCP; c++) {
                     const real_t hi_ = SHFLA(pf, c, e_), lo_ = SHFLA(pf, c, s_);
-                    if (lane < nb) Icm[lane * 10 + c] = hi_ - (lane > 0 ? lo_ : real_t(0.0));
+                    if (lane < nb) Icm[lane * 10 + C0 + c] = hi_ - (lane > 0 ? lo_ : real_t(0.0));
                 }
             }
             DWBC_SYNC();
-        }
-        DWBC_PSTAMP_M(52);  // composite inertias
-        real_t *Sm = L + S::k_S, *Fm = L + S::k_F;
+    };
+    if (is_main) {
+        world_inertias();
+        DWBC_PSTAMP_M(51);  // world inertias
+        composite_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    }
+    if (is_help) {
+        world_inertias();
+        composite_part(std::integral_constant<int, 5>{}, std::integral_constant<int, 10>{});
+    }
+    real_t *Sm = L + S::k_S, *Fm = L + S::k_F;
+    if (is_main) {
+        // motion axes S (frames only: before the halves meet), then F, CRBA, A -> registers, A^-1  (dwbc_cycle2_stage0.inc)
         for (int j = th.tid; j < N; j += NT) {
             real_t w[3] = {0, 0, 0}, v[3] = {0, 0, 0};
             if (j < 3) {
@@ -468,6 +479,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             for (int a = 0; a < 3; a++) { Sm[j * 6 + a] = w[a]; Sm[j * 6 + 3 + a] = v[a]; }
         }
         DWBC_SYNC();
+    }
+    DWBC_PAIR_BARRIER_X();  // ---- B0a: all ten components of the composite inertias
+    if (is_main) {
+        DWBC_PSTAMP_M(52);  // composite inertias, S
         for (int j = th.tid; j < N; j += NT) {
             const int b = j < 6 ? 0 : j - 5;
             const real_t *I = Icm + b * 10;
@@ -482,7 +497,7 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
             Fm[j * 6 + 5] = m * v2 + (w0 * h1 - w1 * h0);
         }
         DWBC_SYNC();
-        DWBC_PSTAMP_M(53);  // motion axes S, forces F
+        DWBC_PSTAMP_M(53);  // forces F
         real_t *A = L + S::k_A;  // lower triangle, row-packed: (i, j <= i) at i (i + 1) / 2 + j
         for (int idx = th.tid; idx < N * (N + 1) / 2; idx += NT) A[idx] = real_t(0.0);
         DWBC_SYNC();
@@ -1081,15 +1096,10 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 }
             }
             DWBC_SYNC();
-            for (int idx = th.tid; idx < T * TTL; idx += NT) {
-                const int i = idx / TTL, j = idx - i * TTL;
-                real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-                if (i < tp) {
-#pragma unroll
-                    for (int c = 0; c < M; c++) a4[c & 3] += Yp[i * S::MS + c] * Ul[c * T + j];
-                }
-                L[S::c_Z + idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-            }
+            wave_gemm<T, TTL, M, false>(  // (rows of Y_0 beyond tp are zero: empty slots)
+                [&](auto, auto, int i, int c) { return Yp[i * S::MS + c]; },
+                [&](auto, int c, int j) { return Ul[c * T + j]; },
+                [&](int i, int j, real_t d) { L[S::c_Z + i * TTL + j] = d; });
             DWBC_SYNC();
             LANES {
 #pragma unroll
