@@ -851,6 +851,74 @@ DWBC_WDEV int spd_inverse_chol6(const real_t *Ain, int lda, int n, real_t *Out, 
     return ok;
 }
 
+// Three such inverses at once (densely stored: row stride n_q, in place allowed): the factorisation above is per-lane work on
+// broadcast data, so three groups of eight lanes can each take a matrix of their own for the price of one -- the helper wave of
+// dwbc_cycle2p.h inverts Lambda_task^-1 of two levels and the null-space Gram matrix this way.  n_q = 0: no such matrix.  ok[q] = 0
+// when a pivot of matrix q is not positive.
+DWBC_WDEV void spd_inverse_chol6_x3(const real_t *A0, int n0, real_t *O0, const real_t *A1, int n1, real_t *O1, const real_t *A2, int n2, real_t *O2, int (&ok)[3]) {
+#if defined(DWBC_HOST_EMU)
+    ok[0] = n0 > 0 ? spd_inverse_chol6(A0, n0, n0, O0, n0) : 1;
+    ok[1] = n1 > 0 ? spd_inverse_chol6(A1, n1, n1, O1, n1) : 1;
+    ok[2] = n2 > 0 ? spd_inverse_chol6(A2, n2, n2, O2, n2) : 1;
+#else
+    const int lane = (int)(threadIdx.x & 63u), g = lane >> 3, c = lane & 7;
+    const real_t *Ag = g == 0 ? A0 : (g == 1 ? A1 : A2);
+    real_t *Og = g == 0 ? O0 : (g == 1 ? O1 : O2);
+    const int n = g == 0 ? n0 : (g == 1 ? n1 : (g == 2 ? n2 : 0));
+    real_t Lc[6][6], ri[6];
+    int okv = 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const real_t v_ = Ag[(i < n ? i * n + j : 0)];
+            Lc[i][j] = (i < n) ? v_ : (i == j ? real_t(1.0) : real_t(0.0));
+        }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        real_t d = Lc[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lc[j][k] * Lc[j][k];
+        if (!(d > real_t(0.0))) { okv = 0; d = real_t(1.0); }
+        ri[j] = fast_rsqrt(d);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            real_t v = Lc[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= Lc[i][k] * Lc[j][k];
+            Lc[i][j] = v * ri[j];
+        }
+    }
+    DWBC_SYNC();  // in place allowed
+    {
+        real_t y[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            real_t v = (c == i) ? real_t(1.0) : real_t(0.0);
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= Lc[i][k] * y[k];
+            y[i] = v * ri[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            real_t v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) v -= Lc[k][i] * y[k];
+            y[i] = v * ri[i];
+        }
+        if (c < n) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (i < n) Og[i * n + c] = y[i];
+        }
+    }
+    ok[0] = __builtin_amdgcn_readlane(okv, 0);
+    ok[1] = __builtin_amdgcn_readlane(okv, 8);
+    ok[2] = __builtin_amdgcn_readlane(okv, 16);
+    DWBC_SYNC();
+#endif
+}
+
 DWBC_DEVN int spd_inverse_small(const real_t *Ain, int lda, int n, real_t *Out, int ldo, real_t *colbuf, real_t *pivratio = nullptr) {
     DWBC_LANE_DECL;
     DWBC_SYNC();

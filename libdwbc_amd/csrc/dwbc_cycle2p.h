@@ -69,10 +69,7 @@ struct Lds4 {
     static constexpr int NVS = NLV * T + 1;                    // vectors W^+ is applied to: one slot per task dof of every level + the gravity pre-vector
     static constexpr int ajt = Rw;
     static_assert(NVS * N <= fend - Rw && Rw % 2 == 0, "J_t A^-1 and A^-1 G borrow the link frames");
-    // phase 4: the vectors transposed, AT[j][v] (M x VS)
-    static constexpr int VS = ev(NVS);
-    static constexpr int at = Rw;
-    static_assert(M * VS <= fend - Rw, "the transposed vectors borrow the link frames");
+    static constexpr int VS = ev(NVS);                         // row stride of the per-slot blocks of phase 4
     // ---- long-lived
     static constexpr int c_JC = fend;                          // N x C: J_C, phase 1a .. 4 (the inverse-dynamics form of W^+ reads it)
     static constexpr int NwJw = c_JC + C * N;
@@ -113,16 +110,17 @@ struct Lds4 {
     // slow-route scratch of phase 5, which starts at `kin` as well)
     static constexpr int T1x = ev(max2(c_BJ + NLV * T * T, kin + 2 * T * M + 6 * T * T + 3 * T));
     static_assert(T1x + NLV * T * MS <= kin_end, "Y, D, the task Gram blocks and T1x borrow the phase-1a scratch");
-    // phase 4 scratch over Y (dead after phase 3): b (C x VS), qb (6 x VS), cv (6 x VS), lam (C x VS), w (K x VS); the torque staging
-    // TS (M x VS) overlays b .. lam once they are consumed
-    static constexpr int p4_b = kin;                           // b = J_Cj a (C x VS); lam = -Hb^T cv takes its place once qb exists
-    static constexpr int p4_qb = p4_b + C * VS;
-    static constexpr int p4_cv = p4_qb + 6 * VS;
-    static constexpr int p4_lam = p4_b;
-    static constexpr int p4_ts = kin;                          // tau_any transposed (M x VS), over all of the above
-    static constexpr int p4_w = at;                            // Vb^T tau_any (K x VS): over the vectors themselves, dead by then
-    static_assert(kin % 2 == 0 && at % 2 == 0, "16-byte aligned rows of the phase-4 blocks (lds_rows_axpy)");
-    static_assert(p4_cv + 6 * VS <= c_D && p4_ts + M * VS <= c_D, "phase-4 scratch stays below D and the task Gram blocks (the helper reads them in parallel)");
+    // phase 4 (main): D Lambda_c of every slot (NVS x C), E = (D Lambda_c)^T + Hb^T cv (C x VS), w = Vb^T tau (K x VS) over Y (dead after
+    // phase 2); the torques tau (M x VS) and the base residuals cv (6 x VS) accumulate in place over the staged mass matrix (dead after
+    // phase 1b), where the helper leaves their starting values J_t^T / G in phase 2
+    static constexpr int p4_dl = kin;
+    static constexpr int p4_e = p4_dl + ev(NVS * C);
+    static constexpr int p4_w = p4_e + C * VS;
+    static constexpr int p4_ts = U;
+    static constexpr int p4_cv = p4_ts + M * VS;
+    static_assert(kin % 2 == 0 && U % 2 == 0, "16-byte aligned rows of the phase-4 blocks (lds_rows_axpy)");
+    static_assert(p4_w + K * VS <= c_D, "phase-4 scratch stays below D and the task Gram blocks (the helper reads them in parallel)");
+    static_assert(p4_cv + 6 * VS <= UAend, "torques and base residuals borrow the place of the staged mass matrix");
     static constexpr int c_QW = kin;                           // Q (slow route)
     static constexpr int c_QWp = c_QW + T * M;                 // Q W^+ (slow route)
     static constexpr int c_Pi = c_QWp + T * M;
@@ -650,6 +648,15 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 }
                 Hb[idx] = acc;
             }
+            if (nc == 0) {  // A_jb A_bb^-1 (M x 6) in VG's place (no contact: no internal wrench basis)
+                for (int idx = th.tid; idx < M * 6; idx += NT) {
+                    const int i = idx / 6, x = idx - i * 6;
+                    real_t acc = real_t(0.0);
+#pragma unroll
+                    for (int y = 0; y < 6; y++) acc += Ap[(6 + i) * (7 + i) / 2 + y] * Gbi[y * 6 + x];
+                    VG[idx] = acc;
+                }
+            }
             DWBC_SYNC();
         }
     }
@@ -720,6 +727,14 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 const int lv = i / T, c_ = j - lv * T;
                 if (c_ >= 0 && c_ < T && lv < su.n_levels) BJ[lv * T * T + (i - lv * T) * T + c_] = d;
             });
+        // starting values of phase 4's accumulations, while J_t^T is still there: row c of [J_t^T of every slot | G], base rows to cv,
+        // joint rows to tau (both transposed to slot-minor); the staged mass matrix they replace was last read in phase 1b
+        for (int idx = th.tid; idx < N * NVS; idx += NT) {
+            const int c = idx / NVS, v = idx - c * NVS, lv = v < GV ? v / T : 0, r = v - lv * T;
+            const real_t jt = L[S::Jtt + lv * N * T + c * T + (v < GV ? r : 0)], gv = L[S::G + c];
+            const real_t val = v == GV ? gv : ((lv < su.n_levels && r < su.t_dof[lv]) ? jt : real_t(0.0));
+            L[(c < 6 ? S::p4_cv + c * VS : S::p4_ts + (c - 6) * VS) + v] = val;
+        }
         DWBC_SYNC();
     }
     DWBC_PAIR_BARRIER_X();  // ---- B1b: the helper is done with J_t^T: Jbar^T takes its place
@@ -732,104 +747,59 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     }
     DWBC_PAIR_BARRIER(2);  // ---- B2: Jbar^T, Lambda_c, D, Y G, the task Gram blocks in LDS
 
-    // ================= phases 3 + 4: the main wave applies W^+ without forming it; the helper finishes NwJw and Lambda_task =================
+    // ================= phases 3 + 4: the main wave applies W^+ without forming it; the helper finishes T1, NwJw and Lambda_task =================
     // W = (A^-1 N_c)[6:, 6:] is the map joint torque -> joint acceleration of the contact-constrained robot, so W^+ a -- all this cycle
     // ever asks of W^+, for a = the rows of T1r of each level (J_kt = W^+ T1r^T ..., wbd.cpp:207-213) and the gravity pre-vector
-    // (wbd.cpp:190), every one of them in range(W) -- is constrained INVERSE dynamics: with qdd = [qb; a],
-    //     J_C qdd = 0                        ->  qb  = -Hb (J_Cj a)                 (least squares, exact: the rows are consistent)
-    //     base rows of A qdd + J_C^T lam = 0 ->  lam = -Hb^T (A_bb qb + A_bj a)     (a particular solution)
-    //     tau_any = A_jb qb + A_jj a + J_Cj^T lam,    W^+ a = (I - P) tau_any       (P = VG Vb^T: the projector on null(W), internal wrenches)
-    // -- products with A, J_C and 6 x 6 blocks instead of the 33-pivot sweep of W + alpha P, its assembly (the rank-12 update A^-1 N_c, the
-    // projector column) and the staging of what rode through it: 21 k + 12 k cycles of round 4's first version of this kernel.
-    // W^+ applied to the NVS vectors stored transposed in AT (M x VS): out[v] = (W^+ a_v)[lane] for lane < M.  One wave; called by the main
-    // wave in phase 4 and again by the slow route of phase 5 (on the rows of Q).
-    auto wplus = [&](auto &tvo) {
-        real_t *AT = L + S::at;
-        real_t *Bv = L + S::p4_b, *Qb = L + S::p4_qb, *Cv = L + S::p4_cv, *Lm = L + S::p4_lam, *Wv = L + S::p4_w, *TS = L + S::p4_ts;
+    // (wbd.cpp:190) -- is constrained INVERSE dynamics, and for THESE vectors it needs neither A nor A^-1: a is the joint part of
+    // qdd = A^-1 N_c j (j = a row of J_t, or G), an acceleration that already satisfies the contacts (J_C A^-1 N_c = 0), and
+    //     A qdd = N_c j = j - J_C^T Jbar j = j - J_C^T (Lambda_c d),     d = J_C A^-1 j  (a row of D = (J_t A^-1) J_C^T, resp. Y G)
+    // so with cv = the base rows of that (j_b - J_Cb^T Lambda_c d), contact forces lam = -Hb^T cv that carry it (a particular solution of
+    // J_Cb^T lam = -cv: Hb = (J_Cb^T J_Cb)^-1 J_Cb^T; without contacts the base takes it, Hb = A_bb^-1) and E = Lambda_c d - lam:
+    //     tau_any = j_j - J_Cj^T E,        W^+ a = (I - P) tau_any        (P = VG Vb^T: the projector on null(W), internal wrenches)
+    // -- five small products on the matrix cores (26 MFMA instructions for all 13 vectors) instead of the W + alpha P assembly (the
+    // rank-12 update A^-1 N_c, the projector column), its 33-pivot sweep and the staging of what rode through it (33 k cycles of round
+    // 4's first version of this kernel).  P_C = Lambda_c (Y G) (wbd.cpp:119) is the gravity slot's row of D Lambda_c.
+    PLA(real_t, tv, VS);  // main wave, lane i < M: (W^+ a_v)[i] for every vector slot v: column i of J_kt of every level, torque_grav_[i]
+    if (is_main) {
+        real_t *DLn = L + S::p4_dl, *Cv = L + S::p4_cv, *Em = L + S::p4_e, *Wv = L + S::p4_w, *TS = L + S::p4_ts;
         const real_t zero = real_t(0.0);
-#if defined(DWBC_HOST_EMU)
-        const int glk = 0;
-#else
-        const int glk = (int)((threadIdx.x & 63u) >> 4);  // this lane's place in a reduction block (wave_gemm)
-#endif
-        // entry (r, c) of the packed symmetric mass matrix for an operand block whose rows lie in [RMIN, RMAX] and whose columns are
-        // 4 sb .. 4 sb + 3: below / above the diagonal the index is linear in the lane's part (constant folded into the offset field);
-        // only the blocks that cross the diagonal pay the max / min / multiply
-        auto apk = [&](auto rmin_c, auto rmax_c, auto sc, int r, int c) {
-            constexpr int RMIN = decltype(rmin_c)::value, RMAX = decltype(rmax_c)::value, sb = decltype(sc)::value;
-#if !defined(DWBC_HOST_EMU)
-            if constexpr (RMIN >= 4 * sb + 3) return Ap[r * (r + 1) / 2 + c];
-            else if constexpr (RMAX <= 4 * sb) return Ap[(glk * (glk + 1) / 2 + r + sb * 4 * glk) + (8 * sb * sb + 2 * sb)];  // c = 4 sb + glk: c (c + 1) / 2 + r
-            else
-#endif
-            {
-                const int hi = r >= c ? r : c, lo = r >= c ? c : r;
-                return Ap[hi * (hi + 1) / 2 + lo];
-            }
-        };
-        if (nc > 0) {
-            wave_gemm<C, VS, M, false>(  // b = J_Cj a
-                [&](auto, auto, int p, int j) { const real_t v_ = JCt[(6 + j) * C + p]; return p < cd ? v_ : zero; },
-                [&](auto, int j, int v) { return AT[j * VS + v]; },
-                [&](int p, int v, real_t d) { Bv[p * VS + v] = d; });
-            DWBC_SYNC();
-            wave_gemm<6, VS, C, false>(  // qb = -Hb b
-                [&](auto, auto, int x, int p) { return -Hb[x * C + p]; },
-                [&](auto, int p, int v) { return Bv[p * VS + v]; },
-                [&](int x, int v, real_t d) { Qb[x * VS + v] = d; });
-            DWBC_SYNC();
-        }
-        DWBC_PSTAMP_M(46);  // W^+: b, qb
-        wave_gemm<6, VS, N, false>(  // cv = A_bb qb + A_bj a   (no contact: cv = A_bj a, qb follows from it)
-            [&](auto, auto sc, int x, int kk) { return apk(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, sc, x, kk); },
-            [&](auto, int kk, int v) {
-                const real_t v_ = (kk < 6 ? Qb + kk * VS : AT + (kk - 6) * VS)[v];
-                return (kk >= 6 || nc > 0) ? v_ : zero;
-            },
-            [&](int x, int v, real_t d) { Cv[x * VS + v] = d; });
+        wave_gemm<NVS, C, C, false>(  // D Lambda_c, one row per slot
+            [&](auto, auto, int v, int p) { return Dm[v * C + p]; },
+            [&](auto, int p, int q_) { return Lam[p * C + q_]; },
+            [&](int v, int q_, real_t d) {
+                DLn[v * C + q_] = d;
+                if (v == GV) L[S::PC + q_] = d;
+            });
         DWBC_SYNC();
+        DWBC_PSTAMP_M(45);  // D Lambda_c, P_C
+        wave_gemm<6, VS, C, false>(  // cv = j_b - J_Cb^T (Lambda_c d): accumulated over the J_t^T / G rows the helper left there
+            [&](auto, auto, int x, int p) { return -JCt[x * C + p]; },
+            [&](auto, int p, int v) { const real_t v_ = DLn[(v < NVS ? v : 0) * C + p]; return v < NVS ? v_ : zero; },
+            [&](int x, int v, real_t d) { Cv[x * VS + v] = d; },
+            [&](int x, int v) { return Cv[x * VS + v]; });
+        DWBC_SYNC();
+        DWBC_PSTAMP_M(46);  // W^+: cv
         if (nc > 0) {
-            wave_gemm<C, VS, 6, false>(  // lam = -Hb^T cv
-                [&](auto, auto, int p, int x) { return -Hb[x * C + p]; },
+            wave_gemm<C, VS, 6, false>(  // E = Lambda_c d + Hb^T cv
+                [&](auto, auto, int p, int x) { return Hb[x * C + p]; },
                 [&](auto, int x, int v) { return Cv[x * VS + v]; },
-                [&](int p, int v, real_t d) { Lm[p * VS + v] = d; });
+                [&](int p, int v, real_t d) { Em[p * VS + v] = d; },
+                [&](int p, int v) { const real_t v_ = DLn[(v < NVS ? v : 0) * C + p]; return v < NVS ? v_ : zero; });
         } else {
-            wave_gemm<6, VS, 6, false>(  // qb = -A_bb^-1 cv
-                [&](auto, auto, int x, int y) { return -Hb[x * C + y]; },
-                [&](auto, int y, int v) { return Cv[y * VS + v]; },
-                [&](int x, int v, real_t d) { Qb[x * VS + v] = d; });
+            for (int idx = th.tid; idx < C * VS; idx += NT) Em[idx] = idx < 6 * VS ? Cv[idx] : zero;  // (the base takes it: see Jx below)
         }
         DWBC_SYNC();
-        DWBC_PSTAMP_M(47);  // W^+: cv, lam
-        // tau_any = [A_jb | A_jj | J_Cj^T] [qb; a; lam], stored transposed over its own operands (TS: M x VS)
-        wave_gemm<M, VS, N + C, true>(
-            [&](auto tc, auto sc, int i, int kk) {
-                constexpr int t = decltype(tc)::value, sb = decltype(sc)::value;
-                constexpr int RMIN = 6 + 16 * t, RMAX = (6 + 16 * t + 15 < N - 1) ? 6 + 16 * t + 15 : N - 1;
-                if constexpr (4 * sb + 3 < N) {
-                    return apk(std::integral_constant<int, RMIN>{}, std::integral_constant<int, RMAX>{}, sc, 6 + i, kk);
-                } else if constexpr (4 * sb >= N) {
-                    return JCt[(6 + i) * C + (kk - N)];  // (rows of inactive contacts are zero)
-                } else {
-                    const int r = 6 + i, c = kk < N ? kk : 0, hi = r >= c ? r : c, lo = r >= c ? c : r;
-                    const real_t va = Ap[hi * (hi + 1) / 2 + lo], vj = JCt[(6 + i) * C + (kk >= N ? kk - N : 0)];
-                    return kk < N ? va : vj;
-                }
-            },
-            [&](auto sc, int kk, int v) {
-                constexpr int sb = decltype(sc)::value;
-                if constexpr (4 * sb >= 6 && 4 * sb + 3 < N) {
-                    return AT[(kk - 6) * VS + v];
-                } else if constexpr (4 * sb >= N) {
-                    const real_t v_ = Lm[(kk - N) * VS + v];
-                    return nc > 0 ? v_ : zero;
-                } else {
-                    const real_t *X = kk < 6 ? Qb + kk * VS : (kk < N ? AT + (kk - 6) * VS : Lm + (kk - N) * VS);
-                    const real_t v_ = X[v];
-                    return (kk < N || nc > 0) ? v_ : zero;
-                }
-            },
-            [&](int i, int v, real_t d) { TS[i * VS + v] = d; });
+        DWBC_PSTAMP_M(47);  // W^+: E
+        {
+            // tau_any = j_j - J_Cj^T E in place; without contacts: j_j - (A_jb A_bb^-1) cv, the helper left A_jb A_bb^-1 (M x 6) in VG's place
+            const real_t *Jx = nc > 0 ? JCt + 6 * C : VG;
+            const int js = nc > 0 ? C : 6;
+            wave_gemm<M, VS, C, false>(
+                [&](auto, auto, int i, int p) { const real_t v_ = Jx[i * js + (p < js ? p : 0)]; return p < js ? -v_ : zero; },
+                [&](auto, int p, int v) { return Em[p * VS + v]; },
+                [&](int i, int v, real_t d) { TS[i * VS + v] = d; },
+                [&](int i, int v) { return TS[i * VS + v]; });
+        }
         DWBC_SYNC();
         DWBC_PSTAMP_M(48);  // W^+: tau_any
         if (k > 0) {  // W^+ a = (I - P) tau_any,  P tau = VG (Vb^T tau)
@@ -842,39 +812,14 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         LANES {
             const int i = lane < M ? lane : 0;
 #pragma unroll
-            for (int v = 0; v < VS; v++) LV(tvo)[v] = TS[i * VS + v];
+            for (int v = 0; v < VS; v++) LV(tv)[v] = TS[i * VS + v];
             if (k > 0) {
                 real_t ga[6];
 #pragma unroll
                 for (int a = 0; a < 6; a++) ga[a] = -VG[i * 6 + a];
-                lds_rows_axpy<6, VS, VS, 3, S::p4_w % 2 == 0>(Wv, ga, LV(tvo));
+                lds_rows_axpy<6, VS, VS, 3, S::p4_w % 2 == 0>(Wv, ga, LV(tv));
             }
         }
-    };
-    PLA(real_t, tv, VS);  // main wave, lane i < M: (W^+ a_v)[i] for every vector slot v: column i of J_kt of every level, torque_grav_[i]
-    if (is_main) {
-        // ---- P_C = Lambda_c (Y G) (wbd.cpp:119), the gravity pre-vector (A^-1 N_c G)[6:] = (A^-1 G - Y^T P_C)[6:], and the joint
-        //      columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level: the vectors a_v, stored transposed AT[j][v]
-        real_t *AT = L + S::at;
-        for (int p_ = th.tid; p_ < C; p_ += NT) {  // (rows and columns of inactive contacts are zero in Lambda_c and in Y G: no conditions)
-            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-#pragma unroll
-            for (int q_ = 0; q_ < C; q_++) a4[q_ & 3] += Lam[p_ * C + q_] * Dm[GV * C + q_];
-            L[S::PC + p_] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        }
-        // the vectors a_v = (J_t A^-1 - D Jbar^T)[v][6:], and with row GV of D = Y G: (A^-1 G - Jbar (Y G))[6:] -- the same thing as
-        // A^-1 G - Y^T P_C (Lambda_c is symmetric); one product on the matrix cores, the riding block read as its starting value
-        wave_gemm<M, NVS, C, true>(
-            [&](auto, auto, int j, int p) { return -JbT[p * N + 6 + j]; },
-            [&](auto, int p, int v) { return Dm[v * C + p]; },
-            [&](int j, int v, real_t d) {
-                AT[j * VS + v] = d;                                                        // (empty slots are zero vectors: J_t A^-1 and D are zero there)
-                if (v < GV) L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d;    // T1x: the chain and the slow route of phase 5 read it
-            },
-            [&](int j, int v) { return AJt[v * N + 6 + j]; });
-        DWBC_SYNC();
-        DWBC_PSTAMP_M(45);  // vectors ready
-        wplus(tv);
         DWBC_PSTAMP_M(49);  // W^+: projected
         LANES {
             if (lane < M) L[S::tg + lane] = LV(tv)[GV];  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
@@ -885,22 +830,39 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         // Lambda_task of every level from the Gram blocks: J_t A^-1 N_c J_t^T = (J_t A^-1) J_t^T - D Lambda_c D^T (wbd.cpp:210), and the
         // condition verdict (dwbc_cycle2.h, task-Jacobian stage)
         int fm = 0;
+        // the joint columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level (T1x: the null-space chain and the slow route of
+        // phase 5 read them), the riding block as the starting value
+        wave_gemm<M, GV, C, false>(
+            [&](auto, auto, int j, int p) { return -JbT[p * N + 6 + j]; },
+            [&](auto, int p, int v) { return Dm[v * C + p]; },
+            [&](int j, int v, real_t d) { L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d; },
+            [&](int j, int v) { return AJt[v * N + 6 + j]; });
         real_t *DLx = L + S::q;  // D Lambda_c (GV x C) in the header scratch (q, G, ...: dead since phase 1b)
         static_assert(GV * C <= S::hend - S::q && NLV <= 2, "D Lambda_c borrows the header scratch; two Lambda_task blocks in the helper's scratch");
+        constexpr int K6 = 6;
+        // the helper's small scratch: Lambda_task^-1 of level 0 | G^-1 (since phase 1b) | Lambda_task^-1 of level 1 | JV | B, X | S
+        real_t *Li0 = L + S::hs, *Gi = L + S::hs + 36, *Li1 = L + S::hs + 72, *JV = L + S::hs + 108, *Bm = L + S::hs + 144, *Sm6 = L + S::hs + 180;
+        static_assert(S::hs_size >= 216, "six 6 x 6 blocks");
         DWBC_SYNC();
         wave_gemm<GV, C, C, false>(
             [&](auto, auto, int i, int p) { return Dm[i * C + p]; },
             [&](auto, int p, int q_) { return Lam[p * C + q_]; },
             [&](int i, int q_, real_t d) { DLx[i * C + q_] = d; });
+        if (k > 0) {  // JV = Jbar[0:k, 6:] Vb  (NwJw = VG X^T with X = (JV G^-1 JV^T)^-1 JV: SPD inverses only, dwbc_cycle2.h)
+            wave_gemm<K6, K6, M, false>(
+                [&](auto, auto, int i, int c) { return JbT[i * N + 6 + c]; },
+                [&](auto, int c, int j) { return Vb[c * K6 + j]; },
+                [&](int i, int j, real_t d) { JV[i * K6 + j] = d; });
+        }
         DWBC_SYNC();
-        wave_gemm<GV, GV, C, false>(  // the diagonal blocks of (J_t A^-1) J_t^T - (D Lambda_c) D^T, level lv at hs + 72 lv, row stride t_lv
+        wave_gemm<GV, GV, C, false>(  // the diagonal blocks of (J_t A^-1) J_t^T - (D Lambda_c) D^T, row stride t_lv
             [&](auto, auto, int i, int p) { return -DLx[i * C + p]; },
             [&](auto, int p, int j) { return Dm[j * C + p]; },
             [&](int i, int j, real_t d) {
                 const int lv = i / T, r = i - lv * T, c_ = j - lv * T;
                 if (c_ >= 0 && c_ < T && lv < su.n_levels) {
                     const int t = su.t_dof[lv];
-                    if (r < t && c_ < t) L[S::hs + 72 * lv + r * t + c_] = d;
+                    if (r < t && c_ < t) (lv == 0 ? Li0 : Li1)[r * t + c_] = d;
                 }
             },
             [&](int i, int j) {
@@ -909,43 +871,37 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 const real_t v_ = BJ[lv * T * T + (i - lv * T) * T + (in ? c_ : 0)];
                 return in ? v_ : real_t(0.0);
             });
+        if (k > 0) {
+            mm_nn<NT>(th, Bm, K6, JV, K6, Gi, K6, K6, K6, K6);                   // B = JV G^-1
+            DWBC_SYNC();
+            mm_nt<NT>(th, Sm6, K6, Bm, K6, JV, K6, K6, K6, K6);                  // S = B JV^T  (SPD)
+        }
         DWBC_SYNC();
+        // the diagonals of Lambda_task^-1 before the inverses overwrite nothing of them (Lt is a block of its own), then all three inverses
+        const int t0 = su.n_levels > 0 ? su.t_dof[0] : 0, t1 = su.n_levels > 1 ? su.t_dof[1] : 0;
+        int ok3[3];
+        spd_inverse_chol6_x3(Li0, t0, L + S::c_Lt, Li1, t1, L + S::c_Lt + T * T, Sm6, k > 0 ? K6 : 0, Sm6, ok3);
         for (int lv = 0; lv < su.n_levels; lv++) {
             const int t = su.t_dof[lv];
-            real_t *Lt = L + S::c_Lt + lv * T * T, *Li = L + S::hs + 72 * lv;
-            const int ok_lt = spd_inverse_small(Li, t, t, Lt, t, L + S::hs + 144);
+            const real_t *Lt = L + S::c_Lt + lv * T * T, *Li = lv == 0 ? Li0 : Li1;
             real_t da = real_t(0.0), dl = real_t(0.0);
             for (int i = 0; i < t; i++) {
                 const real_t a_ = Li[i * t + i], l_ = Lt[i * t + i];
                 da = a_ > da ? a_ : da;
                 dl = l_ > dl ? l_ : dl;
             }
-            if (ok_lt && nc > 0 && da * dl < kCodCondFast) fm |= 1 << lv;
+            if (ok3[lv] && nc > 0 && da * dl < kCodCondFast) fm |= 1 << lv;
         }
-        DWBC_SYNC();
         if (th.tid == 0) flg[1] = (real_t)fm;
-    }
-    if (is_help && k > 0) {
-        // NwJw = VG X^T with X = (JV G^-1 JV^T)^-1 JV, JV = Jbar[0:k, 6:] Vb (dwbc_cycle2.h: SPD inverses only)
-        constexpr int K6 = 6;
-        real_t *JV = L + S::hs, *Gi = L + S::hs + 36, *Bm = L + S::hs + 72, *Sm6 = L + S::hs + 108;
-        DWBC_SYNC();
-        wave_gemm<K6, K6, M, false>(
-            [&](auto, auto, int i, int c) { return JbT[i * N + 6 + c]; },
-            [&](auto, int c, int j) { return Vb[c * K6 + j]; },
-            [&](int i, int j, real_t d) { JV[i * K6 + j] = d; });
-        DWBC_SYNC();
-        mm_nn<NT>(th, Bm, K6, JV, K6, Gi, K6, K6, K6, K6);                       // B = JV G^-1
-        DWBC_SYNC();
-        mm_nt<NT>(th, Sm6, K6, Bm, K6, JV, K6, K6, K6, K6);                      // S = B JV^T  (SPD)
-        DWBC_SYNC();
-        if (!spd_inverse_small(Sm6, K6, K6, Sm6, K6, L + S::hs + 144)) { if (th.tid == 0) flg[0] = real_t(0.0); }
-        mm_nn<NT>(th, Bm, K6, Sm6, K6, JV, K6, K6, K6, K6);                      // X = S^-1 JV
-        DWBC_SYNC();
-        wave_gemm<M, K6, K6, false>(                                             // NwJw = VG X^T
-            [&](auto, auto, int i, int a) { return VG[i * K6 + a]; },
-            [&](auto, int a, int j) { return Bm[j * K6 + a]; },
-            [&](int i, int j, real_t d) { L[S::NwJw + i * K6 + j] = d; });
+        if (k > 0) {
+            if (!ok3[2]) { if (th.tid == 0) flg[0] = real_t(0.0); }
+            mm_nn<NT>(th, Bm, K6, Sm6, K6, JV, K6, K6, K6, K6);                  // X = S^-1 JV
+            DWBC_SYNC();
+            wave_gemm<M, K6, K6, false>(                                         // NwJw = VG X^T
+                [&](auto, auto, int i, int a) { return VG[i * K6 + a]; },
+                [&](auto, int a, int j) { return Bm[j * K6 + a]; },
+                [&](int i, int j, real_t d) { L[S::NwJw + i * K6 + j] = d; });
+        }
         DWBC_SYNC();
     }
     DWBC_PAIR_BARRIER(4);  // ---- B4: J_kt-side vectors in the main wave's registers; Lambda_task, the fast-route mask, NwJw in LDS
@@ -1005,28 +961,23 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
                 Q[idx] = acc;
             }
             DWBC_SYNC();
-            // Q W^+ = (W^+ Q^T)^T: the rows of Q (in range(W) like T1r) through the same inverse-dynamics form, as vector slots 0 .. t-1
-            {
-                real_t *AT = L + S::at;
-                for (int idx = th.tid; idx < M * VS; idx += NT) {
-                    const int j = idx / VS, v = idx - j * VS;
-                    AT[idx] = v < t ? Q[v * M + j] : real_t(0.0);
-                }
-                DWBC_SYNC();
-                PLA(real_t, tq, VS);
-                wplus(tq);  // (its scratch runs over Q: Q is formed again below)
-                DWBC_SYNC();
-                LANES {
-                    if (lane < M) {
+            // Q W^+ = Lambda_t (W^+ T1r^T)^T: W^+ is linear and its values on the rows of T1r are in this lane's registers
+            LANES {
+                real_t tw[TTL];
 #pragma unroll
-                        for (int r = 0; r < TTL; r++) QW[r * M + lane] = LV(tq)[r];
-                    }
+                for (int r = 0; r < TTL; r++) {
+                    real_t v_ = LV(tv)[r];
+                    if constexpr (NLV > 1) v_ = lv == 1 ? LV(tv)[T + r] : v_;
+                    tw[r] = v_;
                 }
-                for (int idx = th.tid; idx < t * M; idx += NT) {
-                    const int i = idx / M, j = idx - i * M;
-                    real_t acc = real_t(0.0);
-                    for (int p = 0; p < t; p++) acc += Lt[i * t + p] * T1rl[p * S::MS + j];
-                    Q[idx] = acc;
+                if (lane < M) {
+#pragma unroll
+                    for (int r = 0; r < TTL; r++) {
+                        real_t acc = real_t(0.0);
+#pragma unroll
+                        for (int r2 = 0; r2 < TTL; r2++) acc += Lt[r * TTL + r2] * tw[r2];
+                        QW[r * M + lane] = acc;
+                    }
                 }
             }
             DWBC_SYNC();

@@ -40,7 +40,9 @@ for i, n in ((5, "stage 3a (J_kt, X, null-space chain)"), (6, "wrench maps (MFMA
     if t[i] > 0:
         print(f"{n:44s} {t[i] - prev:10.0f} {t[i]:12.0f}")
         prev = t[i]
-fine = {51: "phase 1: world inertias", 52: "phase 1: composite inertias (both waves), S", 53: "phase 1: F", 54: "phase 1: mass-matrix pairs staged", 41: "phase 1: CRBA done (A^-1 sweep starts)", 42: "phase 2: Y = J_C A^-1 stored", 43: "phase 2: Lambda_c", 45: "phase 3: P_C, the vectors a_v (T1 joint columns, gravity pre-vector)", 46: "phase 4: b = J_Cj a, qb", 47: "phase 4: cv, lam", 48: "phase 4: tau_any", 49: "phase 4: (I - P) tau_any"}
+fine = {51: "phase 1: world inertias", 52: "phase 1: composite inertias (both waves), S", 53: "phase 1: F", 54: "phase 1: mass-matrix pairs staged", 41: "phase 1: CRBA done (A^-1 sweep starts)", 42: "phase 2: Y = J_C A^-1 stored", 43: "phase 2: Lambda_c", 45: "phase 4: D Lambda_c of every slot, P_C", 46: "phase 4: cv (base residuals)", 47: "phase 4: E = Lambda_c d - lam", 48: "phase 4: tau_any", 49: "phase 4: (I - P) tau_any",
+        16: "level-0 J_kt / X rows in registers", 17: "level-0 chain done", 18: "level-1 J_kt / X rows in registers", 19: "level-1 chain done", 24: "level-0 QP: rows ready", 25: "level-0 QP: committed",
+        26: "redistribution QP: rows ready", 27: "redistribution QP: committed", 28: "torques stored"}
 print("fine stamps of the main wave (cumulative):")
 for i in sorted(fine, key=lambda i_: f[i_]):
     if f[i] > 0:
