@@ -2,31 +2,36 @@
 // instance per SIMD (B <= 4 x CUs: BASELINE configs[1], 1024 instances on 1024 SIMDs).
 //
 // Why: with one wave per instance and one instance per SIMD nothing overlaps -- a lone wave issues one instruction per ~5 cycles and
-// waits out every LDS round trip (SQ_WAIT_ANY 41 %); yet two waves sharing a SIMD each run at nearly their solo speed (the compact
-// kernel at two waves per SIMD does 19.1 M cycles/s against 10.6 M at one: DESIGN.md section 3).  So the cycle's SIDE CHAINS -- work
-// that does not need the column-per-lane registers of the big matrices -- move to a second wave of the same workgroup and run
-// beside the main chain; the two meet at five workgroup barriers:
+// waits out every LDS round trip; yet two waves sharing a SIMD each run at nearly their solo speed.  So the
+// cycle's SIDE CHAINS -- work on LDS-resident thin matrices that does not need the column-per-lane registers of the mass matrix --
+// run on a second wave of the same workgroup beside the main chain; the two meet at workgroup barriers:
 //
-//   main wave (0)                                              | helper wave (1)
-//   kinematics up to the world transforms                      | f* -> LDS
-//   ---------------------------------------------------------- B0 (link frames ready) ----------------------------------------------
-//   world inertias, composite inertias, CRBA, A -> registers,  | contact frames, J_C, internal-wrench basis Vb, its Gram matrix
-//   tree-sparse A^-1 sweep                                     | and G^-1, VG = Vb G^-1; the task Jacobians of every level
-//   ---------------------------------------------------------- B1 (A^-1 in registers, J_C in LDS) ----------------------------------
-//   Y = J_C A^-1, Lambda_c (MFMA tile + 12 x 12 inverse), Jbar^T | (waits)
-//   ---------------------------------------------------------- B2 (Jbar^T in LDS) --------------------------------------------------
-//   A^-1 N_c update, gravity pre-vector, P_C,                  | NwJw = VG X^T chain (J̄_1 Vb, two 6 x 6 SPD inverses, four products)
-//   T1 = J_t A^-1 N_c of every level                           |
-//   ---------------------------------------------------------- B3 (T1, NwJw in LDS) ------------------------------------------------
-//   W + alpha P, the 33-pivot LDS-fed sweep, W^+ correction,   | J_t A^-1 N_c J_t^T, Lambda_task and the condition verdict of every level
-//   gravity torque                                             |
-//   ---------------------------------------------------------- B4 -------------------------------------------------------------------
-//   J_kt / X / null-space chain, wrench maps (MFMA), QP cascade, | (done)
-//   outputs                                                    |
+//   main wave (0)                                                  | helper wave (1)
+//   kinematics up to the world transforms                          | f* -> LDS
+//   -------------------------------------------------------------- B0 (link frames) -------------------------------------------------
+//   world inertias; five of the ten components of the composite    | world inertias (again: no hand-over), the other five components;
+//   inertias (DPP prefix scan); motion axes S                      |
+//   -------------------------------------------------------------- B0a (composite inertias) -----------------------------------------
+//   F, CRBA pairs, columns of A -> registers                       | contact frames, J_C, the task Jacobians of every level
+//   -------------------------------------------------------------- B1a (J_C, J_t, G in LDS) -----------------------------------------
+//   tree-sparse A^-1 sweep, several unrelated pivots per step, the | internal-wrench basis Vb, its Gram matrix, G^-1, VG = Vb G^-1;
+//   pivot columns through LDS; the rows of J_C, of J_t of every    | Hb = (J_Cb^T J_Cb)^-1 J_Cb^T (no contact: A_bb^-1, A_jb A_bb^-1)
+//   level and G ride through it in the 25 idle lanes               |
+//   -------------------------------------------------------------- B1 (Y = J_C A^-1, J_t A^-1, A^-1 G in LDS) ------------------------
+//   Lambda_c^-1 = Y J_C^T (MFMA), 12 x 12 SPD inverse, column of   | D = (J_t A^-1) J_C^T, Y G, the task Gram blocks (J_t A^-1) J_t^T (MFMA);
+//   Jbar^T = Lambda_c Y                                            | J_t^T / G copied to where phase 4 accumulates
+//   -------------------------------------------------------------- B1b, B2 (Jbar^T over J_t^T) ---------------------------------------
+//   W^+ applied to the task rows and the gravity pre-vector as     | Lambda_task^-1 = Gram - (D Lambda_c) D^T of every level, JV = Jbar Vb,
+//   constrained inverse dynamics: D Lambda_c, cv, E, tau_any =     | S = JV G^-1 JV^T (MFMA + two 6 x 6 products); the three 6 x 6 SPD
+//   j_j - J_Cj^T E, (I - P) tau_any (26 MFMA, no product with A);  | inverses in one pass (lane groups); condition verdicts; NwJw = VG X^T
+//   P_C, torque_grav_; the joint columns of T1                     |
+//   -------------------------------------------------------------- B4 ---------------------------------------------------------------
+//   X = J_kt Lambda_t row per lane, null-space chain, wrench maps  | (done)
+//   (MFMA), QP cascade on rows kept per lane, outputs              |
 //
-// The arithmetic of every block is that of dwbc_cycle2.h (same helpers, same order of operations inside a block), so the parity
-// tests of the one-wave kernel apply unchanged; only who executes a block and where it sits in LDS differ.  Lean build only
-// (no dump record, no optional paths: the launcher falls back to the one-wave kernels for those), hqp = true.
+// The arithmetic of the blocks this kernel shares with dwbc_cycle2.h is the same (same helpers, same order of operations inside a
+// block); phases 3 - 4 are its own (see there).  Lean build only (no dump record, no optional paths: the launcher falls back to the
+// one-wave kernels for those), hqp = true.
 #pragma once
 #include "dwbc_cycle2.h"
 
@@ -824,19 +829,19 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
         LANES {
             if (lane < M) L[S::tg + lane] = LV(tv)[GV];  // torque_grav_ = W^+ (A^-1 N_c G)[6:]   (wbd.cpp:190)
         }
+        // the joint columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level (T1x: the null-space chain and the slow route of
+        // phase 5 read them), the riding block as the starting value -- here, because the helper's chain is the longer one
+        wave_gemm<M, GV, C, false>(
+            [&](auto, auto, int j, int p) { return -JbT[p * N + 6 + j]; },
+            [&](auto, int p, int v) { return Dm[v * C + p]; },
+            [&](int j, int v, real_t d) { L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d; },
+            [&](int j, int v) { return AJt[v * N + 6 + j]; });
         DWBC_SYNC();
     }
     if (is_help) {
         // Lambda_task of every level from the Gram blocks: J_t A^-1 N_c J_t^T = (J_t A^-1) J_t^T - D Lambda_c D^T (wbd.cpp:210), and the
         // condition verdict (dwbc_cycle2.h, task-Jacobian stage)
         int fm = 0;
-        // the joint columns of T1 = J_t A^-1 N_c = J_t A^-1 - D Jbar^T of every level (T1x: the null-space chain and the slow route of
-        // phase 5 read them), the riding block as the starting value
-        wave_gemm<M, GV, C, false>(
-            [&](auto, auto, int j, int p) { return -JbT[p * N + 6 + j]; },
-            [&](auto, int p, int v) { return Dm[v * C + p]; },
-            [&](int j, int v, real_t d) { L[S::T1x + (v / T) * T * S::MS + (v % T) * S::MS + j] = d; },
-            [&](int j, int v) { return AJt[v * N + 6 + j]; });
         real_t *DLx = L + S::q;  // D Lambda_c (GV x C) in the header scratch (q, G, ...: dead since phase 1b)
         static_assert(GV * C <= S::hend - S::q && NLV <= 2, "D Lambda_c borrows the header scratch; two Lambda_task blocks in the helper's scratch");
         constexpr int K6 = 6;

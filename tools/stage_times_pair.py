@@ -30,10 +30,12 @@ wbc._L.dwbc_batch_get(wbc._h, 13, d.ctypes.data, nb)
 d = d.reshape(B, -1)
 t = np.median(d[:, 74:90].astype(np.float64), axis=0)      # DG_TIME: main arrivals 0..4, stamps 5.., 15
 f = np.median(d[:, 90:90 + 64].astype(np.float64), axis=0)  # DG_FTIME: helper arrivals 0..4, main departures 8..12
-names = ["B0 link frames", "B1 A^-1 | J_C, Vb, VG, J_t", "B2 Jbar^T", "B3 A^-1 N_c, T1 | NwJw", "B4 W^+ | Lambda_t"]
+names = ["B0 link frames", "B1 A^-1, riding rows | J_C, Vb, VG, Hb", "B2 Lambda_c, Jbar^T | D, Gram blocks", "B3 (gone)", "B4 W^+ a, T1 | Lambda_t, NwJw"]
 print(f"{'barrier':32s} {'main arrives':>13s} {'helper arrives':>15s} {'main leaves':>12s} {'main waited':>12s}")
 prev = 0.0
 for i, n in enumerate(names):
+    if t[i] == 0 and f[i] == 0:
+        continue  # (a barrier this build does not have)
     print(f"{n:32s} {t[i]:13.0f} {f[i]:15.0f} {f[8 + i]:12.0f} {f[8 + i] - t[i]:12.0f}   (main worked {t[i] - prev:.0f} since the last barrier)")
     prev = f[8 + i]
 for i, n in ((5, "stage 3a (J_kt, X, null-space chain)"), (6, "wrench maps (MFMA), QP set-up"), (7, "level-0 QP"), (8, "level-1 QP"), (15, "redistribution QP + outputs")):
