@@ -35,11 +35,11 @@ if ROOT not in sys.path:
 F_ALG = 1.34e6          # flop per cycle, double support 2-level with tau limit (SURVEY 8d / BASELINE.md 3)
 PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (public spec; MI355X_MICROARCH.md lists no fp64 row)
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak (public spec), for --dtype f32 runs
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_final_pmc_summary.json")  # rocprofv3 --pmc passes of this command
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04c_pmc_summary.json")  # rocprofv3 --pmc passes of this command
 # The governing roof is fp64 arithmetic throughput: 78.6 TFLOP/s whether issued as VALU FMAs or as MFMA f64 (same rate on
 # MI355X).  The contract knows two classes of roof, "hbm" and "mfma" (= compute); this kernel belongs to the compute class, and the
 # label says which pipe its fp64 work is actually issued on so that nobody reads it as a claim of matrix-core use.
-ROOF_BOUND = "fp64-fma (compute roof: the contract's 'mfma' class; VALU FMAs + two MFMA f64 tile products per cycle)"
+ROOF_BOUND = "fp64-fma (compute roof: the contract's 'mfma' class; VALU FMAs + ~100 MFMA f64 16x16x4 tile instructions per cycle)"
 ROOF_NOTE = ("compute roof = fp64 FMA throughput, 78.6 TFLOP/s public spec (vector rate = matrix rate on MI355X); algorithmic flop of the "
              "reference's dense formulas; kernel_ms = HIP-event average over max(steps, 200) back-to-back launches")
 
