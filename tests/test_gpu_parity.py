@@ -648,7 +648,7 @@ def test_near_singular_knee_truncated_pseudo_inverse_on_device():
         assert err[3:].max() < 5e-5, err
 
 
-@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "mixed", "one_level"])
+@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "mixed", "one_level", "free"])
 def test_paired_two_wave_kernel_vs_oracle(cfg):
     """Batches of at most one instance per SIMD run the lean cycle with TWO wavefronts per instance (dwbc_cycle2p.h: the side chains
     -- contact Jacobians, internal-wrench algebra, task Jacobians, Lambda_task -- on a helper wave beside the main chain, five
@@ -660,9 +660,11 @@ def test_paired_two_wave_kernel_vs_oracle(cfg):
     tasks, kw = cases.TASKS_2LEVEL, dict(seed=20251226 + 12)
     if cfg == "ds_yaw":
         kw["yaw"] = True
-    elif cfg == "mixed":
+    elif cfg in ("mixed", "free"):
         kw["contact_mode"] = "mixed"
     q, flags, fstar = cases.synth_batch(B, **kw)
+    if cfg == "free":
+        flags[::3] = 0  # a third of the batch without any active contact
     if cfg == "one_level":
         tasks, fstar = [cases.TASKS_2LEVEL[0]], fstar[:, :6].copy()
     tau_r, wr_r, st_r, _ = _oracle(B, q, flags, fstar, tasks=tasks)

@@ -38,7 +38,7 @@ def test_emulated_kernel_on_golden_cases(case):
 
 
 @pytest.mark.parametrize("compact", [False, True, "pair"])
-@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit"])
+@pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit", "free"])
 def test_emulated_kernel_vs_oracle_batches(cfg, compact):
     """compact = True: the lean build on the 20 KB LDS map (Lds3 of dwbc_cycle2.h: the throughput kernel of batches beyond four
     instances per CU) with LDS poisoned by NaN before every instance -- a block read before anything wrote it shows in the result."""
@@ -59,7 +59,11 @@ def test_emulated_kernel_vs_oracle_batches(cfg, compact):
         kw["contact_mode"] = "mixed"
     elif cfg == "nolimit":
         lim = None
+    elif cfg == "free":
+        kw["contact_mode"] = "mixed"
     q, fl, fs = cases.synth_batch(B, **kw)
+    if cfg == "free":
+        fl[::3] = 0  # no active contact at all on a third of the batch (the base carries the task forces: Hb = A_bb^-1 in dwbc_cycle2p.h)
     e = Emu(cases.URDF, contacts, tasks, lim)
     r = e.run(q, fl, fs, compact=compact)
     tau_r, wr_r, st_r, _ = _oracle(q, fl, fs, contacts, tasks, lim)
