@@ -262,6 +262,62 @@ DWBC_WDEV void wave_gemm(FA fa, FB fb, FS fstore) {
     wave_gemm<MR, NCV, KV, SYNC_STORE>(fa, fb, fstore, [](int, int) { return real_t(0.0); });
 }
 
+// Lambda_c^-1 -> Lambda_c for two active contacts, IN PLACE (M: 12 x 12, dense): spd_inverse_small's Jacobi-scaled symmetric sweep
+// (dwbc_cycle2.h: same scaling, same pivots, same arithmetic per row update) with the pivot column fed through LDS instead of
+// v_readlane -- per pivot one ds_write_b64 and six broadcast ds_read_b128 against 24 v_readlane + 12 s_nop.  The matrix sits in
+// registers during the sweep, so its own LDS block serves as the column buffer; scl: 12 doubles for the scale factors.
+template <class R>
+DWBC_WDEV int spd_inverse12_lds(R *Mx, R *Out, R *scl) {
+#if defined(DWBC_HOST_EMU)
+    return spd_inverse_small(Mx, 12, 12, Out, 12, scl);
+#else
+    static_assert(sizeof(R) == 8, "fp64 build");
+    const int lane = (int)(threadIdx.x & 63u);
+    DWBC_SYNC();
+    double s[12], dg, dsc;
+    {
+        const int col = lane < 12 ? lane : 0;
+        const double a = Mx[col * 12 + col];
+        int e2 = 0;
+        (void)frexp(a > 0.0 ? a : 1.0, &e2);
+        dsc = (lane < 12 && a > 0.0) ? ldexp(1.0, -(e2 >> 1)) : 1.0;
+        if (lane < 12) scl[lane] = dsc;
+    }
+    DWBC_SYNC();
+    {
+        const int col = lane < 12 ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const double v_ = Mx[i * 12 + col] * scl[i] * dsc;
+            s[i] = lane < 12 ? v_ : 0.0;
+        }
+        const double d_ = Mx[col * 12 + col] * dsc * dsc;
+        dg = lane < 12 ? d_ : 1.0;
+    }
+    DWBC_SYNC();  // (the matrix is in registers: its block is the column buffer now)
+    int ok = 1;
+    {
+        DWBC_LANE_OPAQUE(lp);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = (i == lp) ? dg - 1.0 : s[i];
+    }
+    double dg2 = dg - 2.0;
+    lds_pivot<12, 11, 0>(s, dg2, ok, (unsigned)(size_t)Mx, lane);
+    ok = DWBC_FLAG_UNIFORM(ok);
+    DWBC_SYNC();
+    if (lane < 12) {
+        DWBC_LANE_OPAQUE(le);
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const double v_ = (i == le) ? -dg2 : -s[i];
+            Out[i * 12 + lane] = v_ * scl[i] * dsc;
+        }
+    }
+    DWBC_SYNC();
+    return ok;
+#endif
+}
+
 // wave: 0 = main, 1 = helper (device); -1 = both roles one after the other in one thread of control (host emulation)
 template <int N, int NB, int NLV, int NT, class Topo>
 DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchIO &io, int inst, real_t *L) {
@@ -670,37 +726,14 @@ DWBC_DEV void cycle_instance_v2p(int wave, Thr th, const Setup &su, const BatchI
     // ================= phase 2: Lambda_c, Jbar^T (main) | D, Y G, the task Gram blocks (helper) =================
     if (is_main) {
         DWBC_PSTAMP_M(42);  // Y = J_C A^-1 stored
-#if !defined(DWBC_HOST_EMU)
-        if constexpr (sizeof(real_t) == 8) {  // J A^-1 J^T = Y J_C^T on one accumulator tile (see dwbc_cycle2_stage1.inc)
-            typedef double lc_d4 __attribute__((ext_vector_type(4)));
-            const int li = lane & 15, lk = lane >> 4;
-            lc_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s_ = 0; s_ < (N + 3) / 4; s_++) {
-                const int c = 4 * s_ + lk;
-                const bool in = c < N;
-                const int cc = in ? c : N - 1;
-                real_t av = Yt[cc * C + (li < C ? li : 0)], bv = JCt[cc * C + (li < C ? li : 0)];
-                av = in ? av : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-            if (li < C) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) L[S::c_s2 + (lk + 4 * r) * C + li] = acc[r];
-            }
-        } else
-#endif
-        for (int idx = th.tid; idx < C * C; idx += NT) {
-            const int i = idx / C, j = idx - i * C;
-            real_t a4[4] = {real_t(0.0), real_t(0.0), real_t(0.0), real_t(0.0)};
-            if (i < cd && j < cd) {
-#pragma unroll
-                for (int c = 0; c < N; c++) a4[c & 3] += Yt[c * C + i] * JCt[c * C + j];
-            }
-            L[S::c_s2 + idx] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        }
-        if (cd > 0) {
-            if (!spd_inverse_small(L + S::c_s2, C, cd, Lam, C, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115)
+        wave_gemm<C, C, N, false>(  // J A^-1 J^T = Y J_C^T (rows and columns of an inactive contact are zero: Y and J_C are)
+            [&](auto, auto, int i, int c) { return Yt[c * C + i]; },
+            [&](auto, int c, int j) { return JCt[c * C + j]; },
+            [&](int i, int j, real_t d) { L[S::c_s2 + i * C + j] = d; });
+        if (cd == C) {
+            if (!spd_inverse12_lds(L + S::c_s2, Lam, L + S::c_s1)) st_contact = 0;  // Lambda_c (wbd.cpp:115), in place
+        } else if (cd > 0) {
+            if (!spd_inverse_small(L + S::c_s2, C, cd, Lam, C, L + S::c_s1)) st_contact = 0;
         } else {
             for (int idx = th.tid; idx < C * C; idx += NT) Lam[idx] = real_t(0.0);
         }
