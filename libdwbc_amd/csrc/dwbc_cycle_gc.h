@@ -13,8 +13,41 @@
 // closed form for any number of contacts.  Lean scope: hqp = true, link tasks, f* from SetTaskSpace, cold-started QPs.
 #pragma once
 #include "dwbc_cycle2.h"
+#include "dwbc_cycle2p.h"  // wave_gemm
 
 namespace dwbc {
+
+// C (m x n) = op(A) op(B) for LDS-resident matrices of run-time size on the matrix cores (wave_gemm, dwbc_cycle2p.h): tiles of 16 x 16
+// up to the compile-time bounds MAXM x MAXN x MAXK, every entry outside the run-time sizes read as zero and not stored.
+// OP 0: A (m x k) B (k x n);  1: A (m x k) B^T (B n x k);  2: A^T (A k x m) B (k x n).  The thread-per-output loops this replaces
+// (mm_nn / mm_nt / mm_tn of dwbc_cycle.h: every term of a dot product waits out its own pair of LDS reads) were 60 % of this
+// kernel's stage 1.  C must not alias A or B.  One wave; the caller fences.
+template <int MAXM, int MAXN, int MAXK, int OP>
+DWBC_WDEV void mmg(real_t *Cm, int ldc, const real_t *A, int lda, const real_t *B, int ldb, int m, int kk, int n) {
+    constexpr int NCT = (MAXN + 15) / 16;
+    static_for<0, NCT>([&](auto ctc) {
+        constexpr int c0 = 16 * decltype(ctc)::value;
+        if (c0 < n) {
+            wave_gemm<MAXM, (MAXN - c0 < 16 ? MAXN - c0 : 16), MAXK, false>(
+                [&](auto, auto, int i, int k_) {
+                    const bool in = i < m && k_ < kk;
+                    const int ii = i < m ? i : 0, k2 = k_ < kk ? k_ : 0;
+                    const real_t v_ = OP == 2 ? A[k2 * lda + ii] : A[ii * lda + k2];
+                    return in ? v_ : real_t(0.0);
+                },
+                [&](auto, int k_, int j) {
+                    const int col = c0 + j;
+                    const bool in = k_ < kk && col < n;
+                    const int cc = col < n ? col : 0, k2 = k_ < kk ? k_ : 0;
+                    const real_t v_ = OP == 1 ? B[cc * ldb + k2] : B[k2 * ldb + cc];
+                    return in ? v_ : real_t(0.0);
+                },
+                [&](int i, int j, real_t d) {
+                    if (i < m && c0 + j < n) Cm[i * ldc + c0 + j] = d;
+                });
+        }
+    });
+}
 
 // TG: task dof per level the map and the QPs are sized for (6: the product kernels' limit; 12: two 6D links on one level)
 template <int N, int NB, int NCC, int TG = kMaxTaskDof>
@@ -83,14 +116,18 @@ struct LdsG {
     static constexpr int qp_V = t_fv + C;             // QN
     static constexpr int qp_x = qp_V + QN;            // QN
     static constexpr int t_end = qp_x + QN;
+    static constexpr int colA = (tmp + 1) & ~1, colW = (c_s1 + 1) & ~1;  // 16-byte aligned pivot-column buffers of the two big sweeps (64 doubles each)
+    static_assert(colA + 64 <= k_end && colW + 64 <= c_s2, "pivot-column buffers");
     static constexpr int total = max2(max2(k_end, c_end), t_end);
     static constexpr int total_bytes = total * (int)sizeof(real_t) + 64;
 };
 
 // SPD inverse with one column per lane in registers (the symmetric sweep of dwbc_cycle2.h), any size up to 56: Sin NN x NN (ld) ->
 // Out (ldo).  Same arithmetic role as Eigen's llt().solve(I) (reference src/dwbc.cpp:307).
+// colbuf: 64 doubles of LDS -- the pivot column goes through it (sweep_inverse_lds: one ds_write_b64 and the column read back in 16-byte
+// broadcast pieces per pivot, against two v_readlane and a hazard s_nop per ROW of every pivot); nullptr: the v_readlane feed
 template <int NN>
-DWBC_DEVN int spd_inverse_reg(const real_t *Sin, int ld, real_t *Out, int ldo) {
+DWBC_DEVN int spd_inverse_reg(const real_t *Sin, int ld, real_t *Out, int ldo, real_t *colbuf = nullptr) {
     DWBC_LANE_DECL;
     PLA(real_t, s, NN);
     PL(real_t, dg);
@@ -101,7 +138,12 @@ DWBC_DEVN int spd_inverse_reg(const real_t *Sin, int ld, real_t *Out, int ldo) {
         for (int i = 0; i < NN; i++) LV(s)[i] = (lane < NN) ? Sin[i * ld + col] : real_t(0.0);
         LV(dg) = (lane < NN) ? Sin[col * ld + col] : real_t(1.0);
     }
-    const int ok = sweep_inverse_rl<NN>(s, dg, NN);
+    DWBC_SYNC();
+    const int ok = colbuf ? sweep_inverse_lds<NN>(s, dg, colbuf) : sweep_inverse_rl<NN>(s, dg, NN);
+#if !defined(DWBC_HOST_EMU)
+#pragma unroll
+    for (int i = 0; i < NN; i++) asm volatile("" : "+v"(s[i]));  // (the stores below are conditional: see sweep_inverse_tree_lds, dwbc_cycle2.h)
+#endif
     DWBC_SYNC();
     LANES {
         if (lane < NN) {
@@ -440,7 +482,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_STAMP(0);  // kinematics + CRBA
     int st_contact = 1;
     // A_inv = llt(A).solve(I)  (dwbc.cpp:307), in place (the columns live in registers meanwhile)
-    if (!spd_inverse_reg<N>(L + S::bufA, N, L + S::bufA, N)) st_contact = 0;
+    if (!spd_inverse_reg<N>(L + S::bufA, N, L + S::bufA, N, L + S::colA)) st_contact = 0;  // (pivot column over the dead kinematics scratch)
     DWBC_STAMP(1);  // A^-1
 
     // ================= stage 1: contacts (dwbc.h:432-474, dwbc.cpp:433-478, wbd.cpp:108-143) =================
@@ -477,26 +519,27 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
     DWBC_SYNC();
     {
         real_t *Ai = L + S::bufA, *JC = L + S::JC, *Y = L + S::c_Y, *Lam = L + S::Lam, *JbT = L + S::JbT, *AiNc = L + S::bufN;
-        mm_nn<NT>(th, Y, N, JC, N, Ai, N, cd, N, N);                 // Y = J_C A^-1
+        mmg<C, N, N, 0>(Y, N, JC, N, Ai, N, cd, N, N);                // Y = J_C A^-1
         DWBC_SYNC();
-        mm_nt<NT>(th, L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);      // J A^-1 J^T
+        mmg<C, C, N, 1>(L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);     // J A^-1 J^T
         if (cd > 0) {
             // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan in LDS, as the reference's .inverse() -- 45 k cycles for 18 x 18, and worth them: the
             // scaled register sweep (spd_inverse_scaled) left two three-contact instances in 6000 at 3e-6 .. 5e-6 Nm
             const real_t cond = gj_inverse_wave<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
             if (!(cond > real_t(1e-14))) st_contact = 0;
         }
-        mm_nn<NT>(th, JbT, N, Lam, cd, Y, N, cd, cd, N);             // Jbar^T = Lambda J A^-1 (wbd.cpp:116)
+        mmg<C, N, C, 0>(JbT, N, Lam, cd, Y, N, cd, cd, N);            // Jbar^T = Lambda J A^-1 (wbd.cpp:116)
         DWBC_SYNC();
         DWBC_STAMP(2);  // J_C, Y, Lambda_c, Jbar
         // A^-1 N_c = A^-1 - Y^T Jbar^T   (wbd.cpp:117-118 without materialising N_c)
-        for (int idx = th.tid; idx < N * N; idx += NT) {
-            const int i = idx / N, j = idx - i * N;
-            real_t s = Ai[idx];
-            _Pragma("unroll 6")
-            for (int p = 0; p < cd; p++) s -= Y[p * N + i] * JbT[p * N + j];
-            AiNc[idx] = s;
-        }
+        static_for<0, (N + 15) / 16>([&](auto ctc) {
+            constexpr int c0 = 16 * decltype(ctc)::value;
+            wave_gemm<N, (N - c0 < 16 ? N - c0 : 16), C, false>(
+                [&](auto, auto, int i, int p) { const real_t v_ = Y[(p < cd ? p : 0) * N + i]; return p < cd ? -v_ : real_t(0.0); },
+                [&](auto, int p, int j) { const real_t v_ = JbT[(p < cd ? p : 0) * N + c0 + j]; return p < cd ? v_ : real_t(0.0); },
+                [&](int i, int j, real_t d) { AiNc[i * N + c0 + j] = d; },
+                [&](int i, int j) { return Ai[i * N + c0 + j]; });
+        });
         DWBC_SYNC();
         DWBC_STAMP(3);  // A^-1 N_c
         // ---- W^+ and NwJw.  null(W) is known in closed form: W = S A^-1 N_c S^T vanishes exactly on
@@ -526,25 +569,21 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             // G = Vb^T Vb, G^-1, VG = Vb G^-1;  projector on null(W):  P = VG Vb^T
             real_t *Gm = L + S::c_s2, *cb = L + S::c_s1;
-            mm_tn<NT>(th, Gm, k, Vb, k, Vb, k, k, M, k);
-            spd_inverse_scaled<S::K>(Gm, k, k, Gm, k, cb);
-            mm_nn<NT>(th, L + S::c_VG, k, Vb, k, Gm, k, M, k, k);
+            mmg<S::K, S::K, M, 2>(Gm, k, Vb, k, Vb, k, k, M, k);
             DWBC_SYNC();
-            mm_nt<NT>(th, P, M, L + S::c_VG, k, Vb, k, M, k, M);
+            spd_inverse_scaled<S::K>(Gm, k, k, Gm, k, cb);
+            mmg<M, S::K, S::K, 0>(L + S::c_VG, k, Vb, k, Gm, k, M, k, k);
+            DWBC_SYNC();
+            mmg<M, M, S::K, 1>(P, M, L + S::c_VG, k, Vb, k, M, k, M);
             DWBC_SYNC();
             // NwJw = Vb (Jbar[0:k,6:] Vb)^-1   (wbd.cpp:128; invariant to the choice of basis of span(V2^T)).  Jbar1 Vb is a general k x k
             // matrix: pivoted Gauss-Jordan, as the reference's .inverse().  (The SPD-only form of the product kernels, VG JV^T (JV G^-1 JV^T)^-1,
             // squares its condition number: measured 5e-6 Nm on one three-contact instance in 6000, 1e-8 with the direct inverse.)
-            for (int idx = th.tid; idx < k * k; idx += NT) {
-                const int i = fdk.div(idx), j = idx - i * k;
-                real_t s = real_t(0.0);
-                _Pragma("unroll 8")
-                for (int c2 = 0; c2 < M; c2++) s += JbT[i * N + 6 + c2] * Vb[c2 * k + j];
-                Gm[idx] = s;
-            }
+            mmg<S::K, S::K, M, 0>(Gm, k, JbT + 6, N, Vb, k, k, M, k);  // Jbar[0:k, 6:] Vb
+            DWBC_SYNC();
             const real_t cond = gj_inverse_wave<NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
             if (!(cond > real_t(1e-13))) st_contact = 0;
-            mm_nn<NT>(th, L + S::NwJw, k, Vb, k, Gm, k, M, k, k);
+            mmg<M, S::K, S::K, 0>(L + S::NwJw, k, Vb, k, Gm, k, M, k, k);
             DWBC_SYNC();
         }
         DWBC_STAMP(4);  // Vb, NwJw, projector
@@ -560,7 +599,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         }
         DWBC_SYNC();
         {
-            if (!spd_inverse_reg<M>(W1, M, W1, M)) st_contact = 0;
+            if (!spd_inverse_reg<M>(W1, M, W1, M, L + S::colW)) st_contact = 0;  // (pivot column over the idle Gauss-Jordan scratch)
             const real_t ia = alpha != real_t(0.0) ? real_t(1.0) / alpha : real_t(0.0);
             for (int idx = th.tid; idx < M * M; idx += NT) Winv[idx] = W1[idx] - (k > 0 ? P[idx] * ia : real_t(0.0));  // (in place: Winv is W1)
             DWBC_SYNC();
@@ -624,20 +663,15 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             }
             DWBC_SYNC();
             // --- CalculateJKT (wbd.cpp:207-213)
-            mm_nn<NT>(th, T1, N, Jt, N, AiNc, N, t, N, N);           // J_t A^-1 N_c
+            mmg<T, N, N, 0>(T1, N, Jt, N, AiNc, N, t, N, N);          // J_t A^-1 N_c
             DWBC_SYNC();
-            mm_nt<NT>(th, L + S::t_s2, t, T1, N, Jt, N, t, N, t);
+            mmg<T, T, N, 1>(L + S::t_s2, t, T1, N, Jt, N, t, N, t);
             gj_inverse_wave<NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task (plain inverse, wbd.cpp:210)
-            for (int idx = th.tid; idx < t * M; idx += NT) {             // Q = (Lambda J A^-1 N_c)[:,6:]
-                const int i = idx / M, j = idx - i * M;
-                real_t s = real_t(0.0);
-                for (int p = 0; p < t; p++) s += Lt[i * t + p] * T1[p * N + 6 + j];
-                Q[idx] = s;
-            }
+            mmg<T, M, T, 0>(Q, M, Lt, t, T1 + 6, N, t, t, M);           // Q = (Lambda J A^-1 N_c)[:,6:]
             DWBC_SYNC();
-            mm_nn<NT>(th, QW, M, Q, M, Winv, M, t, M, M);              // Q W^+
+            mmg<T, M, M, 0>(QW, M, Q, M, Winv, M, t, M, M);            // Q W^+
             DWBC_SYNC();
-            mm_nt<NT>(th, L + S::t_s2, t, QW, M, Q, M, t, M, t);       // Q W^+ Q^T
+            mmg<T, T, M, 1>(L + S::t_s2, t, QW, M, Q, M, t, M, t);      // Q W^+ Q^T
             DWBC_SYNC();
             // PinvCODWB (wbd.cpp:5-30, 212): the inverse when the block has full rank, the rank-revealing pseudo-inverse otherwise
             // (threshold 1e-6 on the pivots of a column-pivoted QR, as in the product kernels)
@@ -647,21 +681,15 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 pinv_cod_small<NT>(th, L + S::t_s2, t, kCodThreshold, L + S::t_s3, cod, cod + T * T, cod + 2 * T * T, cod + 3 * T * T);
                 DWBC_SYNC();
             }
-            for (int idx = th.tid; idx < M * t; idx += NT) {             // J_kt = W^+ Q^T pinv(.)
-                const int i = fdt.div(idx), j = idx - i * t;
-                real_t s = real_t(0.0);
-                for (int p = 0; p < t; p++) s += QW[p * M + i] * L[S::t_s3 + p * t + j];
-                Jkt[idx] = s;
-            }
+            mmg<M, T, T, 2>(Jkt, t, QW, M, L + S::t_s3, t, M, t, t);     // J_kt = W^+ Q^T pinv(.)
             DWBC_SYNC();
             // X = J_kt Lambda ;  Y = (J_t A^-1 N_c)[:,6:]   => Null_i = Null_{i-1} (I - X Y)   (wbd.cpp:257-261)
             real_t *X = (lv < kMaxLevels - 1) ? L + S::Xl + lv * M * T : L + S::t_QW;
+            mmg<M, T, T, 0>(X, T, Jkt, t, Lt, t, M, t, t);
+            DWBC_SYNC();
             for (int idx = th.tid; idx < M * t; idx += NT) {
                 const int i = fdt.div(idx), j = idx - i * t;
-                real_t s = real_t(0.0);
-                for (int p = 0; p < t; p++) s += Jkt[i * t + p] * Lt[p * t + j];
-                X[i * T + j] = s;
-                U[i * T + j] = s;
+                U[i * T + j] = X[i * T + j];
             }
             if (lv < kMaxLevels - 1)
                 for (int idx = th.tid; idx < t * M; idx += NT) {
@@ -674,13 +702,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
                 const int tp = su.t_dof[pl];
                 const real_t *Xp = L + S::Xl + pl * M * T, *Yp = L + S::Yl + pl * T * M;
                 DWBC_SYNC();
-                for (int idx = th.tid; idx < tp * t; idx += NT) {       // Z = Yp U  (tp x t)
-                    const int i = fdt.div(idx), j = idx - i * t;
-                    real_t s = real_t(0.0);
-                    _Pragma("unroll 8")
-                    for (int c = 0; c < M; c++) s += Yp[i * M + c] * U[c * T + j];
-                    L[S::t_s2 + idx] = s;
-                }
+                mmg<T, T, M, 0>(L + S::t_s2, t, Yp, M, U, T, tp, M, t);  // Z = Yp U  (tp x t)
                 DWBC_SYNC();
                 for (int idx = th.tid; idx < M * t; idx += NT) {
                     const int i = fdt.div(idx), j = idx - i * t;
