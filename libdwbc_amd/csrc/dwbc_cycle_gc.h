@@ -195,58 +195,80 @@ DWBC_DEVN int spd_inverse_scaled(const real_t *Sin, int ld, int n, real_t *Out, 
     return ok;
 }
 
-// Gauss-Jordan inverse with partial pivoting (gj_inverse of dwbc_cycle.h; stands in for Eigen's .inverse(), reference src/wbd.cpp:115,128)
-// for one wavefront and n <= 64: the pivot search is one LDS read per lane and a wave arg-max instead of n dependent reads by every lane
-// (18 x 70 cycles per pivot).  W: n x 2n scratch.  Returns min |pivot| / max |pivot|.
-template <int NT>
-DWBC_DEVN real_t gj_inverse_wave(Thr th, const real_t *A, int lda, int n, real_t *Ai, int ldi, real_t *W) {
+// Inverse of a small general matrix as the reference's .inverse() behaves where it matters here: Gauss-Jordan with partial pivoting on
+// [A | I] (largest remaining element of the column), the matrix in REGISTERS, one row per lane: the factor of row i is the lane's own element, the scaled pivot row goes through LDS once per pivot
+// (W: 2 NMAX doubles) and every lane updates its row with 2 NMAX FMAs -- no element of the augmented matrix travels through LDS per
+// update (round 3 kept the augmented matrix in LDS and touched all n x 2n elements there per pivot: 45 k cycles for 18 x 18, ~17 k now).  Rows are never exchanged: the lane that
+// served as the pivot of column c holds row c of the inverse at the end.  NMAX: compile-time bound of n (the pivot loop is unrolled
+// over it, so the pivot element is a static register).  In place allowed.  Returns the smallest / largest pivot magnitude.
+template <int NMAX, int NT>
+DWBC_DEVN real_t gj_inverse_rows(Thr th, const real_t *A, int lda, int n, real_t *Ai, int ldi, real_t *W) {
     DWBC_LANE_DECL;
-    const int w = 2 * n;
-    const FastDiv fdw(w), fdn(n);  // (a run-time integer division costs ~40 VALU instructions: 11 of them per pivot in the elimination loop)
-    DWBC_SYNC();
-    for (int idx = th.tid; idx < n * w; idx += NT) {
-        int i = fdw.div(idx), j = idx - i * w;
-        W[idx] = j < n ? A[i * lda + j] : (j - n == i ? real_t(1.0) : real_t(0.0));
-    }
-    real_t pmin = kF32 ? real_t(1e30) : real_t(1e300), pmax = real_t(0.0);
+    constexpr int W2 = 2 * NMAX;
+    static_assert(NMAX <= 32, "one row per lane, 2 NMAX registers per row");
+    PLA(real_t, r, W2);
+    PL(int, used);
+    PL(int, mycol);
     PL(real_t, pv);
     PL(int, pk);
-    for (int c = 0; c < n; c++) {
-        DWBC_SYNC();
-        LANES {
-            const bool in = lane >= c && lane < n;
-            LV(pv) = in ? -fabs(W[(in ? lane : c) * w + c]) : DWBC_QP_INF;
-            LV(pk) = lane;
+    DWBC_SYNC();
+    LANES {
+        const int row = lane < n ? lane : 0;
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+            const real_t v_ = A[row * lda + (j < n ? j : 0)];
+            LV(r)[j] = (lane < n && j < n) ? v_ : real_t(0.0);
+            LV(r)[NMAX + j] = (lane < n && j == lane) ? real_t(1.0) : real_t(0.0);
         }
-        real_t bneg;
-        int p;
-        WAVE_ARGMIN(pv, pk, bneg, p);
-        const real_t best = -bneg;
-        pmin = best < pmin ? best : pmin;
-        pmax = best > pmax ? best : pmax;
-        DWBC_SYNC();
-        if (p != c)
-            for (int j = th.tid; j < w; j += NT) { real_t t = W[c * w + j]; W[c * w + j] = W[p * w + j]; W[p * w + j] = t; }
-        DWBC_SYNC();
-        const real_t piv = W[c * w + c];
-        const real_t inv = piv != real_t(0.0) ? real_t(1.0) / piv : real_t(0.0);
-        DWBC_SYNC();
-        for (int j = th.tid; j < w; j += NT) W[c * w + j] *= inv;
-        DWBC_SYNC();
-        // eliminate: element (i, j) -= W[i][c] * W[c][j]; column c itself is read before it is overwritten
-        for (int idx = th.tid; idx < n * w; idx += NT) {
-            int i = fdw.div(idx), j = idx - i * w;
-            if (i == c || j == c) continue;
-            W[idx] -= W[i * w + c] * W[c * w + j];
+        LV(used) = lane < n ? 0 : 1;
+        LV(mycol) = -1;
+    }
+    real_t pmin = kF32 ? real_t(1e30) : real_t(1e300), pmax = real_t(0.0);
+#pragma unroll
+    for (int c = 0; c < NMAX; c++) {
+        if (c < n) {
+            LANES {
+                LV(pv) = LV(used) ? DWBC_QP_INF : -fabs(LV(r)[c]);
+                LV(pk) = lane;
+            }
+            real_t bneg;
+            int p;
+            WAVE_ARGMIN(pv, pk, bneg, p);
+            const real_t best = -bneg;
+            pmin = best < pmin ? best : pmin;
+            pmax = best > pmax ? best : pmax;
+            DWBC_SYNC();  // (the previous pivot row has been read by every lane)
+            LANES {
+                if (lane == p) {
+                    const real_t piv = LV(r)[c];
+                    const real_t inv = piv != real_t(0.0) ? real_t(1.0) / piv : real_t(0.0);
+#pragma unroll
+                    for (int j = 0; j < W2; j++) {
+                        LV(r)[j] *= inv;
+                        W[j] = LV(r)[j];
+                    }
+                    LV(used) = 1;
+                    LV(mycol) = c;
+                }
+            }
+            DWBC_SYNC();
+            LANES {
+                if (lane != p) {
+                    const real_t f = LV(r)[c];
+#pragma unroll
+                    for (int j = 0; j < W2; j++) LV(r)[j] -= f * W[j];
+                    LV(r)[c] = real_t(0.0);
+                }
+            }
         }
-        DWBC_SYNC();
-        for (int i = th.tid; i < n; i += NT)
-            if (i != c) W[i * w + c] = real_t(0.0);
     }
     DWBC_SYNC();
-    for (int idx = th.tid; idx < n * n; idx += NT) {
-        int i = fdn.div(idx), j = idx - i * n;
-        Ai[i * ldi + j] = W[i * w + n + j];
+    LANES {
+        if (lane < n && LV(mycol) >= 0) {
+#pragma unroll
+            for (int j = 0; j < NMAX; j++)
+                if (j < n) Ai[LV(mycol) * ldi + j] = LV(r)[NMAX + j];
+        }
     }
     DWBC_SYNC();
     return pmax > real_t(0.0) ? pmin / pmax : real_t(0.0);
@@ -525,7 +547,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         if (cd > 0) {
             // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan in LDS, as the reference's .inverse() -- 45 k cycles for 18 x 18, and worth them: the
             // scaled register sweep (spd_inverse_scaled) left two three-contact instances in 6000 at 3e-6 .. 5e-6 Nm
-            const real_t cond = gj_inverse_wave<NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
+            const real_t cond = gj_inverse_rows<C, NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
             if (!(cond > real_t(1e-14))) st_contact = 0;
         }
         mmg<C, N, C, 0>(JbT, N, Lam, cd, Y, N, cd, cd, N);            // Jbar^T = Lambda J A^-1 (wbd.cpp:116)
@@ -581,7 +603,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             // squares its condition number: measured 5e-6 Nm on one three-contact instance in 6000, 1e-8 with the direct inverse.)
             mmg<S::K, S::K, M, 0>(Gm, k, JbT + 6, N, Vb, k, k, M, k);  // Jbar[0:k, 6:] Vb
             DWBC_SYNC();
-            const real_t cond = gj_inverse_wave<NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
+            const real_t cond = gj_inverse_rows<S::K, NT>(th, Gm, k, k, Gm, k, L + S::c_s1);
             if (!(cond > real_t(1e-13))) st_contact = 0;
             mmg<M, S::K, S::K, 0>(L + S::NwJw, k, Vb, k, Gm, k, M, k, k);
             DWBC_SYNC();
@@ -666,7 +688,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             mmg<T, N, N, 0>(T1, N, Jt, N, AiNc, N, t, N, N);          // J_t A^-1 N_c
             DWBC_SYNC();
             mmg<T, T, N, 1>(L + S::t_s2, t, T1, N, Jt, N, t, N, t);
-            gj_inverse_wave<NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task (plain inverse, wbd.cpp:210)
+            gj_inverse_rows<T, NT>(th, L + S::t_s2, t, t, Lt, t, L + S::t_s1);  // Lambda_task (plain inverse, wbd.cpp:210)
             mmg<T, M, T, 0>(Q, M, Lt, t, T1 + 6, N, t, t, M);           // Q = (Lambda J A^-1 N_c)[:,6:]
             DWBC_SYNC();
             mmg<T, M, M, 0>(QW, M, Q, M, Winv, M, t, M, M);            // Q W^+
@@ -675,7 +697,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
             DWBC_SYNC();
             // PinvCODWB (wbd.cpp:5-30, 212): the inverse when the block has full rank, the rank-revealing pseudo-inverse otherwise
             // (threshold 1e-6 on the pivots of a column-pivoted QR, as in the product kernels)
-            const real_t piv = gj_inverse_wave<NT>(th, L + S::t_s2, t, t, L + S::t_s3, t, L + S::t_s1);
+            const real_t piv = gj_inverse_rows<T, NT>(th, L + S::t_s2, t, t, L + S::t_s3, t, L + S::t_s1);
             if (!(piv > kCodCheck)) {
                 real_t *cod = L + S::t_cod;
                 pinv_cod_small<NT>(th, L + S::t_s2, t, kCodThreshold, L + S::t_s3, cod, cod + T * T, cod + 2 * T * T, cod + 3 * T * T);
