@@ -20,7 +20,10 @@ wbc.set_state(q); wbc.set_contact(fl); wbc.set_fstar_all(fs)
 for _ in range(3):
     wbc.solve(reduced=True)
 wbc.sync()
-d = wbc.get("diag")
+nb = wbc._L.dwbc_batch_field_bytes(wbc._h, 13)  # (the diagnostic build's record is longer than the product build's)
+d = np.zeros(nb // 4, dtype=np.int32)
+wbc._L.dwbc_batch_get(wbc._h, 13, d.ctypes.data, nb)
+d = d.reshape(B, -1)
 t = np.median(d[:, 74:90].astype(np.float64), axis=0)
 order = [(0, "kin+CRBA"), (1, "A_inv"), (3, "reduced dynamics (J_I_nc, A_R, J_I_nc_inv_T)"), (2, "J_C/Lambda_c/Jbar/AiNc"),
          (4, "A_R_inv N_CR, J_CR_INV_T, G_R"), (5, "NwJw_R"), (6, "W_R^+ + grav"), (7, "J_base_R_kt"), (8, "task-space levels"),
