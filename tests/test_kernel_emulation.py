@@ -38,6 +38,26 @@ def test_emulated_kernel_on_golden_cases(case):
 
 
 @pytest.mark.parametrize("compact", [False, True, "pair"])
+@pytest.mark.parametrize("case", [1, 2])
+def test_redistribution_shortcut_against_the_reference_outputs(case, compact):
+    """the shortcut that skips the contact-redistribution QP when the last task QP's final slacks show none of its rows
+    violated is checked against the REFERENCE's own outputs, not only against the restatement that was changed with it: in both
+    golden cases of tests/dwbc_test.cpp the shortcut fires (no redistribution step in any of the three kernels) and torque_contact_
+    is the reference's (case 2 within the 1e-3 its qpOASES termination leaves, as in test_golden_cases_*).  The fixtures hold no
+    state in which the reference's redistribution moves the forces, so the active branch stays pinned by the two restatements."""
+    q = np.array([cases.Q_CASE[case]], dtype=np.float64)
+    fl = np.array([[1, 1, 0, 0]], dtype=np.uint8)
+    fs = np.array([list(cases.FSTAR_CASE[case][0]) + list(cases.FSTAR_CASE[case][1])])
+    e = Emu(cases.URDF, cases.CONTACTS_4, cases.TASKS_2LEVEL, cases.TAU_LIM)
+    r = e.run(q, fl, fs, compact=compact)
+    assert r["status"][0] == 1
+    assert r["diag"][0, 4 + 4] == 0  # iterations of the redistribution QP (slot kMaxLevels)
+    tc = cases.golden(case, "torque_contact_")[:, 0]
+    assert np.abs(tc).max() > 1.0  # (the contact-null torque is not trivially zero in these states)
+    assert np.abs(r["tau"][0, 2] - tc).max() < (1e-8 if case == 1 else 1e-3)
+
+
+@pytest.mark.parametrize("compact", [False, True, "pair"])
 @pytest.mark.parametrize("cfg", ["ds", "ds_yaw", "ss_L", "ss_R", "mixed", "nolimit", "free"])
 def test_emulated_kernel_vs_oracle_batches(cfg, compact):
     """compact = True: the lean build on the 20 KB LDS map (Lds3 of dwbc_cycle2.h: the throughput kernel of batches beyond four
