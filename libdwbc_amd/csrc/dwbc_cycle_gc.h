@@ -4,7 +4,7 @@
 // The product kernels (dwbc_cycle2.h, dwbc_cycle2p.h) are built around two contacts: 12 contact rows fit the register / LDS budget
 // that gives them their speed, and their small blocks are unrolled for k in {0, 6}.  This kernel is the general statement of the same
 // cycle, one wavefront per instance, every matrix resident in LDS (80 KB: two workgroups per CU) and every loop over run-time
-// dimensions cd = 6 nc, k = cd - 6, t -- correctness first; a batch opts into it with dwbc_batch_set_max_active_contacts(b, 3).
+// dimensions cd = 6 nc, k = cd - 6, t (the dense products on matrix-core tiles, mmg below; the inverses in registers) -- correctness first; a batch opts into it with dwbc_batch_set_max_active_contacts(b, 3).
 // NCC = 3: 18 contact rows, 12 contact-null variables, QPs of up to 18 variables and 33 + 30 = 63 rows -- still one row per lane of
 // the wave-level active-set solver (dwbc_qp_wave.h, instantiated for 18 variables).  Four contacts would need 73 lanes: not built.
 //
@@ -438,12 +438,35 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         // composite inertia: subtree of body i is the contiguous DFS range [i, i + subtree[i])
         real_t *Icm = L + S::k_Ic;
-        for (int idx = th.tid; idx < nb * 10; idx += NT) {
-            const int i = idx / 10, c = idx - i * 10;
-            const int e = i + topo[2 * nb + i];
-            real_t s = real_t(0.0);
-            for (int j = i; j < e; j++) s += Iw[j * 10 + c];
-            Icm[idx] = s;
+        {
+            // inclusive prefix sums over the body order in registers (DPP), Ic[b] = P[b + len_b - 1] - P[b - 1] (dwbc_cycle2p.h: everything is
+            // about the pelvis origin, where the smallest subtree is within 1e3 of the total) -- the sum over each subtree, one dependent
+            // LDS read per body of it, was 8 k cycles of this stage
+            static_assert(NB <= 64, "one body per lane");
+            DWBC_LANE_DECL;
+            PLA(real_t, pf, 10);
+            PL(int, len);
+            LANES {
+                const int bi = lane < nb ? lane : 0;
+                LV(len) = lane < nb ? topo[2 * nb + bi] : 1;
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    const real_t v_ = Iw[bi * 10 + c];
+                    LV(pf)[c] = lane < nb ? v_ : real_t(0.0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 10; c++) WAVE_PREFIX_A(pf, c);
+            LANES {
+                int e_ = lane + LV(len) - 1;
+                e_ = e_ < 63 ? e_ : 63;
+                const int s_ = lane > 0 ? lane - 1 : 0;
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    const real_t hi_ = SHFLA(pf, c, e_), lo_ = SHFLA(pf, c, s_);
+                    if (lane < nb) Icm[lane * 10 + c] = hi_ - (lane > 0 ? lo_ : real_t(0.0));
+                }
+            }
         }
         // motion axes S_j = [omega; v_O] about O
         real_t *Sm = L + S::k_S, *Fm = L + S::k_F;
@@ -545,7 +568,7 @@ DWBC_DEV void cycle_instance_gc(Thr th, const Setup &su, const BatchIO &io, int 
         DWBC_SYNC();
         mmg<C, C, N, 1>(L + S::c_s2, cd, Y, N, JC, N, cd, N, cd);     // J A^-1 J^T
         if (cd > 0) {
-            // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan in LDS, as the reference's .inverse() -- 45 k cycles for 18 x 18, and worth them: the
+            // Lambda_c (wbd.cpp:115): pivoted Gauss-Jordan, as the reference's .inverse() -- worth its pivot search: the
             // scaled register sweep (spd_inverse_scaled) left two three-contact instances in 6000 at 3e-6 .. 5e-6 Nm
             const real_t cond = gj_inverse_rows<C, NT>(th, L + S::c_s2, cd, cd, Lam, cd, L + S::c_s1);
             if (!(cond > real_t(1e-14))) st_contact = 0;
